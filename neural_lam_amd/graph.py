@@ -1,0 +1,394 @@
+"""Graph assets for the message-passing hot path: generation, on-disk format, CSR.
+
+Host-side logic (numpy/scipy/torch CPU); nothing here touches the GPU.
+
+* ``create_regular_grid_graph`` restates the *algorithm* of the reference's
+  offline generator ``neural_lam/create_graph.py:356-862`` for regular grids in
+  vectorised numpy (the reference walks networkx graphs edge by edge); the edge
+  *sets* and features are identical, the edge *order* is sender-major with
+  ascending receivers (the reference's order is networkx insertion order; the
+  model is invariant to a consistent permutation of edges).
+* ``save_graph`` / ``load_graph`` speak the reference's graph storage spec
+  v0.1.0 (``docs/graph_storage_spec.md``; loader semantics of
+  ``neural_lam/utils/graph.py:146-422``): int64 ``[2,E]`` edge indices that are
+  zero-based per node set, float32 ``[E,3] = [len, vdiff_x, vdiff_y]`` features,
+  lists per level, ``metainfo.yaml``.
+* ``EdgeCSR`` is the MI355X-side layout: receiver-sorted (CSR) edge order for
+  coalesced segment reduction, plus the sender-sorted (CSC) view the backward
+  pass needs, all int32.
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+import torch
+import yaml
+from scipy.spatial import KDTree  # same class + leafsize as the reference: 4-NN ties break alike
+
+GRAPH_SPEC_VERSION = "0.1.0"  # create_graph.py:24
+METAINFO_FILENAME = "metainfo.yaml"  # create_graph.py:23
+DM_SCALE = 0.67  # create_graph.py:698
+MESH_CHILDREN = 3  # create_graph.py:436 (nx)
+
+
+# --------------------------------------------------------------------------
+# generation
+# --------------------------------------------------------------------------
+def _mesh_level_positions(xy: np.ndarray, n: int) -> np.ndarray:
+    """Cell-centre node positions of an n x n mesh level (create_graph.py:296-309)."""
+    xm, xM = np.amin(xy[:, :, 0][:, 0]), np.amax(xy[:, :, 0][:, 0])
+    ym, yM = np.amin(xy[:, :, 1][0, :]), np.amax(xy[:, :, 1][0, :])
+    dx = (xM - xm) / n
+    dy = (yM - ym) / n
+    lx = np.linspace(xm + dx / 2, xM - dx / 2, n)
+    ly = np.linspace(ym + dy / 2, yM - dy / 2, n)
+    gx, gy = np.meshgrid(lx, ly, indexing="ij")
+    return np.stack([gx, gy], axis=-1)  # (n, n, 2)
+
+
+_NEIGH8 = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]
+
+
+def _level_edges(pos: np.ndarray):
+    """8-neighbour bidirectional edges of one n x n level (create_graph.py:306-329).
+
+    Returns (send_ij, rec_ij, length, vdiff) with vdiff = pos[sender]-pos[receiver].
+    """
+    n = pos.shape[0]
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    send, rec = [], []
+    for di, dj in _NEIGH8:
+        ri, rj = ii + di, jj + dj
+        ok = (ri >= 0) & (ri < n) & (rj >= 0) & (rj < n)
+        send.append(np.stack([ii[ok], jj[ok]], axis=-1))
+        rec.append(np.stack([ri[ok], rj[ok]], axis=-1))
+    send = np.concatenate(send)
+    rec = np.concatenate(rec)
+    vdiff = pos[send[:, 0], send[:, 1]] - pos[rec[:, 0], rec[:, 1]]
+    length = np.sqrt(np.sum(vdiff**2, axis=1))
+    return send, rec, length, vdiff
+
+
+def _sender_major(send_idx, rec_idx, length, vdiff):
+    order = np.lexsort((rec_idx, send_idx))
+    ei = torch.from_numpy(np.stack([send_idx[order], rec_idx[order]]).astype(np.int64))
+    feat = torch.from_numpy(
+        np.concatenate([length[order, None], vdiff[order]], axis=1).astype(np.float32)
+    )
+    return ei, feat
+
+
+def mesh_level_sizes(nx_grid: int, ny_grid: int, n_max_levels: int | None = None):
+    """Side lengths of the mesh levels (create_graph.py:436-453)."""
+    nlev = int(np.log(max(nx_grid, ny_grid)) / np.log(MESH_CHILDREN))
+    nleaf = MESH_CHILDREN**nlev
+    mesh_levels = nlev - 1
+    if n_max_levels:
+        mesh_levels = min(mesh_levels, n_max_levels)
+    return [int(nleaf / (MESH_CHILDREN**lev)) for lev in range(1, mesh_levels + 1)]
+
+
+def create_regular_grid_graph(
+    xy: np.ndarray, n_max_levels: int | None = None, hierarchical: bool = False
+) -> dict:
+    """Build all graph components for grid coordinates ``xy`` of shape (Nx, Ny, 2).
+
+    Returns the *raw* (un-normalised, on-disk) tensors keyed like the files the
+    reference writes (create_graph.py:366-410).
+    """
+    xy = np.asarray(xy, dtype=np.float64)
+    Nx, Ny = xy.shape[:2]
+    sizes = mesh_level_sizes(Nx, Ny, n_max_levels)
+    if not sizes:
+        raise ValueError(f"grid {Nx}x{Ny} too small for a mesh (needs >= 9 points on a side)")
+    pos_levels = [_mesh_level_positions(xy, n) for n in sizes]
+    out: dict = {}
+
+    if hierarchical:
+        m2m_ei, m2m_feat, mesh_pos = [], [], []
+        for pos in pos_levels:
+            n = pos.shape[0]
+            s, r, length, vd = _level_edges(pos)
+            ei, feat = _sender_major(s[:, 0] * n + s[:, 1], r[:, 0] * n + r[:, 1], length, vd)
+            m2m_ei.append(ei)
+            m2m_feat.append(feat)
+            mesh_pos.append(torch.from_numpy(pos.reshape(-1, 2).astype(np.float32)))
+        up_ei, up_feat, down_ei, down_feat = [], [], [], []
+        for lower, upper in zip(pos_levels[:-1], pos_levels[1:]):
+            lo = lower.reshape(-1, 2)
+            up = upper.reshape(-1, 2)
+            # each lower node -> its single nearest upper node (create_graph.py:488-509)
+            _, nearest = KDTree(up).query(lo, 1)
+            vd = lo - up[nearest]
+            length = np.sqrt(np.sum(vd**2, axis=1))
+            ei, feat = _sender_major(np.arange(lo.shape[0]), nearest, length, vd)
+            up_ei.append(ei)
+            up_feat.append(feat)
+            # down = reversed up with negated vdiff (create_graph.py:573-577)
+            down_ei.append(torch.stack((ei[1], ei[0]), dim=0))
+            dfeat = feat.clone()
+            dfeat[:, 1:] = -dfeat[:, 1:]
+            down_feat.append(dfeat)
+        out.update(
+            mesh_up_edge_index=up_ei,
+            mesh_up_features=up_feat,
+            mesh_down_edge_index=down_ei,
+            mesh_down_features=down_feat,
+        )
+        bottom_pos = pos_levels[0].reshape(-1, 2)
+    else:
+        # multiscale: coarser levels live on the fine nodes [1::3, 1::3]
+        # (create_graph.py:646-659); node id = i * n0 + j after sorting (:667-669)
+        n0 = sizes[0]
+        s_all, r_all, len_all, vd_all = [], [], [], []
+        node_pos = pos_levels[0].copy()
+        for lev, pos in enumerate(pos_levels):
+            stride = MESH_CHILDREN**lev
+            off = (stride - 1) // 2
+            s, r, length, vd = _level_edges(pos)
+            s_all.append((off + stride * s[:, 0]) * n0 + off + stride * s[:, 1])
+            r_all.append((off + stride * r[:, 0]) * n0 + off + stride * r[:, 1])
+            len_all.append(length)
+            vd_all.append(vd)
+            if lev > 0:
+                # networkx.compose lets the coarser level's "pos" win (:659)
+                n = pos.shape[0]
+                idx = off + stride * np.arange(n)
+                node_pos[np.ix_(idx, idx)] = pos
+        ei, feat = _sender_major(
+            np.concatenate(s_all), np.concatenate(r_all), np.concatenate(len_all), np.concatenate(vd_all)
+        )
+        m2m_ei, m2m_feat = [ei], [feat]
+        mesh_pos = [torch.from_numpy(node_pos.reshape(-1, 2).astype(np.float32))]
+        bottom_pos = node_pos.reshape(-1, 2)
+
+    out.update(m2m_edge_index=m2m_ei, m2m_features=m2m_feat, mesh_features=mesh_pos)
+
+    # ---- grid2mesh: grid nodes within 0.67*dm of each bottom mesh node (:698-758)
+    n0 = sizes[0]
+    p00 = bottom_pos[0]  # node (0, 0, 0)
+    p10 = bottom_pos[n0]  # node (0, 1, 0)
+    dm = np.sqrt(np.sum((p10 - p00) ** 2))
+    grid_pos = xy.reshape(-1, 2)  # flat index i * Ny + j
+    kdt_g = KDTree(grid_pos)
+    neigh = kdt_g.query_ball_point(bottom_pos, dm * DM_SCALE)
+    rec = np.repeat(np.arange(bottom_pos.shape[0]), [len(x) for x in neigh])
+    send = np.concatenate([np.asarray(x, dtype=np.int64) for x in neigh])
+    vd = grid_pos[send] - bottom_pos[rec]
+    out["g2m_edge_index"], out["g2m_features"] = _sender_major(
+        send, rec, np.sqrt(np.sum(vd**2, axis=1)), vd
+    )
+
+    # ---- mesh2grid: 4 nearest bottom mesh nodes of each grid node (:780-793)
+    _, nn4 = KDTree(bottom_pos).query(grid_pos, 4)
+    rec = np.repeat(np.arange(grid_pos.shape[0]), 4)
+    send = nn4.reshape(-1)
+    vd = bottom_pos[send] - grid_pos[rec]
+    out["m2g_edge_index"], out["m2g_features"] = _sender_major(
+        send, rec, np.sqrt(np.sum(vd**2, axis=1)), vd
+    )
+    return out
+
+
+def regular_grid_xy(nx_grid: int, ny_grid: int, spacing: float = 2500.0) -> np.ndarray:
+    """xy[i, j] = (spacing*i, spacing*j): the synthetic MEPS-shaped grid."""
+    ii, jj = np.meshgrid(np.arange(nx_grid), np.arange(ny_grid), indexing="ij")
+    return np.stack([ii * spacing, jj * spacing], axis=-1).astype(np.float64)
+
+
+# --------------------------------------------------------------------------
+# on-disk format
+# --------------------------------------------------------------------------
+_LIST_KEYS = ("m2m", "mesh_up", "mesh_down")
+
+
+def save_graph(graph_dir: str | os.PathLike, raw: dict) -> None:
+    """Write the reference's file set (create_graph.py:132-166, 688-690, 857-862)."""
+    graph_dir = Path(graph_dir)
+    graph_dir.mkdir(parents=True, exist_ok=True)
+    for name in ("g2m", "m2g"):
+        torch.save(raw[f"{name}_edge_index"], graph_dir / f"{name}_edge_index.pt")
+        torch.save(raw[f"{name}_features"], graph_dir / f"{name}_features.pt")
+    for name in _LIST_KEYS:
+        if f"{name}_edge_index" in raw:
+            torch.save(list(raw[f"{name}_edge_index"]), graph_dir / f"{name}_edge_index.pt")
+            torch.save(list(raw[f"{name}_features"]), graph_dir / f"{name}_features.pt")
+    torch.save(list(raw["mesh_features"]), graph_dir / "mesh_features.pt")
+    with open(graph_dir / METAINFO_FILENAME, "w", encoding="utf-8") as fp:
+        yaml.dump({"spec_version": GRAPH_SPEC_VERSION}, fp)
+
+
+def read_graph_files(graph_dir: str | os.PathLike) -> dict:
+    graph_dir = Path(graph_dir)
+
+    def ld(fn):
+        return torch.load(graph_dir / fn, map_location="cpu", weights_only=True)
+
+    raw = {
+        "mesh_features": ld("mesh_features.pt"),
+        "m2m_edge_index": ld("m2m_edge_index.pt"),
+        "m2m_features": ld("m2m_features.pt"),
+        "g2m_edge_index": ld("g2m_edge_index.pt"),
+        "g2m_features": ld("g2m_features.pt"),
+        "m2g_edge_index": ld("m2g_edge_index.pt"),
+        "m2g_features": ld("m2g_features.pt"),
+    }
+    if (graph_dir / "mesh_up_edge_index.pt").exists():
+        for name in ("mesh_up", "mesh_down"):
+            raw[f"{name}_edge_index"] = ld(f"{name}_edge_index.pt")
+            raw[f"{name}_features"] = ld(f"{name}_features.pt")
+    meta = graph_dir / METAINFO_FILENAME
+    if not meta.exists():
+        raise ValueError(
+            f"{meta} missing: only graph spec {GRAPH_SPEC_VERSION} is supported "
+            "(the reference's legacy pre-spec format is out of scope)"
+        )
+    spec = (yaml.safe_load(meta.read_text(encoding="utf-8")) or {}).get("spec_version")
+    if spec != GRAPH_SPEC_VERSION:
+        raise ValueError(f"Unsupported graph spec version {spec!r} in {METAINFO_FILENAME}")
+    return raw
+
+
+def normalise_graph(raw: dict, mesh_node_features_scaling: float):
+    """Load-time normalisation of utils/graph.py:291-303 (mesh coords / max grid
+    span) and :343-350 (edge features / longest m2m edge); flat graphs unwrap
+    level 0 (:399-408).  Returns (hierarchical, dict of tensors / lists)."""
+    if mesh_node_features_scaling == 0:
+        mesh_node_features_scaling = 1.0
+    mesh = [m.clone().to(torch.float32) for m in raw["mesh_features"]]
+    for m in mesh:
+        m[:, :2] /= mesh_node_features_scaling
+    m2m_ei = [e.clone() for e in raw["m2m_edge_index"]]
+    hierarchical = len(m2m_ei) > 1
+    longest = max(torch.max(f[:, 0]) for f in raw["m2m_features"])
+    out = {
+        "g2m_edge_index": raw["g2m_edge_index"].clone(),
+        "m2g_edge_index": raw["m2g_edge_index"].clone(),
+        "g2m_features": raw["g2m_features"] / longest,
+        "m2g_features": raw["m2g_features"] / longest,
+    }
+    # BufferList.__itruediv__ multiplies by the reciprocal (utils/buffer_list.py),
+    # while g2m/m2g use a true division (utils/graph.py:343-350): keep both.
+    recip = 1.0 / longest
+    m2m_feat = [f * recip for f in raw["m2m_features"]]
+    assert len(m2m_feat) == len(m2m_ei) == len(mesh), "Inconsistent number of levels in mesh"
+    if hierarchical:
+        out.update(
+            m2m_edge_index=m2m_ei,
+            m2m_features=m2m_feat,
+            mesh_static_features=mesh,
+            mesh_up_edge_index=[e.clone() for e in raw["mesh_up_edge_index"]],
+            mesh_down_edge_index=[e.clone() for e in raw["mesh_down_edge_index"]],
+            mesh_up_features=[f * recip for f in raw["mesh_up_features"]],
+            mesh_down_features=[f * recip for f in raw["mesh_down_features"]],
+        )
+    else:
+        out.update(
+            m2m_edge_index=m2m_ei[0],
+            m2m_features=m2m_feat[0],
+            mesh_static_features=mesh[0],
+            mesh_up_edge_index=[],
+            mesh_down_edge_index=[],
+            mesh_up_features=[],
+            mesh_down_features=[],
+        )
+    return hierarchical, out
+
+
+def load_graph(graph_dir, mesh_node_features_scaling: float):
+    """Mirror of ``utils.load_graph`` (utils/graph.py:146) for spec-0.1.0 graphs."""
+    return normalise_graph(read_graph_files(graph_dir), mesh_node_features_scaling)
+
+
+# --------------------------------------------------------------------------
+# MI355X-side edge layout
+# --------------------------------------------------------------------------
+@dataclass
+class EdgeCSR:
+    """Receiver-sorted edge list + sender-sorted view, int32, on one device.
+
+    position p in [0, E) is the CSR (receiver-major, stable) position of original
+    edge ``perm[p]``.  ``rowptr[r]:rowptr[r+1]`` are receiver r's positions.
+    ``cperm`` lists CSR positions grouped by sender (``colptr`` delimits them),
+    which turns the backward scatter-by-sender into another segment reduction.
+    ``tiles`` partitions the receivers into runs of whole receivers whose edges
+    fit one workgroup tile ("tile schedule").
+    """
+
+    num_send: int
+    num_rec: int
+    num_edges: int
+    perm: torch.Tensor  # (E,) original edge id at CSR position p
+    send: torch.Tensor  # (E,) sender of CSR position p
+    rec: torch.Tensor  # (E,) receiver of CSR position p
+    rowptr: torch.Tensor  # (N_r + 1,)
+    colptr: torch.Tensor  # (N_s + 1,)
+    cperm: torch.Tensor  # (E,) CSR positions sorted by sender (stable)
+    inv_deg: torch.Tensor  # (N_r,) 1 / max(in_degree, 1)  float32
+    max_in_degree: int
+
+    def to(self, device):
+        kw = {}
+        for k, v in self.__dict__.items():
+            kw[k] = v.to(device) if torch.is_tensor(v) else v
+        return EdgeCSR(**kw)
+
+
+def build_edge_csr(edge_index: torch.Tensor, num_send: int | None = None, num_rec: int | None = None) -> EdgeCSR:
+    """edge_index: int64 (2, E), row 0 senders, row 1 receivers, zero-based per node set.
+
+    ``num_rec`` defaults to ``edge_index[1].max() + 1`` exactly like
+    ``InteractionNet.__init__`` (gnn_layers.py:73).
+    """
+    assert edge_index.dim() == 2 and edge_index.shape[0] == 2
+    ei = edge_index.detach().cpu().to(torch.int64)
+    E = ei.shape[1]
+    if E == 0:
+        raise ValueError("edge_index must contain at least one edge")
+    if num_rec is None:
+        num_rec = int(ei[1].max()) + 1
+    if num_send is None:
+        num_send = int(ei[0].max()) + 1
+    if E >= 2**31 or num_send >= 2**31 or num_rec >= 2**31:
+        raise ValueError("int32 index space exceeded")
+    perm = torch.argsort(ei[1], stable=True)
+    send = ei[0][perm]
+    rec = ei[1][perm]
+    deg = torch.bincount(rec, minlength=num_rec)
+    rowptr = torch.zeros(num_rec + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    cperm = torch.argsort(send, stable=True)
+    sdeg = torch.bincount(send, minlength=num_send)
+    colptr = torch.zeros(num_send + 1, dtype=torch.int64)
+    colptr[1:] = torch.cumsum(sdeg, 0)
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    return EdgeCSR(
+        num_send=num_send,
+        num_rec=num_rec,
+        num_edges=E,
+        perm=i32(perm),
+        send=i32(send),
+        rec=i32(rec),
+        rowptr=i32(rowptr),
+        colptr=i32(colptr),
+        cperm=i32(cperm),
+        inv_deg=(1.0 / deg.clamp(min=1).to(torch.float32)).contiguous(),
+        max_in_degree=int(deg.max()),
+    )
+
+
+def graph_summary(raw: dict) -> dict:
+    """Sizes used in DESIGN.md / bench config strings."""
+    s = {
+        "mesh_nodes": [int(m.shape[0]) for m in raw["mesh_features"]],
+        "m2m_edges": [int(e.shape[1]) for e in raw["m2m_edge_index"]],
+        "g2m_edges": int(raw["g2m_edge_index"].shape[1]),
+        "m2g_edges": int(raw["m2g_edge_index"].shape[1]),
+    }
+    if "mesh_up_edge_index" in raw:
+        s["up_edges"] = [int(e.shape[1]) for e in raw["mesh_up_edge_index"]]
+    return s

@@ -1,0 +1,218 @@
+"""Generate tests/golden/*.pt by running the REFERENCE's own code.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+Every tensor stored under key "ref_*" was computed by the reference's files
+(gnn_layers.py, utils/networks.py, utils/graph.py, create_graph.py,
+models/step_predictors/**, models/forecasters/autoregressive.py, metrics.py)
+imported unmodified through tests/golden/ref_harness.py.  The only non-reference
+code in the loop is the torch_geometric stand-in of ref_harness.py (PyG 2.3.1 is
+not installed and there is no network) and the duck-typed SyntheticDatastore.
+"""
+import sys
+import tempfile
+from pathlib import Path
+
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent.parent))
+
+import ref_harness as rh  # noqa: E402
+from neural_lam_amd import graph as G  # noqa: E402
+from neural_lam_amd.datastore import SyntheticDatastore  # noqa: E402
+
+NOTE = (
+    "ref_* tensors computed by /root/reference code (mllam/neural-lam) on top of a "
+    "torch_geometric stand-in (tests/golden/ref_harness.py); fp32 CPU, torch "
+    + torch.__version__
+)
+
+
+def rand_edge_index(ns, nr, e, seed, force_max=True):
+    g = torch.Generator().manual_seed(seed)
+    s = torch.randint(0, ns, (e,), generator=g)
+    r = torch.randint(0, nr, (e,), generator=g)
+    if force_max:
+        r[-1] = nr - 1
+        s[-1] = ns - 1
+    return torch.stack([s, r])
+
+
+def layer_case(ref, name, cls_name, ns, nr, e, d, batch, seed, skip_rec=None, **kw):
+    ei = rand_edge_index(ns, nr, e, seed)
+    if skip_rec is not None:  # leave a receiver below the max without edges
+        ei[1][ei[1] == skip_rec] = (skip_rec + 1) % nr
+        ei[1][-1] = nr - 1
+    torch.manual_seed(seed + 1)
+    net = getattr(ref.gnn_layers, cls_name)(ei, d, **kw)
+    # non-trivial LayerNorm affine so the parameters are pinned too
+    with torch.no_grad():
+        for n_, p in net.named_parameters():
+            if n_.endswith("3.weight"):
+                p.add_(0.1 * torch.randn_like(p))
+            if n_.endswith("3.bias"):
+                p.add_(0.1 * torch.randn_like(p))
+    shape = (lambda n: (n, d)) if batch is None else (lambda n: (batch, n, d))
+    g = torch.Generator().manual_seed(seed + 2)
+    send = torch.randn(shape(ns), generator=g, requires_grad=True)
+    rec = torch.randn(shape(nr), generator=g, requires_grad=True)
+    edge = torch.randn(shape(e), generator=g, requires_grad=True)
+    out = net(send, rec, edge)
+    outs = out if isinstance(out, tuple) else (out,)
+    # fixed random cotangents -> scalar
+    cots = [torch.randn(o.shape, generator=g) for o in outs]
+    loss = sum((o * c).sum() for o, c in zip(outs, cots))
+    loss.backward()
+    case = {
+        "cls": cls_name,
+        "kwargs": kw,
+        "d": d,
+        "edge_index": ei.to(torch.int32),
+        "state_dict": {k: v.detach().clone() for k, v in net.state_dict().items()},
+        "send": send.detach(),
+        "rec": rec.detach(),
+        "edge": edge.detach(),
+        "cotangents": cots,
+        "ref_out": [o.detach() for o in outs],
+        "ref_grad_send": send.grad,
+        "ref_grad_rec": rec.grad,
+        "ref_grad_edge": edge.grad,
+        "ref_grad_params": {k: p.grad.clone() for k, p in net.named_parameters()},
+    }
+    print(f"  layer case {name}: E={e} d={d} out={[tuple(o.shape) for o in outs]}")
+    return case
+
+
+def make_layers(ref):
+    cases = {}
+    cases["inet_sum_update_d8"] = layer_case(ref, "inet_sum_update_d8", "InteractionNet", 5, 4, 10, 8, None, 0)
+    cases["inet_mean_noupdate_b2_d8"] = layer_case(
+        ref, "inet_mean_noupdate_b2_d8", "InteractionNet", 7, 6, 20, 8, 2, 10, update_edges=False, aggr="mean"
+    )
+    cases["propnet_b2_d8"] = layer_case(ref, "propnet_b2_d8", "PropagationNet", 6, 5, 17, 8, 2, 20)
+    cases["propnet_noupdate_d16"] = layer_case(
+        ref, "propnet_noupdate_d16", "PropagationNet", 9, 4, 30, 16, None, 25, update_edges=False
+    )
+    cases["inet_chunked_d8"] = layer_case(
+        ref, "inet_chunked_d8", "InteractionNet", 6, 6, 12, 8, 2, 30, edge_chunk_sizes=[5, 7], aggr_chunk_sizes=[2, 4]
+    )
+    cases["inet_100to10_gap_d16"] = layer_case(
+        ref, "inet_100to10_gap_d16", "InteractionNet", 100, 10, 200, 16, None, 40, skip_rec=3
+    )
+    cases["inet_sum_update_b2_d64"] = layer_case(ref, "inet_sum_update_b2_d64", "InteractionNet", 50, 40, 300, 64, 2, 50)
+    cases["inet_highdeg_d32"] = layer_case(
+        ref, "inet_highdeg_d32", "InteractionNet", 300, 3, 500, 32, None, 60, aggr="mean"
+    )
+    cases["inet_hidden12_d8"] = layer_case(ref, "inet_hidden12_d8", "InteractionNet", 5, 4, 10, 8, None, 70, hidden_dim=8)
+    torch.save({"note": NOTE, "cases": cases}, HERE / "layers.pt")
+
+
+def compress_graph(raw):
+    out = {}
+    for k, v in raw.items():
+        if isinstance(v, list):
+            out[k] = [t.to(torch.int32) if t.dtype == torch.int64 else t for t in v]
+        else:
+            out[k] = v.to(torch.int32) if v.dtype == torch.int64 else v
+    return out
+
+
+def model_case(ref, name, model_name, ds_kwargs, graph_kwargs, model_kwargs, B, T, seed):
+    tmp = tempfile.mkdtemp()
+    ds = SyntheticDatastore(root_path=tmp, **ds_kwargs)
+    gdir = Path(tmp) / "graph" / "g"
+    ref.create_graph.create_graph(str(gdir), ds.get_xy("state"), **graph_kwargs)
+    raw = G.read_graph_files(gdir)
+    torch.manual_seed(seed)
+    cls = getattr(ref, model_name)
+    predictor = cls(ds, graph_name="g", **model_kwargs)
+    forecaster = ref.ARForecaster(predictor, ds)
+    n_state, n_forc = ds.get_num_data_vars("state"), ds.get_num_data_vars("forcing")
+    N = ds.num_grid_points
+    g = torch.Generator().manual_seed(seed + 1)
+    init = torch.randn(B, 2, N, n_state, generator=g)
+    target = torch.randn(B, T, N, n_state, generator=g)
+    forcing = torch.randn(B, T, N, n_forc * 3, generator=g)
+    if model_kwargs.get("output_clamping_lower") or model_kwargs.get("output_clamping_upper"):
+        # states must start inside the clamp range for the inverse maps to be meaningful
+        init = init.abs() * 0.1 + 0.2
+        target = target.abs() * 0.1 + 0.2
+    # reference per_var_std (module.py:158-176, uniform weights) and interior mask
+    st = ds.get_standardization_dataarray("state")
+    diff_std = torch.tensor(st.state_diff_std_standardized.values, dtype=torch.float32)
+    w = torch.tensor([1.0 / n_state] * n_state, dtype=torch.float32)
+    per_var_std = diff_std / torch.sqrt(w)
+    interior = (1.0 - torch.tensor(ds.boundary_mask.values, dtype=torch.float32)).to(torch.bool)
+    pred, loss = rh.ref_training_loss(ref, forecaster, (init, target, forcing), per_var_std, interior)
+    loss.backward()
+    # reference-loaded (normalised) graph tensors, straight from the module's buffers
+    names = [
+        "g2m_edge_index", "m2g_edge_index", "m2m_edge_index", "mesh_up_edge_index", "mesh_down_edge_index",
+        "g2m_features", "m2g_features", "m2m_features", "mesh_up_features", "mesh_down_features",
+        "mesh_static_features",
+    ]
+    loaded = {}
+    for n_ in names:
+        v = getattr(predictor, n_)
+        loaded[n_] = v.clone() if torch.is_tensor(v) else [t.clone() for t in v]
+    one_step, one_std = predictor(init[:, 1], init[:, 0], forcing[:, 0])
+    case = {
+        "note": NOTE,
+        "model": model_name,
+        "ds_kwargs": ds_kwargs,
+        "graph_kwargs": graph_kwargs,
+        "model_kwargs": model_kwargs,
+        "ref_graph_raw": compress_graph(raw),
+        "ref_graph_loaded": compress_graph(loaded),
+        "ref_hierarchical": bool(predictor.hierarchical),
+        "state_dict": {k: v.detach().clone() for k, v in forecaster.state_dict().items()},
+        "init": init,
+        "target": target,
+        "forcing": forcing,
+        "ref_one_step": one_step.detach(),
+        "ref_one_std": None if one_std is None else one_std.detach(),
+        "ref_prediction": pred.detach(),
+        "ref_loss": loss.detach(),
+        "ref_grads": {k: p.grad.clone() for k, p in forecaster.named_parameters()},
+    }
+    torch.save(case, HERE / f"{name}.pt")
+    print(f"  model case {name}: loss={float(loss):.6f} params={sum(p.numel() for p in forecaster.parameters())}")
+
+
+def main():
+    ref = rh.load_reference()
+    make_layers(ref)
+    ds_small = dict(nx=30, ny=27, num_state=5, num_forcing=2, num_static=1, boundary="random", seed=3,
+                    state_stats={"state_mean": [0.1, -0.2, 0.3, 0.0, 0.5], "state_std": [1.0, 2.0, 0.5, 1.5, 1.0],
+                                 "state_diff_mean_standardized": [0.01, -0.02, 0.0, 0.03, 0.0],
+                                 "state_diff_std_standardized": [0.5, 0.8, 1.0, 1.2, 0.9]})
+    model_case(ref, "graphlam_30x27", "GraphLAM", ds_small, dict(n_max_levels=None, hierarchical=False),
+               dict(hidden_dim=16, hidden_layers=1, processor_layers=2), B=2, T=2, seed=42)
+    model_case(ref, "graphlam_30x27_variants", "GraphLAM", ds_small, dict(n_max_levels=1, hierarchical=False),
+               dict(hidden_dim=8, hidden_layers=1, processor_layers=1, mesh_aggr="mean", output_std=True,
+                    g2m_gnn_type="PropagationNet", m2g_gnn_type="PropagationNet",
+                    output_clamping_lower={"state_var_0": 0.0, "state_var_2": 0.0},
+                    output_clamping_upper={"state_var_2": 1.0, "state_var_3": 5.0}), B=1, T=3, seed=43)
+    ds_hi = dict(nx=81, ny=30, num_state=5, num_forcing=2, num_static=1, boundary="frame", boundary_width=4, seed=5)
+    model_case(ref, "hilam_81x30", "HiLAM", ds_hi, dict(n_max_levels=3, hierarchical=True),
+               dict(hidden_dim=8, hidden_layers=1, processor_layers=1), B=1, T=1, seed=44)
+    model_case(ref, "hilam_parallel_81x30", "HiLAMParallel", ds_hi, dict(n_max_levels=3, hierarchical=True),
+               dict(hidden_dim=8, hidden_layers=1, processor_layers=1, mesh_up_gnn_type="PropagationNet"), B=1, T=1, seed=45)
+    # reference generator edge counts at MEPS size (slow pure-python path, run once)
+    if "--meps" in sys.argv:
+        tmp = tempfile.mkdtemp()
+        xy = G.regular_grid_xy(238, 268)
+        ref.create_graph.create_graph(tmp + "/ms", xy, n_max_levels=None, hierarchical=False)
+        ref.create_graph.create_graph(tmp + "/hi", xy, n_max_levels=3, hierarchical=True)
+        sizes = {"multiscale": G.graph_summary(G.read_graph_files(tmp + "/ms")),
+                 "hierarchical": G.graph_summary(G.read_graph_files(tmp + "/hi"))}
+        torch.save({"note": NOTE, "ref_meps_graph_sizes": sizes}, HERE / "meps_graph_sizes.pt")
+        print(sizes)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+"""Graph generator / loader / CSR host logic against the reference's own
+create_graph + load_graph outputs stored in the golden fixtures.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import graph_from_case, load_golden
+from neural_lam_amd import graph as G
+from neural_lam_amd.datastore import SyntheticDatastore
+
+
+def _edge_dict(ei, feat):
+    return {(int(s), int(r)): feat[k] for k, (s, r) in enumerate(ei.t().tolist())}
+
+
+def _cmp_edges(ei_a, f_a, ei_b, f_b):
+    da, db = _edge_dict(ei_a, f_a), _edge_dict(ei_b, f_b)
+    assert da.keys() == db.keys()
+    fa = torch.stack([da[k] for k in sorted(da)])
+    fb = torch.stack([db[k] for k in sorted(da)])
+    assert torch.allclose(fa, fb, rtol=1e-6, atol=1e-6 * float(fb.abs().max()))
+
+
+@pytest.mark.parametrize("name", ["graphlam_30x27", "graphlam_30x27_variants", "hilam_81x30"])
+def test_generator_matches_reference_create_graph(name, tmp_path):
+    case = load_golden(name)
+    ds = SyntheticDatastore(root_path=tmp_path, **case["ds_kwargs"])
+    mine = G.create_regular_grid_graph(ds.get_xy("state"), **case["graph_kwargs"])
+    ref = graph_from_case(case, "ref_graph_raw")
+    names = ["g2m", "m2g"]
+    for n in names:
+        _cmp_edges(mine[f"{n}_edge_index"], mine[f"{n}_features"], ref[f"{n}_edge_index"], ref[f"{n}_features"])
+    list_names = ["m2m"] + (["mesh_up", "mesh_down"] if case["graph_kwargs"]["hierarchical"] else [])
+    for n in list_names:
+        assert len(mine[f"{n}_edge_index"]) == len(ref[f"{n}_edge_index"])
+        for l in range(len(ref[f"{n}_edge_index"])):
+            _cmp_edges(mine[f"{n}_edge_index"][l], mine[f"{n}_features"][l], ref[f"{n}_edge_index"][l], ref[f"{n}_features"][l])
+    for a, b in zip(mine["mesh_features"], ref["mesh_features"]):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["graphlam_30x27", "hilam_81x30"])
+def test_save_load_roundtrip_matches_reference_load_graph(name, tmp_path):
+    """Reference-written raw tensors -> our save_graph/load_graph == the tensors the
+    reference's own utils.load_graph registered on its model."""
+    case = load_golden(name)
+    ds = SyntheticDatastore(root_path=tmp_path, **case["ds_kwargs"])
+    raw = graph_from_case(case, "ref_graph_raw")
+    G.save_graph(tmp_path / "graph" / "g", raw)
+    ext = ds.get_xy_extent("state")
+    span = max(ext[1] - ext[0], ext[3] - ext[2])  # graph/base.py:113-117
+    hier, loaded = G.load_graph(tmp_path / "graph" / "g", span)
+    assert hier == case["ref_hierarchical"]
+    ref = graph_from_case(case, "ref_graph_loaded")
+    for k, v in ref.items():
+        mine = loaded[k]
+        if isinstance(v, list):
+            assert len(mine) == len(v), k
+            for a, b in zip(mine, v):
+                assert torch.equal(a, b), k  # bit-exact: same fp32 ops as the reference loader
+        else:
+            assert torch.equal(mine, v), k
+
+
+def test_meps_sizes_match_reference_generator():
+    """The reference's generator on the 238x268 grid (recorded once by make_golden.py --meps)."""
+    ref = load_golden("meps_graph_sizes")["ref_meps_graph_sizes"]
+    xy = G.regular_grid_xy(238, 268)
+    assert G.graph_summary(G.create_regular_grid_graph(xy)) == ref["multiscale"]
+    assert G.graph_summary(G.create_regular_grid_graph(xy, n_max_levels=3, hierarchical=True)) == ref["hierarchical"]
+
+
+def test_unsupported_spec_raises(tmp_path):
+    raw = G.create_regular_grid_graph(G.regular_grid_xy(27, 27))
+    G.save_graph(tmp_path, raw)
+    (tmp_path / G.METAINFO_FILENAME).write_text("spec_version: '9.9'\n")
+    with pytest.raises(ValueError):
+        G.load_graph(tmp_path, 1.0)
+
+
+def test_edge_csr_structure():
+    g = torch.Generator().manual_seed(0)
+    ns, nr, E = 13, 7, 60
+    ei = torch.stack([torch.randint(0, ns, (E,), generator=g), torch.randint(0, nr - 1, (E,), generator=g)])
+    ei[1][ei[1] == 2] = 3  # receiver 2 has no edges
+    csr = G.build_edge_csr(ei, num_send=ns)
+    assert csr.num_rec == int(ei[1].max()) + 1  # gnn_layers.py:73 semantics
+    perm = csr.perm.long()
+    assert torch.equal(csr.send.long(), ei[0][perm]) and torch.equal(csr.rec.long(), ei[1][perm])
+    assert torch.all(csr.rec[1:] >= csr.rec[:-1])
+    for r in range(csr.num_rec):
+        seg = csr.rec[csr.rowptr[r] : csr.rowptr[r + 1]]
+        assert torch.all(seg == r)
+    assert csr.rowptr[3] - csr.rowptr[2] == 0
+    # CSC view: positions grouped by sender
+    cs = csr.send.long()[csr.cperm.long()]
+    assert torch.all(cs[1:] >= cs[:-1])
+    for s in range(ns):
+        seg = cs[csr.colptr[s] : csr.colptr[s + 1]]
+        assert torch.all(seg == s)
+    deg = torch.bincount(ei[1], minlength=csr.num_rec).clamp(min=1).float()
+    assert torch.allclose(csr.inv_deg, 1.0 / deg)

@@ -1,0 +1,76 @@
+"""Pin the oracle against golden vectors computed by the reference's own code
+(tests/golden/make_golden.py).  CPU only."""
+import pytest
+import torch
+
+from conftest import graph_from_case, load_golden, rel_err
+from neural_lam_amd.datastore import SyntheticDatastore
+from oracle import gnn_layers as og
+from oracle import models as om
+
+TOL = 1e-5  # oracle and reference run the same torch CPU ops; only op order may differ
+
+
+def _build_layer(case):
+    ei = case["edge_index"].to(torch.int64)
+    net = og.get_gnn_class(case["cls"])(ei, case["d"], **case["kwargs"])
+    missing = net.load_state_dict(case["state_dict"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net
+
+
+LAYER_CASES = [
+    "inet_sum_update_d8", "inet_mean_noupdate_b2_d8", "propnet_b2_d8", "propnet_noupdate_d16",
+    "inet_chunked_d8", "inet_100to10_gap_d16", "inet_sum_update_b2_d64", "inet_highdeg_d32", "inet_hidden12_d8",
+]
+
+
+@pytest.mark.parametrize("name", LAYER_CASES)
+def test_layer_forward_backward_matches_reference(golden_layers, name):
+    case = golden_layers[name]
+    net = _build_layer(case)
+    send = case["send"].clone().requires_grad_()
+    rec = case["rec"].clone().requires_grad_()
+    edge = case["edge"].clone().requires_grad_()
+    out = net(send, rec, edge)
+    outs = out if isinstance(out, tuple) else (out,)
+    assert len(outs) == len(case["ref_out"])
+    for o, r in zip(outs, case["ref_out"]):
+        assert o.shape == r.shape
+        assert rel_err(o, r) < TOL
+    sum((o * c).sum() for o, c in zip(outs, case["cotangents"])).backward()
+    assert rel_err(send.grad, case["ref_grad_send"]) < TOL
+    assert rel_err(rec.grad, case["ref_grad_rec"]) < TOL
+    assert rel_err(edge.grad, case["ref_grad_edge"]) < TOL
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad, case["ref_grad_params"][k]) < TOL, k
+
+
+MODEL_CASES = ["graphlam_30x27", "graphlam_30x27_variants", "hilam_81x30", "hilam_parallel_81x30"]
+ORACLE_CLS = {"GraphLAM": om.GraphLAM, "HiLAM": om.HiLAM, "HiLAMParallel": om.HiLAMParallel}
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_model_training_step_matches_reference(name, tmp_path):
+    case = load_golden(name)
+    ds = SyntheticDatastore(root_path=tmp_path, **case["ds_kwargs"])
+    graph = (case["ref_hierarchical"], graph_from_case(case))
+    predictor = ORACLE_CLS[case["model"]](ds, graph, **case["model_kwargs"])
+    forecaster = om.ARForecaster(predictor, ds)
+    res = forecaster.load_state_dict(case["state_dict"], strict=True)  # identical parameter names
+    assert not res.missing_keys and not res.unexpected_keys
+    one, one_std = predictor(case["init"][:, 1], case["init"][:, 0], case["forcing"][:, 0])
+    assert rel_err(one, case["ref_one_step"]) < TOL
+    if case["ref_one_std"] is not None:
+        assert rel_err(one_std, case["ref_one_std"]) < TOL
+    pred, loss = om.training_loss(
+        forecaster, (case["init"], case["target"], case["forcing"]), om.per_var_std_uniform(ds), om.interior_mask_bool(ds)
+    )
+    assert rel_err(pred, case["ref_prediction"]) < TOL
+    assert abs(float(loss) - float(case["ref_loss"])) < TOL * max(1.0, abs(float(case["ref_loss"])))
+    loss.backward()
+    for k, p in forecaster.named_parameters():
+        ref_g = case["ref_grads"][k]
+        assert p.grad is not None, k
+        # relative to the largest gradient entry of that parameter (tiny grads: absolute floor)
+        assert float((p.grad - ref_g).abs().max()) < 1e-4 * max(float(ref_g.abs().max()), 1e-3), k
