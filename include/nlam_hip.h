@@ -1,0 +1,186 @@
+/* nlam_hip.h -- C-ABI of the MI355X (gfx950) GNN message-passing hot path.
+ *
+ * The reference (mllam/neural-lam) has no FFI seam for this path: its "operator
+ * interface" is the Python class API of neural_lam/gnn_layers.py and
+ * neural_lam/utils/networks.py executed through ATen/PyG ops (SURVEY.md §2.4,
+ * §8b).  This header is the seam a maintainer binds instead (ctypes stub in
+ * INTEGRATION.md).  Every entry point takes plain device pointers + sizes and a
+ * HIP stream; nothing allocates, nothing synchronises, no torch types.
+ *
+ * All float tensors are fp32, row-major, innermost dimension contiguous.
+ * All index tensors are int32 on the device.  Return value: 0 on success,
+ * a negative NLAM_E* code on bad arguments, a positive hipError_t on launch
+ * failure.
+ *
+ * Replaces, per entry point:
+ *   nlam_mlp_fwd / nlam_mlp_bwd
+ *       utils.make_mlp blocks  Linear -> SiLU -> Linear [-> LayerNorm]
+ *       (neural_lam/utils/networks.py:8-40) together with the torch.cat of their
+ *       inputs and the residual add around them:
+ *         aggr_mlp(cat(rec_rep, aggr)) + residual   gnn_layers.py:148-151
+ *         grid_emb + encoding_grid_mlp(grid_emb)    models/step_predictors/graph/base.py:308
+ *         grid_embedder / *_embedder / output_map    graph/base.py:286-295, 322
+ *   nlam_edge_fwd / nlam_edge_bwd
+ *       InteractionNet / PropagationNet message + aggregate (+ edge update):
+ *         PyG propagate: x_j/x_i index_select, message() = edge_mlp(cat(edge, x_j, x_i))
+ *         [+ x_j], aggregate() = scatter sum/mean onto num_rec receivers,
+ *         edge_rep + edge_diff                       gnn_layers.py:144-155, 168-189, 241-249
+ *   nlam_wgrad
+ *       autograd's weight gradients of the nn.Linear layers inside those MLPs.
+ *   nlam_segment_sum
+ *       autograd of index_select (= index_add by sender), as a CSC segment sum.
+ *   nlam_reduce_partials
+ *       deterministic second stage of the per-workgroup partial sums.
+ *   nlam_adamw_step
+ *       torch.optim.AdamW(lr, betas=(0.9, 0.95)) of models/module.py:293-304 on
+ *       one flat fp32 parameter buffer.
+ */
+#ifndef NLAM_HIP_H
+#define NLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLAM_ABI_VERSION 1
+#define NLAM_MAX_SRC 3
+
+#define NLAM_EINVAL (-1)   /* inconsistent sizes / null pointers        */
+#define NLAM_EUNSUP (-2)   /* width outside what this build instantiates */
+
+/* flags */
+#define NLAM_F_ADD_SRC0   1u   /* out  = msg + src[0]   (edge update / node residual)          */
+#define NLAM_F_ADD_SRC1   2u   /* msg  = mlp + src[1]   (PropagationNet sender / aggr residual) */
+#define NLAM_F_MEAN       4u   /* aggregate = mean over in-edges (sum otherwise)               */
+#define NLAM_F_SILU_B     8u   /* wgrad: apply SiLU to the B operand while loading             */
+
+typedef struct {
+    const float* ptr;     /* (batch|1, n_rows_of_source, width) */
+    const int32_t* idx;   /* per tile-row gather index into the source rows, or NULL = row id */
+    int64_t bstride;      /* elements between batches; 0 = shared by all batches */
+    int32_t width;        /* columns taken from this source */
+    int32_t _pad;
+} nlam_src_t;
+
+/* One wave-tile of <= 32 consecutive rows (CSR positions) made of whole receivers. */
+typedef struct {
+    int32_t row0;    /* first row (CSR position)                   */
+    int32_t nrows;   /* rows in tile, 0..32                        */
+    int32_t seg0;    /* first receiver covered                     */
+    int32_t nseg;    /* receivers covered (bit 30 set: partial sum of a split receiver -> atomic add) */
+} nlam_tile_t;
+#define NLAM_TILE_SPLIT (1 << 30)
+
+typedef struct {
+    /* ---- inputs: concatenated (and gathered) sources ---- */
+    nlam_src_t src[NLAM_MAX_SRC];
+    int32_t nsrc;
+    int32_t batch;
+    int32_t rows;          /* rows per batch (edges or nodes) */
+    int32_t ntiles;        /* tiles per batch; tiles==NULL -> ceil(rows/32) dense tiles */
+    const nlam_tile_t* tiles;
+    /* ---- MLP parameters (torch.nn.Linear layout: weight (out, in)) ---- */
+    const float* W1; const float* b1;   /* (hid, kin), (hid) ; kin = sum of src widths */
+    const float* W2; const float* b2;   /* (dout, hid), (dout) */
+    const float* ln_w; const float* ln_b; /* (dout) or NULL = no LayerNorm */
+    float eps;
+    int32_t hid;
+    int32_t dout;
+    uint32_t flags;
+    /* ---- outputs ---- */
+    float* out;            /* (batch, out_rows, dout) row output or NULL */
+    const int32_t* out_idx;/* per tile-row scatter index (unique) or NULL = row id */
+    int64_t out_bstride;
+    float* aggr;           /* (batch, nseg_total, dout) segment-reduced msg or NULL */
+    const int32_t* rowptr; /* (nseg_total + 1) CSR row pointers (needed with aggr)  */
+    const float* inv_deg;  /* (nseg_total) 1/max(deg,1) (needed with NLAM_F_MEAN)   */
+    int32_t nseg_total;
+    int32_t _pad;
+    /* ---- saved for backward (all nullable; tile-row order) ---- */
+    float* z1;             /* (batch, rows, hid)  pre-activation  */
+    float* xhat;           /* (batch, rows, dout) normalised, pre-affine (LN only) */
+    float* rstd;           /* (batch, rows) */
+} nlam_mlp_fwd_t;
+
+typedef struct {
+    /* forward geometry, exactly as in the forward call */
+    nlam_src_t src[NLAM_MAX_SRC];
+    int32_t nsrc;
+    int32_t batch;
+    int32_t rows;
+    int32_t ntiles;
+    const nlam_tile_t* tiles;
+    const float* W1; const float* W2;
+    const float* ln_w;     /* NULL = no LayerNorm */
+    int32_t hid;
+    int32_t dout;
+    uint32_t flags;
+    int32_t nseg_total;
+    /* upstream gradients */
+    const float* g_out;    /* grad of `out` (batch, out_rows, dout) or NULL */
+    const int32_t* out_idx;
+    int64_t out_bstride;
+    const float* g_aggr;   /* grad of `aggr` (batch, nseg_total, dout) or NULL */
+    const int32_t* seg_of_row; /* (rows) receiver of each tile-row (needed with g_aggr) */
+    const int32_t* rowptr;     /* (nseg_total + 1) CSR row pointers (needed with dmode 3) */
+    const float* inv_deg;
+    /* saved */
+    const float* z1; const float* xhat; const float* rstd;
+    /* outputs */
+    float* dz1;            /* (batch, rows, hid)   for nlam_wgrad */
+    float* dz2;            /* (batch, rows, dout)  for nlam_wgrad */
+    float* dsrc[NLAM_MAX_SRC];     /* gradient wrt each source, see dmode */
+    int64_t dsrc_bstride[NLAM_MAX_SRC];
+    int32_t dmode[NLAM_MAX_SRC];   /* 0 none | 1 rows scattered through src[k].idx (unique)
+                                      | 2 tile-row order (rows, width) for a later segment sum
+                                      | 3 segment-summed over the tile's receivers -> (nseg_total, width) */
+    int32_t _pad;
+    float* vec_partials;   /* (nwaves, 4, DP): db1, db2, dgamma, dbeta partial sums */
+    int32_t vec_partials_rows; /* out: capacity in rows; must be >= nlam_grid_waves() */
+    int32_t _pad2;
+} nlam_mlp_bwd_t;
+
+typedef struct {
+    const float* A;        /* (batch*rows, m) contiguous: dz1 or dz2 */
+    int32_t m;
+    int32_t batch;
+    int32_t rows;
+    int32_t nsrc;
+    nlam_src_t src[NLAM_MAX_SRC]; /* B operand = concat of gathered sources (tile-row order idx) */
+    uint32_t flags;        /* NLAM_F_SILU_B */
+    int32_t n;             /* sum of widths */
+    float* partials;       /* (nparts, m, n) */
+    int32_t nparts;        /* number of row-slices = workgroups launched */
+    int32_t _pad;
+} nlam_wgrad_t;
+
+/* number of persistent waves the fwd/bwd kernels launch (for sizing vec_partials) */
+int32_t nlam_grid_waves(void);
+int32_t nlam_abi_version(void);
+/* widest hidden/output width the fused kernels of this build instantiate */
+int32_t nlam_max_width(void);
+
+int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream);
+int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream);
+int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream);
+
+/* out[b, s, :] = scale(s) * sum_{q in [ptr[s], ptr[s+1])} in[b, order[q], :]   (order NULL = q) */
+int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order,
+                         const float* scale, float* out, int32_t nseg, int32_t width, int32_t batch,
+                         void* hip_stream);
+
+/* out[i] (+)= sum_p partials[p * stride + i], i < n ; accumulate != 0 adds into out */
+int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stride, int32_t n, float* out,
+                             int32_t accumulate, void* hip_stream);
+
+/* decoupled-weight-decay Adam on flat buffers; step_count is the 1-based step */
+int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step_count,
+                        float grad_scale, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLAM_HIP_H */

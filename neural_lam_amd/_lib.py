@@ -1,0 +1,192 @@
+"""ctypes binding of libnlam_hip.so (the C-ABI declared in include/nlam_hip.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` /
+``python -m neural_lam_amd.build``.  There is no CPU fallback: if the library is
+missing, or a tensor is not on a HIP device, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "libnlam_hip.so"
+
+NLAM_MAX_SRC = 3
+F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B = 1, 2, 4, 8
+TILE_SPLIT = 1 << 30
+
+EXPORTS = [
+    "nlam_abi_version",
+    "nlam_grid_waves",
+    "nlam_max_width",
+    "nlam_mlp_fwd",
+    "nlam_mlp_bwd",
+    "nlam_wgrad",
+    "nlam_segment_sum",
+    "nlam_reduce_partials",
+    "nlam_adamw_step",
+]
+
+
+class Src(C.Structure):
+    _fields_ = [
+        ("ptr", C.c_void_p),
+        ("idx", C.c_void_p),
+        ("bstride", C.c_int64),
+        ("width", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+class MlpFwd(C.Structure):
+    _fields_ = [
+        ("src", Src * NLAM_MAX_SRC),
+        ("nsrc", C.c_int32),
+        ("batch", C.c_int32),
+        ("rows", C.c_int32),
+        ("ntiles", C.c_int32),
+        ("tiles", C.c_void_p),
+        ("W1", C.c_void_p),
+        ("b1", C.c_void_p),
+        ("W2", C.c_void_p),
+        ("b2", C.c_void_p),
+        ("ln_w", C.c_void_p),
+        ("ln_b", C.c_void_p),
+        ("eps", C.c_float),
+        ("hid", C.c_int32),
+        ("dout", C.c_int32),
+        ("flags", C.c_uint32),
+        ("out", C.c_void_p),
+        ("out_idx", C.c_void_p),
+        ("out_bstride", C.c_int64),
+        ("aggr", C.c_void_p),
+        ("rowptr", C.c_void_p),
+        ("inv_deg", C.c_void_p),
+        ("nseg_total", C.c_int32),
+        ("_pad", C.c_int32),
+        ("z1", C.c_void_p),
+        ("xhat", C.c_void_p),
+        ("rstd", C.c_void_p),
+    ]
+
+
+class MlpBwd(C.Structure):
+    _fields_ = [
+        ("src", Src * NLAM_MAX_SRC),
+        ("nsrc", C.c_int32),
+        ("batch", C.c_int32),
+        ("rows", C.c_int32),
+        ("ntiles", C.c_int32),
+        ("tiles", C.c_void_p),
+        ("W1", C.c_void_p),
+        ("W2", C.c_void_p),
+        ("ln_w", C.c_void_p),
+        ("hid", C.c_int32),
+        ("dout", C.c_int32),
+        ("flags", C.c_uint32),
+        ("nseg_total", C.c_int32),
+        ("g_out", C.c_void_p),
+        ("out_idx", C.c_void_p),
+        ("out_bstride", C.c_int64),
+        ("g_aggr", C.c_void_p),
+        ("seg_of_row", C.c_void_p),
+        ("rowptr", C.c_void_p),
+        ("inv_deg", C.c_void_p),
+        ("z1", C.c_void_p),
+        ("xhat", C.c_void_p),
+        ("rstd", C.c_void_p),
+        ("dz1", C.c_void_p),
+        ("dz2", C.c_void_p),
+        ("dsrc", C.c_void_p * NLAM_MAX_SRC),
+        ("dsrc_bstride", C.c_int64 * NLAM_MAX_SRC),
+        ("dmode", C.c_int32 * NLAM_MAX_SRC),
+        ("_pad", C.c_int32),
+        ("vec_partials", C.c_void_p),
+        ("vec_partials_rows", C.c_int32),
+        ("_pad2", C.c_int32),
+    ]
+
+
+class Wgrad(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p),
+        ("m", C.c_int32),
+        ("batch", C.c_int32),
+        ("rows", C.c_int32),
+        ("nsrc", C.c_int32),
+        ("src", Src * NLAM_MAX_SRC),
+        ("flags", C.c_uint32),
+        ("n", C.c_int32),
+        ("partials", C.c_void_p),
+        ("nparts", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib_path() -> Path:
+    return LIB_PATH
+
+
+def load():
+    """dlopen the in-tree library once; fail loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()').  "
+            "neural_lam_amd has no CPU / eager fallback."
+        )
+    import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so both share one HIP runtime)
+
+    lib = C.CDLL(str(LIB_PATH))
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise RuntimeError(f"{LIB_PATH} does not export {name}")
+    i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
+    lib.nlam_abi_version.restype = i32
+    lib.nlam_grid_waves.restype = i32
+    lib.nlam_max_width.restype = i32
+    lib.nlam_mlp_fwd.argtypes = [C.POINTER(MlpFwd), vp]
+    lib.nlam_mlp_fwd.restype = i32
+    lib.nlam_mlp_bwd.argtypes = [C.POINTER(MlpBwd), vp]
+    lib.nlam_mlp_bwd.restype = i32
+    lib.nlam_wgrad.argtypes = [C.POINTER(Wgrad), vp]
+    lib.nlam_wgrad.restype = i32
+    lib.nlam_segment_sum.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.nlam_segment_sum.restype = i32
+    lib.nlam_reduce_partials.argtypes = [vp, i32, i64, i32, vp, i32, vp]
+    lib.nlam_reduce_partials.restype = i32
+    lib.nlam_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
+    lib.nlam_adamw_step.restype = i32
+    if lib.nlam_abi_version() != 1:
+        raise RuntimeError("libnlam_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "NLAM_EINVAL (bad arguments)", -2: "NLAM_EUNSUP (width not instantiated in this build)"}.get(
+            rc, f"hipError_t {rc}"
+        )
+        raise RuntimeError(f"{what} failed: {kind}")
+
+
+def build(verbose: bool = False) -> Path:
+    """Compile csrc/nlam_hip.hip for gfx950 into the in-tree shared library."""
+    import subprocess
+
+    src = HERE / "csrc" / "nlam_hip.hip"
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", str(src), "-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH

@@ -1,0 +1,1030 @@
+// nlam_hip.hip -- gfx950 (MI355X, CDNA4) kernels behind include/nlam_hip.h.
+//
+// Design (see DESIGN.md for the full derivation):
+//  * One *wave* owns a tile of <= 32 rows (edges in receiver-sorted CSR order, or
+//    nodes).  The tile is the N (column) side of v_mfma_f32_32x32x2_f32; the
+//    weight matrix is the A operand (rows = output features).  In this
+//    "transposed" form the accumulator layout of GEMM1 *is* the B-operand layout
+//    of GEMM2 (K order is a free permutation, applied to the weights once when
+//    they are staged into LDS), so Linear -> SiLU -> Linear -> LayerNorm runs
+//    register to register with no LDS round trip and no shuffles.
+//  * Weights are staged once per persistent workgroup into LDS in a "packed"
+//    order so every lane fetches the A operands of four MFMAs with one
+//    conflict-free ds_read_b128.
+//  * Tiles consist of whole receivers (host-built schedule), so the segment
+//    reduction (sum / mean aggregation) happens inside the wave through an LDS
+//    staging buffer with plain stores: no atomics, deterministic.  Receivers with
+//    in-degree > 32 are split over several tiles and only those use atomics.
+//  * fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf
+//    chain, so parity with the fp32 oracle is at rounding-order level.
+//
+// "chunk" below always means: 4 consecutive features [8t + 4hi, 8t + 4hi + 4) of
+// one row, held by lane (j = lane & 31, hi = lane >> 5) as one float4.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nlam_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+constexpr int kWavesPerBlock = 8;                  // 512 threads: two waves per SIMD
+constexpr int kBlockThreads = kWavesPerBlock * 64;
+constexpr int kNumCUs = 256;
+constexpr int kMaxGridBlocks = kNumCUs;            // one persistent workgroup per CU
+constexpr int kMaxWidth = 64;                      // widest hidden/output width instantiated
+
+__device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Order the wave's own LDS traffic (cross-lane exchange through LDS inside one
+// wave; other waves of the block are at unrelated points, so no s_barrier).
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS instructions of one wave are issued and serviced in order; the asm is a
+    // compiler barrier for memory operations and drains the wave's own LDS queue.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------
+// packed A-operand staging
+//   dst[(((mb * T + t) * 2 + hi) * 32 + i) * 4 + c] = A[mb*32 + i][8*t + 4*hi + c]
+//   with A[m][k] = W[m * ldm + k * ldk] for m < M, k < Kw (zero elsewhere); the
+//   Kw columns are placed at chunk offset t0 of a matrix that has T chunks total.
+// ---------------------------------------------------------------------------
+__device__ void stage_packed(float* dst, int T, int t0, const float* W, long ldm, long ldk, int M, int MB, int Kw) {
+    const int nt = (Kw + 7) >> 3;
+    const int total = MB * nt * 64;
+    for (int s = threadIdx.x; s < total; s += blockDim.x) {
+        const int i = s & 31;
+        const int hi = (s >> 5) & 1;
+        const int rest = s >> 6;
+        const int t = rest % nt;
+        const int mb = rest / nt;
+        const int m = mb * 32 + i;
+        const int kb = 8 * t + 4 * hi;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < M) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = kb + c;
+                if (k < Kw) v[c] = W[(long)m * ldm + (long)k * ldk];
+            }
+        }
+        *reinterpret_cast<f32x4*>(&dst[((((size_t)mb * T + (t0 + t)) * 2 + hi) * 32 + i) * 4]) = v;
+    }
+}
+
+__device__ void stage_vec(float* dst, const float* v, int n, int np, float fill) {
+    for (int s = threadIdx.x; s < np; s += blockDim.x) dst[s] = (v != nullptr && s < n) ? v[s] : fill;
+}
+
+// four MFMAs (K = 8 features) against every 32-row block of the packed A matrix
+template <int MB>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MB], const float* Ap, int T, int t, f32x4 x, int lane) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&Ap[(((size_t)mb * T + t) * 64 + lane) * 4]);
+        acc[mb] = MFMA32(a[0], x[0], acc[mb]);
+        acc[mb] = MFMA32(a[1], x[1], acc[mb]);
+        acc[mb] = MFMA32(a[2], x[2], acc[mb]);
+        acc[mb] = MFMA32(a[3], x[3], acc[mb]);
+    }
+}
+// note: (((mb*T + t)*2 + hi)*32 + i) == ((mb*T + t)*64 + lane) because lane = hi*32 + i.
+
+// chunk t of one row (row pointer already resolved); zero outside [0, w)
+__device__ __forceinline__ f32x4 load_chunk(const float* row, int w, int t, int hi, bool valid) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int c0 = 8 * t + 4 * hi;
+    if (valid && c0 < w) {
+        if ((w & 3) == 0) {
+            v = *reinterpret_cast<const f32x4*>(row + c0);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c0 + c < w) v[c] = row[c0 + c];
+        }
+    }
+    return v;
+}
+
+__device__ __forceinline__ void store_chunk(float* row, int w, int t, int hi, bool valid, f32x4 v) {
+    const int c0 = 8 * t + 4 * hi;
+    if (valid && c0 < w) {
+        if ((w & 3) == 0) {
+            *reinterpret_cast<f32x4*>(row + c0) = v;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c0 + c < w) row[c0 + c] = v[c];
+        }
+    }
+}
+
+__device__ __forceinline__ f32x4 acc_chunk(const f32x16& a, int tt) {
+    f32x4 v;
+    v[0] = a[4 * tt + 0];
+    v[1] = a[4 * tt + 1];
+    v[2] = a[4 * tt + 2];
+    v[3] = a[4 * tt + 3];
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+__device__ __forceinline__ float silu_grad_f(float z) {
+    const float s = 1.f / (1.f + __expf(-z));
+    return s * (1.f + z * (1.f - s));
+}
+
+// sum over the two half-wave partners (lane, lane ^ 32): full-row reductions
+__device__ __forceinline__ float row_allreduce(float v) { return v + __shfl_xor(v, 32, 64); }
+
+struct TileInfo {
+    int row0, nrows, seg0, nseg;
+    bool split;
+};
+
+__device__ __forceinline__ TileInfo get_tile(const nlam_tile_t* tiles, int ti, int rows) {
+    TileInfo t;
+    if (tiles != nullptr) {
+        const nlam_tile_t d = tiles[ti];
+        t.row0 = d.row0;
+        t.nrows = d.nrows;
+        t.seg0 = d.seg0;
+        t.split = (d.nseg & NLAM_TILE_SPLIT) != 0;
+        t.nseg = d.nseg & ~NLAM_TILE_SPLIT;
+    } else {
+        t.row0 = ti * 32;
+        t.nrows = min(32, rows - t.row0);
+        t.seg0 = t.row0;
+        t.nseg = t.nrows;
+        t.split = false;
+    }
+    return t;
+}
+
+// Segment-sum the wave's staged tile (stg[row][col], stride S) over the tile's
+// receivers and write (or atomically add, for split receivers) the result.
+__device__ __forceinline__ void tile_segment_reduce(const float* stg, int S, const TileInfo& tl, const int32_t* rowptr,
+                                                    const float* inv_deg, float* out_b /* (nseg_total, w) */, int w,
+                                                    int lane) {
+    for (int sg = 0; sg < tl.nseg; ++sg) {
+        const int r = tl.seg0 + sg;
+        int lo, hi_;
+        if (tl.split) {
+            lo = 0;
+            hi_ = tl.nrows;
+        } else {
+            lo = rowptr[r] - tl.row0;
+            hi_ = rowptr[r + 1] - tl.row0;
+        }
+        const float scale = inv_deg != nullptr ? inv_deg[r] : 1.f;
+        for (int c = lane; c < w; c += 64) {
+            float s = 0.f;
+            for (int q = lo; q < hi_; ++q) s += stg[q * S + c];
+            s *= scale;
+            float* dst = out_b + (size_t)r * w + c;
+            if (tl.split)
+                atomicAdd(dst, s);
+            else
+                *dst = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward:  [gather | concat] -> Linear -> SiLU -> Linear -> [LayerNorm]
+//           -> [+src1] -> {segment-reduce -> aggr} -> [+src0] -> out
+// HB = padded hidden width / 32, OB = padded output width / 32
+// ---------------------------------------------------------------------------
+template <int HB, int OB>
+__global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_fwd_t p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int DPH = HB * 32, OP = OB * 32;
+    constexpr int STG = OP + 4;  // staging row stride: conflict-free b128 writes, b32 column reads
+
+    int T1 = 0;
+    for (int s = 0; s < p.nsrc; ++s) T1 += (p.src[s].width + 7) >> 3;
+    constexpr int T2 = DPH / 8;
+
+    float* W1p = smem;                                // DPH x (8*T1)
+    float* W2p = W1p + (size_t)DPH * 8 * T1;          // OP x DPH
+    float* b1l = W2p + (size_t)OP * DPH;              // DPH
+    float* b2l = b1l + DPH;                           // OP
+    float* gml = b2l + OP;                            // OP
+    float* btl = gml + OP;                            // OP
+    float* stg_all = btl + OP;                        // kWavesPerBlock x 32 x STG (only when aggr)
+
+    int kin = 0;
+    for (int s = 0; s < p.nsrc; ++s) kin += p.src[s].width;
+    {
+        int t0 = 0, off = 0;
+        for (int s = 0; s < p.nsrc; ++s) {
+            const int w = p.src[s].width;
+            stage_packed(W1p, T1, t0, p.W1 + off, kin, 1, p.hid, HB, w);
+            off += w;
+            t0 += (w + 7) >> 3;
+        }
+    }
+    stage_packed(W2p, T2, 0, p.W2, p.hid, 1, p.dout, OB, p.hid);
+    // columns >= hid of W2p beyond (hid+7)/8 chunks must be zero too
+    {
+        const int nt_used = (p.hid + 7) >> 3;
+        for (int s = threadIdx.x; s < OB * (T2 - nt_used) * 64; s += blockDim.x) {
+            const int l = s & 63;
+            const int rest = s >> 6;
+            const int t = nt_used + rest % (T2 - nt_used);
+            const int mb = rest / (T2 - nt_used);
+            *reinterpret_cast<f32x4*>(&W2p[(((size_t)mb * T2 + t) * 64 + l) * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    stage_vec(b1l, p.b1, p.hid, DPH, 0.f);
+    stage_vec(b2l, p.b2, p.dout, OP, 0.f);
+    stage_vec(gml, p.ln_w, p.dout, OP, 1.f);
+    stage_vec(btl, p.ln_b, p.dout, OP, 0.f);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    float* stg = stg_all + (size_t)wave * 32 * STG;
+    const bool has_ln = p.ln_w != nullptr;
+    const float inv_dout = 1.f / (float)p.dout;
+
+    const long total_tiles = (long)p.ntiles * p.batch;
+    for (long gt = (long)blockIdx.x * kWavesPerBlock + wave; gt < total_tiles; gt += (long)gridDim.x * kWavesPerBlock) {
+        const int b = (int)(gt / p.ntiles);
+        const int ti = (int)(gt % p.ntiles);
+        const TileInfo tl = get_tile(p.tiles, ti, p.rows);
+        const bool valid = j < tl.nrows;
+        const int prow = tl.row0 + j;
+
+        // ---- GEMM1 over the concatenated, gathered sources ----
+        f32x16 acc1[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[hb][r] = 0.f;
+
+        const float* srow[NLAM_MAX_SRC] = {nullptr, nullptr, nullptr};
+        int tg = 0;
+        for (int s = 0; s < p.nsrc; ++s) {
+            const nlam_src_t S = p.src[s];
+            long ridx = prow;
+            if (valid && S.idx != nullptr) ridx = S.idx[prow];
+            const float* row = S.ptr + (long)b * S.bstride + (valid ? ridx : 0) * (long)S.width;
+            srow[s] = row;
+            const int nt = (S.width + 7) >> 3;
+            for (int t = 0; t < nt; ++t) {
+                const f32x4 x = load_chunk(row, S.width, t, hi, valid);
+                mma_chunk<HB>(acc1, W1p, T1, tg + t, x, lane);
+            }
+            tg += nt;
+        }
+
+        // ---- bias, save pre-activation, SiLU -> B operand of GEMM2 ----
+        float* z1row = p.z1 != nullptr ? p.z1 + ((size_t)b * p.rows + prow) * p.hid : nullptr;
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = hb * 4 + tt;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(&b1l[8 * t + 4 * hi]);
+                f32x4 z = acc_chunk(acc1[hb], tt) + bias;
+                if (z1row != nullptr) store_chunk(z1row, p.hid, t, hi, valid, z);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc1[hb][4 * tt + c] = silu_f(z[c]);
+            }
+        }
+
+        // ---- GEMM2 straight from the accumulators ----
+        f32x16 acc2[OB];
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[ob][r] = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) mma_chunk<OB>(acc2, W2p, T2, hb * 4 + tt, acc_chunk(acc1[hb], tt), lane);
+
+        // ---- bias 2 + LayerNorm over the real dout features ----
+        float sum = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(&b2l[c0]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = acc2[ob][4 * tt + c] + bias[c];
+                    acc2[ob][4 * tt + c] = v;
+                    sum += (c0 + c < p.dout) ? v : 0.f;
+                }
+            }
+        if (has_ln) {
+            const float mean = row_allreduce(sum) * inv_dout;
+            float sq = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float dlt = acc2[ob][4 * tt + c] - mean;
+                        acc2[ob][4 * tt + c] = dlt;
+                        sq += (c0 + c < p.dout) ? dlt * dlt : 0.f;
+                    }
+                }
+            const float rstd = rsqrtf(row_allreduce(sq) * inv_dout + p.eps);
+            if (p.rstd != nullptr && valid && hi == 0) p.rstd[(size_t)b * p.rows + prow] = rstd;
+            float* xrow = p.xhat != nullptr ? p.xhat + ((size_t)b * p.rows + prow) * p.dout : nullptr;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int t = ob * 4 + tt;
+                    const int c0 = 8 * t + 4 * hi;
+                    f32x4 xh;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xh[c] = acc2[ob][4 * tt + c] * rstd;
+                    if (xrow != nullptr) store_chunk(xrow, p.dout, t, hi, valid, xh);
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(&gml[c0]);
+                    const f32x4 be = *reinterpret_cast<const f32x4*>(&btl[c0]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc2[ob][4 * tt + c] = xh[c] * g[c] + be[c];
+                }
+        }
+
+        // ---- msg = mlp [+ src1]; aggregate; out = msg [+ src0] ----
+        float* orow = nullptr;
+        if (p.out != nullptr) {
+            long oidx = prow;
+            if (valid && p.out_idx != nullptr) oidx = p.out_idx[prow];
+            orow = p.out + (long)b * p.out_bstride + (valid ? oidx : 0) * (long)p.dout;
+        }
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = ob * 4 + tt;
+                f32x4 m = acc_chunk(acc2[ob], tt);
+                if (p.flags & NLAM_F_ADD_SRC1) m += load_chunk(srow[1], p.dout, t, hi, valid);
+                if (p.aggr != nullptr) {
+                    if (!valid) m = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(&stg[j * STG + 8 * t + 4 * hi]) = m;
+                }
+                if (orow != nullptr) {
+                    if (p.flags & NLAM_F_ADD_SRC0) m += load_chunk(srow[0], p.dout, t, hi, valid);
+                    store_chunk(orow, p.dout, t, hi, valid, m);
+                }
+            }
+        if (p.aggr != nullptr) {
+            wave_lds_sync();
+            tile_segment_reduce(stg, STG, tl, p.rowptr, (p.flags & NLAM_F_MEAN) ? p.inv_deg : nullptr,
+                                p.aggr + (size_t)b * p.nseg_total * p.dout, p.dout, lane);
+            wave_lds_sync();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward (data gradients + bias / LayerNorm-affine partial sums)
+// ---------------------------------------------------------------------------
+// column sums of a staged 32 x w tile, accumulated into one register per lane
+// (two for w > 64 are not needed: kMaxWidth = 64)
+__device__ __forceinline__ float tile_colsum(const float* stg, int S, int w, int lane) {
+    float s = 0.f;
+    if (lane < w) {
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) s += stg[q * S + lane];
+    }
+    return s;
+}
+
+template <int HB, int OB>
+__global__ __launch_bounds__(kBlockThreads) void mlp_bwd_kernel(const nlam_mlp_bwd_t p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int DPH = HB * 32, OP = OB * 32;
+    constexpr int WMAX = (DPH > OP ? DPH : OP) > 64 ? (DPH > OP ? DPH : OP) : 64;
+    constexpr int STG = WMAX + 4;
+    constexpr int T2 = OP / 8;    // K chunks of dh = W2^T dz2   (K = dout)
+    constexpr int T1 = DPH / 8;   // K chunks of dx = W1^T dz1   (K = hid)
+
+    int kin = 0;
+    for (int s = 0; s < p.nsrc; ++s) kin += p.src[s].width;
+
+    // W2^T packed: M = hid (HB blocks), K = dout
+    float* W2t = smem;                              // DPH x OP
+    float* W1t = W2t + (size_t)DPH * OP;            // per source: round32(w) x DPH, only for sources with dmode != 0
+    size_t w1t_floats = 0;
+    int w1t_off[NLAM_MAX_SRC];
+    for (int s = 0; s < p.nsrc; ++s) {
+        w1t_off[s] = (int)w1t_floats;
+        if (p.dmode[s] != 0) w1t_floats += (size_t)round_up(p.src[s].width, 32) * DPH;
+    }
+    float* gml = W1t + w1t_floats;                  // OP
+    float* stg_all = gml + OP;                      // kWavesPerBlock x 32 x STG
+
+    // A[m][k] = W2[k][m]  ->  ldm = 1, ldk = hid
+    stage_packed(W2t, T2, 0, p.W2, 1, p.hid, p.hid, HB, p.dout);
+    {
+        const int nt_used = (p.dout + 7) >> 3;
+        if (nt_used < T2)
+            for (int s = threadIdx.x; s < HB * (T2 - nt_used) * 64; s += blockDim.x) {
+                const int l = s & 63;
+                const int rest = s >> 6;
+                const int t = nt_used + rest % (T2 - nt_used);
+                const int mb = rest / (T2 - nt_used);
+                *reinterpret_cast<f32x4*>(&W2t[(((size_t)mb * T2 + t) * 64 + l) * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+    {
+        int off = 0;
+        for (int s = 0; s < p.nsrc; ++s) {
+            const int w = p.src[s].width;
+            if (p.dmode[s] != 0) {
+                // A[m][k] = W1[k][off + m]  ->  ldm = 1, ldk = kin ; M = w, K = hid
+                float* dst = W1t + w1t_off[s];
+                const int MBs = round_up(w, 32) / 32;
+                stage_packed(dst, T1, 0, p.W1 + off, 1, kin, w, MBs, p.hid);
+                const int nt_used = (p.hid + 7) >> 3;
+                if (nt_used < T1)
+                    for (int q = threadIdx.x; q < MBs * (T1 - nt_used) * 64; q += blockDim.x) {
+                        const int l = q & 63;
+                        const int rest = q >> 6;
+                        const int t = nt_used + rest % (T1 - nt_used);
+                        const int mb = rest / (T1 - nt_used);
+                        *reinterpret_cast<f32x4*>(&dst[(((size_t)mb * T1 + t) * 64 + l) * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+            off += w;
+        }
+    }
+    stage_vec(gml, p.ln_w, p.dout, OP, 1.f);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    float* stg = stg_all + (size_t)wave * 32 * STG;
+    const bool has_ln = p.ln_w != nullptr;
+    const float inv_dout = 1.f / (float)p.dout;
+
+    // per-lane column accumulators (lane = column): db1, db2, dgamma, dbeta
+    float acc_db1 = 0.f, acc_db2 = 0.f, acc_dg = 0.f, acc_dbt = 0.f;
+
+    const long total_tiles = (long)p.ntiles * p.batch;
+    for (long gt = (long)blockIdx.x * kWavesPerBlock + wave; gt < total_tiles; gt += (long)gridDim.x * kWavesPerBlock) {
+        const int b = (int)(gt / p.ntiles);
+        const int ti = (int)(gt % p.ntiles);
+        const TileInfo tl = get_tile(p.tiles, ti, p.rows);
+        const bool valid = j < tl.nrows;
+        const int prow = tl.row0 + j;
+        const size_t srow_id = (size_t)b * p.rows + prow;
+
+        // ---- upstream gradient wrt msg (C layout chunks) ----
+        const float* grow = nullptr;
+        if (p.g_out != nullptr) {
+            long oidx = prow;
+            if (valid && p.out_idx != nullptr) oidx = p.out_idx[prow];
+            grow = p.g_out + (long)b * p.out_bstride + (valid ? oidx : 0) * (long)p.dout;
+        }
+        const float* garow = nullptr;
+        float gscale = 1.f;
+        if (p.g_aggr != nullptr) {
+            const int sg = valid ? p.seg_of_row[prow] : 0;
+            garow = p.g_aggr + ((size_t)b * p.nseg_total + sg) * p.dout;
+            if (p.flags & NLAM_F_MEAN) gscale = p.inv_deg[sg];
+        }
+        const float* xrow = has_ln ? p.xhat + srow_id * p.dout : nullptr;
+        const float rstd = (has_ln && valid) ? p.rstd[srow_id] : 0.f;
+
+        f32x16 dz2[OB];
+        // pass 1: dmsg, LN-affine partials, LN reductions
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = ob * 4 + tt;
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                if (grow != nullptr) g += load_chunk(grow, p.dout, t, hi, valid);
+                if (garow != nullptr) g += load_chunk(garow, p.dout, t, hi, valid) * gscale;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dz2[ob][4 * tt + c] = g[c];
+                // stage dmsg for the dbeta column sum
+                *reinterpret_cast<f32x4*>(&stg[j * STG + 8 * t + 4 * hi]) = g;
+            }
+        if (has_ln) {
+            wave_lds_sync();
+            acc_dbt += tile_colsum(stg, STG, p.dout, lane);
+            wave_lds_sync();
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int t = ob * 4 + tt;
+                    const f32x4 xh = load_chunk(xrow, p.dout, t, hi, valid);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(&gml[8 * t + 4 * hi]);
+                    f32x4 gx;  // dmsg * xhat -> dgamma
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float g = dz2[ob][4 * tt + c];
+                        gx[c] = g * xh[c];
+                        const float gy = g * gm[c];
+                        dz2[ob][4 * tt + c] = gy;
+                        m1 += gy;          // padded columns: g == 0
+                        m2 += gy * xh[c];
+                    }
+                    *reinterpret_cast<f32x4*>(&stg[j * STG + 8 * t + 4 * hi]) = gx;
+                }
+            wave_lds_sync();
+            acc_dg += tile_colsum(stg, STG, p.dout, lane);
+            wave_lds_sync();
+            m1 = row_allreduce(m1) * inv_dout;
+            m2 = row_allreduce(m2) * inv_dout;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int t = ob * 4 + tt;
+                    const int c0 = 8 * t + 4 * hi;
+                    const f32x4 xh = load_chunk(xrow, p.dout, t, hi, valid);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float v = rstd * (dz2[ob][4 * tt + c] - m1 - xh[c] * m2);
+                        dz2[ob][4 * tt + c] = (valid && c0 + c < p.dout) ? v : 0.f;
+                    }
+                }
+        }
+        // ---- dz2 out (for wgrad) + db2 partial ----
+        {
+            float* drow = p.dz2 != nullptr ? p.dz2 + srow_id * p.dout : nullptr;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int t = ob * 4 + tt;
+                    const f32x4 v = acc_chunk(dz2[ob], tt);
+                    if (drow != nullptr) store_chunk(drow, p.dout, t, hi, valid, v);
+                    *reinterpret_cast<f32x4*>(&stg[j * STG + 8 * t + 4 * hi]) = v;
+                }
+            wave_lds_sync();
+            acc_db2 += tile_colsum(stg, STG, p.dout, lane);
+            wave_lds_sync();
+        }
+
+        // ---- dh = W2^T dz2 ; dz1 = dh * silu'(z1) ----
+        f32x16 dz1[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz1[hb][r] = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) mma_chunk<HB>(dz1, W2t, T2, ob * 4 + tt, acc_chunk(dz2[ob], tt), lane);
+        {
+            const float* zrow = p.z1 + srow_id * p.hid;
+            float* drow = p.dz1 != nullptr ? p.dz1 + srow_id * p.hid : nullptr;
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int t = hb * 4 + tt;
+                    const f32x4 z = load_chunk(zrow, p.hid, t, hi, valid);
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        v[c] = valid ? dz1[hb][4 * tt + c] * silu_grad_f(z[c]) : 0.f;
+                        dz1[hb][4 * tt + c] = v[c];
+                    }
+                    if (drow != nullptr) store_chunk(drow, p.hid, t, hi, valid, v);
+                    *reinterpret_cast<f32x4*>(&stg[j * STG + 8 * t + 4 * hi]) = v;
+                }
+            wave_lds_sync();
+            acc_db1 += tile_colsum(stg, STG, p.hid, lane);
+            wave_lds_sync();
+        }
+
+        // ---- dx_s = W1_s^T dz1 per source ----
+        for (int s = 0; s < p.nsrc; ++s) {
+            const int mode = p.dmode[s];
+            if (mode == 0) continue;
+            const nlam_src_t S = p.src[s];
+            const int w = S.width;
+            const float* A = W1t + w1t_off[s];
+            const int MBs = (w + 31) >> 5;  // 1 or 2 (kMaxWidth = 64)
+            f32x16 dx[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dx[mb][r] = 0.f;
+            if (MBs == 1) {
+                f32x16 d1[1];
+                d1[0] = dx[0];
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) mma_chunk<1>(d1, A, T1, hb * 4 + tt, acc_chunk(dz1[hb], tt), lane);
+                dx[0] = d1[0];
+            } else {
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) mma_chunk<2>(dx, A, T1, hb * 4 + tt, acc_chunk(dz1[hb], tt), lane);
+            }
+            // residual paths
+            const bool add_gout = (s == 0) && (p.flags & NLAM_F_ADD_SRC0) && grow != nullptr;
+            const bool add_gmsg = (s == 1) && (p.flags & NLAM_F_ADD_SRC1);
+            float* drow = nullptr;
+            if (mode == 1) {
+                long ridx = prow;
+                if (valid && S.idx != nullptr) ridx = S.idx[prow];
+                drow = p.dsrc[s] + (long)b * p.dsrc_bstride[s] + (valid ? ridx : 0) * (long)w;
+            } else if (mode == 2) {
+                drow = p.dsrc[s] + srow_id * w;
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                if (mb < MBs) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int t = mb * 4 + tt;
+                        f32x4 v = acc_chunk(dx[mb], tt);
+                        if (add_gout) v += load_chunk(grow, p.dout, t, hi, valid);
+                        if (add_gmsg) {
+                            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                            if (grow != nullptr) g += load_chunk(grow, p.dout, t, hi, valid);
+                            if (garow != nullptr) g += load_chunk(garow, p.dout, t, hi, valid) * gscale;
+                            v += g;
+                        }
+                        if (mode == 3) {
+                            if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                            *reinterpret_cast<f32x4*>(&stg[j * STG + 8 * t + 4 * hi]) = v;
+                        } else {
+                            store_chunk(drow, w, t, hi, valid, v);
+                        }
+                    }
+                }
+            }
+            if (mode == 3) {
+                wave_lds_sync();
+                tile_segment_reduce(stg, STG, tl, p.rowptr, nullptr, p.dsrc[s] + (long)b * p.dsrc_bstride[s], w, lane);
+                wave_lds_sync();
+            }
+        }
+    }
+
+    // ---- flush the per-wave vector partials ----
+    if (p.vec_partials != nullptr) {
+        const int gw = blockIdx.x * kWavesPerBlock + wave;
+        float* dst = p.vec_partials + (size_t)gw * 4 * kMaxWidth;
+        if (lane < kMaxWidth) {
+            dst[0 * kMaxWidth + lane] = acc_db1;
+            dst[1 * kMaxWidth + lane] = acc_db2;
+            dst[2 * kMaxWidth + lane] = acc_dg;
+            dst[3 * kMaxWidth + lane] = acc_dbt;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// weight gradients:  C[m][n] = sum_rows A[row][m] * B[row][n]
+//   A = dz (contiguous), B = gathered concat of sources (optionally SiLU'd)
+// One workgroup (4 waves) = one partial; each wave owns up to NBW 32x32 blocks.
+// ---------------------------------------------------------------------------
+constexpr int kWgradThreads = 256;
+constexpr int kWgradRows = 32;
+
+template <int NBW>
+__global__ __launch_bounds__(kWgradThreads) void wgrad_kernel(const nlam_wgrad_t p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int MP = round_up(p.m, 32), NP = round_up(p.n, 32);
+    const int SA = MP + 4, SB = NP + 4;  // +4: row r and r+1 land 4 banks apart
+    float* As = smem;                    // kWgradRows x SA
+    float* Bs = As + kWgradRows * SA;    // kWgradRows x SB
+    const int MB = MP / 32, NB = NP / 32;
+    const int nblocks = MB * NB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, hi = lane >> 5;
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int q = 0; q < NBW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    // zero the padding columns once (never overwritten)
+    for (int s = threadIdx.x; s < kWgradRows * SA; s += blockDim.x) As[s] = 0.f;
+    for (int s = threadIdx.x; s < kWgradRows * SB; s += blockDim.x) Bs[s] = 0.f;
+    __syncthreads();
+
+    const int chunks_per_batch = (p.rows + kWgradRows - 1) / kWgradRows;
+    const long total_chunks = (long)chunks_per_batch * p.batch;
+    for (long ch = blockIdx.x; ch < total_chunks; ch += gridDim.x) {
+        const int b = (int)(ch / chunks_per_batch);
+        const int r0 = (int)(ch % chunks_per_batch) * kWgradRows;
+        const int nr = min(kWgradRows, p.rows - r0);
+        // ---- stage A rows (zero-fill rows >= nr) ----
+        for (int s = threadIdx.x; s < kWgradRows * p.m; s += blockDim.x) {
+            const int r = s / p.m, c = s % p.m;
+            As[r * SA + c] = (r < nr) ? p.A[((size_t)b * p.rows + r0 + r) * p.m + c] : 0.f;
+        }
+        // ---- stage B rows: gathered concat ----
+        int off = 0;
+        for (int q = 0; q < p.nsrc; ++q) {
+            const nlam_src_t S = p.src[q];
+            const int w = S.width;
+            for (int s = threadIdx.x; s < kWgradRows * w; s += blockDim.x) {
+                const int r = s / w, c = s % w;
+                float v = 0.f;
+                if (r < nr) {
+                    const long prow = r0 + r;
+                    const long ridx = S.idx != nullptr ? S.idx[prow] : prow;
+                    v = S.ptr[(long)b * S.bstride + ridx * w + c];
+                    if (p.flags & NLAM_F_SILU_B) v = silu_f(v);
+                }
+                Bs[r * SB + off + c] = v;
+            }
+            off += w;
+        }
+        __syncthreads();
+        // ---- MFMA: K = the 32 staged rows ----
+#pragma unroll
+        for (int q = 0; q < NBW; ++q) {
+            const int blk = wave + 4 * q;
+            if (blk < nblocks) {
+                const int mb = blk / NB, nb = blk % NB;
+#pragma unroll
+                for (int ks = 0; ks < kWgradRows / 2; ++ks) {
+                    const float a = As[(2 * ks + hi) * SA + mb * 32 + i];
+                    const float bv = Bs[(2 * ks + hi) * SB + nb * 32 + i];
+                    acc[q] = MFMA32(a, bv, acc[q]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- write this workgroup's partial (m x n) ----
+    float* P = p.partials + (size_t)blockIdx.x * p.m * p.n;
+#pragma unroll
+    for (int q = 0; q < NBW; ++q) {
+        const int blk = wave + 4 * q;
+        if (blk < nblocks) {
+            const int mb = blk / NB, nb = blk % NB;
+            const int n = nb * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < p.m && n < p.n) P[(size_t)m * p.n + n] = acc[q][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// small HBM-bound kernels
+// ---------------------------------------------------------------------------
+__global__ void segment_sum_kernel(const float* in, long in_bstride, const int32_t* ptr, const int32_t* order,
+                                   const float* scale, float* out, int nseg, int width, int batch) {
+    const int w4 = (width + 3) >> 2;
+    const long total = (long)batch * nseg * w4;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(gid % w4);
+        const long rest = gid / w4;
+        const int sgm = (int)(rest % nseg);
+        const int b = (int)(rest / nseg);
+        const int lo = ptr[sgm], hi_ = ptr[sgm + 1];
+        const float* base = in + (long)b * in_bstride;
+        float* o = out + ((size_t)b * nseg + sgm) * width + 4 * c4;
+        const float sc = scale != nullptr ? scale[sgm] : 1.f;
+        if ((width & 3) == 0) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int q = lo; q < hi_; ++q) {
+                const long row = order != nullptr ? order[q] : q;
+                acc += *reinterpret_cast<const f32x4*>(base + row * width + 4 * c4);
+            }
+            *reinterpret_cast<f32x4*>(o) = acc * sc;
+        } else {
+            for (int c = 0; c < 4 && 4 * c4 + c < width; ++c) {
+                float acc = 0.f;
+                for (int q = lo; q < hi_; ++q) {
+                    const long row = order != nullptr ? order[q] : q;
+                    acc += base[row * width + 4 * c4 + c];
+                }
+                o[c] = acc * sc;
+            }
+        }
+    }
+}
+
+__global__ void reduce_partials_kernel(const float* partials, int nparts, long stride, int n, float* out, int accumulate) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int q = 0; q < nparts; ++q) s += partials[(size_t)q * stride + idx];
+        out[idx] = accumulate ? out[idx] + s : s;
+    }
+}
+
+__global__ void adamw_kernel(float* param, const float* grad, float* m, float* v, long n, float lr, float b1, float b2,
+                             float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const float g = grad[idx] * gscale;
+        float pv = param[idx];
+        pv *= (1.f - lr * wd);                       // torch.optim.AdamW: decoupled decay first
+        const float mi = b1 * m[idx] + (1.f - b1) * g;
+        const float vi = b2 * v[idx] + (1.f - b2) * g * g;
+        m[idx] = mi;
+        v[idx] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        param[idx] = pv - (lr / bc1) * (mi / denom);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side helpers
+// ---------------------------------------------------------------------------
+size_t fwd_lds_bytes(const nlam_mlp_fwd_t* p, int HB, int OB) {
+    const int DPH = HB * 32, OP = OB * 32;
+    size_t T1 = 0;
+    for (int s = 0; s < p->nsrc; ++s) T1 += (p->src[s].width + 7) / 8;
+    size_t f = (size_t)DPH * 8 * T1 + (size_t)OP * DPH + DPH + 3 * OP;
+    if (p->aggr != nullptr) f += (size_t)kWavesPerBlock * 32 * (OP + 4);
+    return f * sizeof(float);
+}
+
+size_t bwd_lds_bytes(const nlam_mlp_bwd_t* p, int HB, int OB) {
+    const int DPH = HB * 32, OP = OB * 32;
+    const int wmax = (DPH > OP ? DPH : OP) > 64 ? (DPH > OP ? DPH : OP) : 64;
+    size_t f = (size_t)DPH * OP + OP + (size_t)kWavesPerBlock * 32 * (wmax + 4);
+    for (int s = 0; s < p->nsrc; ++s)
+        if (p->dmode[s] != 0) f += (size_t)((p->src[s].width + 31) / 32 * 32) * DPH;
+    return f * sizeof(float);
+}
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > kMaxLds) return NLAM_EUNSUP;
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+int grid_blocks(long total_tiles) {
+    long need = (total_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (need < 1) need = 1;
+    return (int)(need < kMaxGridBlocks ? need : kMaxGridBlocks);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int32_t nlam_abi_version(void) { return NLAM_ABI_VERSION; }
+int32_t nlam_grid_waves(void) { return kMaxGridBlocks * kWavesPerBlock; }
+int32_t nlam_max_width(void) { return kMaxWidth; }
+
+#define NLAM_LAUNCH_FWD(HB_, OB_)                                                                      \
+    do {                                                                                               \
+        const size_t lds = fwd_lds_bytes(p, HB_, OB_);                                                 \
+        int rc = set_lds(mlp_fwd_kernel<HB_, OB_>, lds);                                               \
+        if (rc != 0) return rc;                                                                        \
+        hipLaunchKernelGGL((mlp_fwd_kernel<HB_, OB_>), dim3(blocks), dim3(kBlockThreads), lds, stream, *p); \
+    } while (0)
+
+int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
+    if (p == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
+    if (p->batch < 1 || p->rows < 0 || p->hid < 1 || p->dout < 1) return NLAM_EINVAL;
+    if (p->hid > kMaxWidth || p->dout > kMaxWidth) return NLAM_EUNSUP;
+    if (p->aggr != nullptr && (p->rowptr == nullptr || p->tiles == nullptr)) return NLAM_EINVAL;
+    if ((p->flags & NLAM_F_MEAN) && p->inv_deg == nullptr) return NLAM_EINVAL;
+    if ((p->flags & NLAM_F_ADD_SRC0) && p->src[0].width != p->dout) return NLAM_EINVAL;
+    if ((p->flags & NLAM_F_ADD_SRC1) && (p->nsrc < 2 || p->src[1].width != p->dout)) return NLAM_EINVAL;
+    if (p->rows == 0) return 0;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const int blocks = grid_blocks((long)p->ntiles * p->batch);
+    const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
+    if (HB == 1 && OB == 1) NLAM_LAUNCH_FWD(1, 1);
+    else if (HB == 2 && OB == 1) NLAM_LAUNCH_FWD(2, 1);
+    else if (HB == 1 && OB == 2) NLAM_LAUNCH_FWD(1, 2);
+    else if (HB == 2 && OB == 2) NLAM_LAUNCH_FWD(2, 2);
+    else return NLAM_EUNSUP;
+    return (int32_t)hipGetLastError();
+}
+
+#define NLAM_LAUNCH_BWD(HB_, OB_)                                                                      \
+    do {                                                                                               \
+        const size_t lds = bwd_lds_bytes(p, HB_, OB_);                                                 \
+        int rc = set_lds(mlp_bwd_kernel<HB_, OB_>, lds);                                               \
+        if (rc != 0) return rc;                                                                        \
+        hipLaunchKernelGGL((mlp_bwd_kernel<HB_, OB_>), dim3(blocks), dim3(kBlockThreads), lds, stream, *p); \
+    } while (0)
+
+int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
+    if (p == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
+    if (p->hid > kMaxWidth || p->dout > kMaxWidth) return NLAM_EUNSUP;
+    if (p->z1 == nullptr) return NLAM_EINVAL;
+    if (p->ln_w != nullptr && (p->xhat == nullptr || p->rstd == nullptr)) return NLAM_EINVAL;
+    if (p->g_aggr != nullptr && p->seg_of_row == nullptr) return NLAM_EINVAL;
+    if ((p->flags & NLAM_F_MEAN) && p->g_aggr != nullptr && p->inv_deg == nullptr) return NLAM_EINVAL;
+    for (int s = 0; s < p->nsrc; ++s) {
+        if (p->src[s].width > kMaxWidth && p->dmode[s] != 0) return NLAM_EUNSUP;
+        if (p->dmode[s] != 0 && p->dsrc[s] == nullptr) return NLAM_EINVAL;
+        if (p->dmode[s] == 3 && (p->rowptr == nullptr || p->tiles == nullptr)) return NLAM_EINVAL;
+    }
+    if (p->vec_partials != nullptr && p->vec_partials_rows < nlam_grid_waves()) return NLAM_EINVAL;
+    if (p->rows == 0) return 0;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const int blocks = grid_blocks((long)p->ntiles * p->batch);
+    if (p->vec_partials != nullptr) {
+        // waves of blocks that are not launched contribute zeros
+        hipError_t e = hipMemsetAsync(p->vec_partials, 0, (size_t)nlam_grid_waves() * 4 * kMaxWidth * sizeof(float), stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
+    if (HB == 1 && OB == 1) NLAM_LAUNCH_BWD(1, 1);
+    else if (HB == 2 && OB == 1) NLAM_LAUNCH_BWD(2, 1);
+    else if (HB == 1 && OB == 2) NLAM_LAUNCH_BWD(1, 2);
+    else if (HB == 2 && OB == 2) NLAM_LAUNCH_BWD(2, 2);
+    else return NLAM_EUNSUP;
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
+    if (p == nullptr || p->A == nullptr || p->partials == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC) return NLAM_EINVAL;
+    int n = 0;
+    for (int s = 0; s < p->nsrc; ++s) n += p->src[s].width;
+    if (n != p->n || p->m < 1 || p->nparts < 1) return NLAM_EINVAL;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const int MP = (p->m + 31) / 32 * 32, NP = (p->n + 31) / 32 * 32;
+    const int nblocks = (MP / 32) * (NP / 32);
+    const size_t lds = (size_t)kWgradRows * (MP + 4 + NP + 4) * sizeof(float);
+    const int nbw = (nblocks + 3) / 4;
+#define NLAM_LAUNCH_WG(N_)                                                                             \
+    do {                                                                                               \
+        int rc = set_lds(wgrad_kernel<N_>, lds);                                                       \
+        if (rc != 0) return rc;                                                                        \
+        hipLaunchKernelGGL((wgrad_kernel<N_>), dim3(p->nparts), dim3(kWgradThreads), lds, stream, *p); \
+    } while (0)
+    if (nbw <= 1) NLAM_LAUNCH_WG(1);
+    else if (nbw <= 2) NLAM_LAUNCH_WG(2);
+    else if (nbw <= 3) NLAM_LAUNCH_WG(3);
+    else return NLAM_EUNSUP;
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
+                         float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream) {
+    if (in == nullptr || ptr == nullptr || out == nullptr || nseg < 0 || width < 1 || batch < 1) return NLAM_EINVAL;
+    if (nseg == 0) return 0;
+    const long total = (long)batch * nseg * ((width + 3) / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, in, (long)in_bstride,
+                       ptr, order, scale, out, nseg, width, batch);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stride, int32_t n, float* out,
+                             int32_t accumulate, void* hip_stream) {
+    if (partials == nullptr || out == nullptr || nparts < 1 || n < 1) return NLAM_EINVAL;
+    int blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream, partials, nparts,
+                       (long)stride, n, out, accumulate);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int32_t step_count, float grad_scale,
+                        void* hip_stream) {
+    if (param == nullptr || grad == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || n < 0 || step_count < 1)
+        return NLAM_EINVAL;
+    if (n == 0) return 0;
+    const float bc1 = 1.f - powf(beta1, (float)step_count);
+    const float bc2 = 1.f - powf(beta2, (float)step_count);
+    long blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, param, grad, exp_avg,
+                       exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    return (int32_t)hipGetLastError();
+}
+
+}  // extern "C"

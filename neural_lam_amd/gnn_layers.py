@@ -1,0 +1,331 @@
+"""MI355X drop-in for ``neural_lam/gnn_layers.py`` and ``neural_lam/utils/networks.py``.
+
+Same class names, constructor arguments, public attributes, parameter names and
+``forward`` contract as the reference, so reference checkpoints
+load with ``load_state_dict`` and the reference's model code can instantiate
+these classes unchanged.  Underneath, each layer is two kernel launches of
+``libnlam_hip.so`` (edge kernel: gather + edge MLP + LayerNorm + segment
+aggregation [+ edge update]; node kernel: aggr MLP + LayerNorm + residual).
+
+Reference -> here:
+  utils.make_mlp (utils/networks.py:8-40)            -> make_mlp / FusedMLP
+  InteractionNet (gnn_layers.py:14-189)              -> InteractionNet
+  PropagationNet (gnn_layers.py:192-249)             -> PropagationNet
+  SplitMLPs (gnn_layers.py:274-324)                  -> SplitMLPs
+  GNN_TYPES / get_gnn_class (gnn_layers.py:252-271)  -> same names
+  pyg.nn.Sequential of layers (graph_lam.py:117-126) -> GNNSequential
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .graph import EdgeCSR, build_edge_csr, build_tile_schedule
+from .ops import FusedMLPFunction, MlpGeometry, as_batched, segment_sum
+
+
+class FusedMLP(nn.Sequential):
+    """``Linear -> SiLU -> Linear [-> LayerNorm]`` with the reference's child
+    names (``0``, ``2``, ``3``), executed as one HIP kernel."""
+
+    def __init__(self, blueprint, layer_norm: bool = True):
+        hidden_layers = len(blueprint) - 2
+        assert hidden_layers >= 0, "Invalid MLP blueprint"
+        if hidden_layers != 1:
+            raise NotImplementedError(
+                "the fused gfx950 kernels cover hidden_layers == 1 (every BASELINE config); "
+                f"got a blueprint with {hidden_layers} hidden layers"
+            )
+        layers = [nn.Linear(blueprint[0], blueprint[1]), nn.SiLU(), nn.Linear(blueprint[1], blueprint[2])]
+        if layer_norm:
+            layers.append(nn.LayerNorm(blueprint[2]))
+        super().__init__(*layers)
+        self.has_layer_norm = layer_norm
+        self._geom = MlpGeometry(nsrc=1)
+
+    def params(self):
+        ln = self[3] if self.has_layer_norm else None
+        return (
+            self[0].weight, self[0].bias, self[2].weight, self[2].bias,
+            ln.weight if ln is not None else None, ln.bias if ln is not None else None,
+        )
+
+    def forward(self, x):
+        out, _ = FusedMLPFunction.apply(self._geom, *self.params(), x)
+        return out
+
+    def forward_fused(self, geom: MlpGeometry, *srcs):
+        """Run with a caller-supplied geometry (concatenated sources, residuals, ...)."""
+        return FusedMLPFunction.apply(geom, *self.params(), *srcs)
+
+
+def make_mlp(blueprint, layer_norm: bool = True) -> FusedMLP:
+    """utils/networks.py:8-40."""
+    return FusedMLP(blueprint, layer_norm=layer_norm)
+
+
+class SplitMLPs(nn.Module):
+    """gnn_layers.py:274-324: chunks of dim -2 through separate MLPs."""
+
+    def __init__(self, mlps, chunk_sizes):
+        super().__init__()
+        assert len(mlps) == len(chunk_sizes), "Number of MLPs must match the number of chunks"
+        self.mlps = nn.ModuleList(mlps)
+        self.chunk_sizes = chunk_sizes
+
+    def forward(self, x):
+        chunks = torch.split(x, self.chunk_sizes, dim=-2)
+        return torch.cat([mlp(c.contiguous()) for mlp, c in zip(self.mlps, chunks)], dim=-2)
+
+
+class _SegmentAggregate(torch.autograd.Function):
+    """messages in original edge order -> sum/mean per receiver (CSR segment sum)."""
+
+    @staticmethod
+    def forward(ctx, msgs, csr: EdgeCSR, mean: bool):
+        t, B, bstride, lead = as_batched(msgs)
+        d = msgs.shape[-1]
+        out = segment_sum(t, bstride, csr.rowptr, csr.perm, csr.inv_deg if mean else None, csr.num_rec, d, B)
+        ctx.csr, ctx.mean, ctx.shape = csr, mean, msgs.shape
+        return out.reshape(*lead, csr.num_rec, d)
+
+    @staticmethod
+    def backward(ctx, g):
+        csr = ctx.csr
+        g = g.reshape(-1, csr.num_rec, g.shape[-1])
+        if ctx.mean:
+            g = g * csr.inv_deg.view(1, -1, 1)
+        gm = torch.empty((g.shape[0], csr.num_edges, g.shape[-1]), device=g.device, dtype=g.dtype)
+        gm[:, csr.perm.long()] = g[:, csr.rec.long()]
+        return gm.reshape(ctx.shape), None, None
+
+
+class InteractionNet(nn.Module):
+    """Interaction network layer (Battaglia et al. 2016) as in gnn_layers.py:14-189."""
+
+    def __init__(
+        self,
+        edge_index: torch.Tensor,
+        input_dim: int,
+        update_edges: bool = True,
+        hidden_layers: int = 1,
+        hidden_dim: int | None = None,
+        edge_chunk_sizes: list[int] | None = None,
+        aggr_chunk_sizes: list[int] | None = None,
+        aggr: str = "sum",
+    ) -> None:
+        if aggr not in ("sum", "mean"):
+            raise ValueError(f"Unknown aggregation method: {aggr}")
+        super().__init__()
+        self.aggr = aggr
+        if hidden_dim is None:
+            hidden_dim = input_dim
+        self.num_rec = edge_index[1].max() + 1  # 0-dim tensor like the reference (gnn_layers.py:73)
+        self._edge_index_local = edge_index.detach().cpu().to(torch.int64)
+        self.register_buffer(
+            "edge_index", torch.stack((edge_index[0] + self.num_rec, edge_index[1]), dim=0), persistent=False
+        )
+        edge_recipe = [3 * input_dim] + [hidden_dim] * (hidden_layers + 1)
+        aggr_recipe = [2 * input_dim] + [hidden_dim] * (hidden_layers + 1)
+        if edge_chunk_sizes is None:
+            self.edge_mlp = make_mlp(edge_recipe)
+        else:
+            self.edge_mlp = SplitMLPs([make_mlp(edge_recipe) for _ in edge_chunk_sizes], edge_chunk_sizes)
+        if aggr_chunk_sizes is None:
+            self.aggr_mlp = make_mlp(aggr_recipe)
+        else:
+            self.aggr_mlp = SplitMLPs([make_mlp(aggr_recipe) for _ in aggr_chunk_sizes], aggr_chunk_sizes)
+        self.update_edges = update_edges
+        self._csr_cache: dict = {}
+        self._geom_cache: dict = {}
+
+    # reference hook points kept for API parity (gnn_layers.py:159-166, 231-239)
+    propagates_sender = False  # message() adds x_j               (PropagationNet)
+    residual_on_aggregate = False  # node residual targets the aggregate (PropagationNet)
+
+    def node_residual_target(self, rec_rep, edge_rep_aggr):
+        return edge_rep_aggr if self.residual_on_aggregate else rec_rep
+
+    # ---- device-side graph structure, built lazily per (device, num_send) ----
+    def _csr(self, device, num_send: int) -> EdgeCSR:
+        key = (str(device), num_send)
+        if key not in self._csr_cache:
+            n_rec = int(self.num_rec)
+            if num_send <= int(self._edge_index_local[0].max()):
+                raise RuntimeError("send_rep has fewer rows than the largest sender index in edge_index")
+            csr = build_edge_csr(self._edge_index_local, num_send=num_send, num_rec=n_rec)
+            tiles, has_split = build_tile_schedule(csr.rowptr)
+            csr = csr.to(device)
+            csr.tiles = tiles.to(device)
+            csr.has_split = has_split
+            self._csr_cache[key] = csr
+        return self._csr_cache[key]
+
+    def _edge_geom(self, csr: EdgeCSR, want_out: bool, add_edge: bool, key) -> MlpGeometry:
+        gkey = (key, want_out, add_edge)
+        if gkey not in self._geom_cache:
+            flags = 0
+            if add_edge:
+                flags |= L.F_ADD_SRC0
+            if self.propagates_sender:
+                flags |= L.F_ADD_SRC1
+            if self.aggr == "mean":
+                flags |= L.F_MEAN
+            self._geom_cache[gkey] = MlpGeometry(
+                nsrc=3,
+                flags=flags,
+                src_idx=[csr.perm, csr.send, csr.rec],
+                rows=csr.num_edges,
+                tiles=csr.tiles,
+                out_idx=csr.perm,
+                out_rows=csr.num_edges,
+                want_out=want_out,
+                aggregate=True,
+                rowptr=csr.rowptr,
+                inv_deg=csr.inv_deg,
+                seg_of_row=csr.rec,
+                nseg_total=csr.num_rec,
+                has_split=csr.has_split,
+                dmode=[1, 2, 3],
+                colptr=csr.colptr,
+                cperm=csr.cperm,
+                num_send=csr.num_send,
+            )
+        return self._geom_cache[gkey]
+
+    def _node_geom(self) -> MlpGeometry:
+        if "node" not in self._geom_cache:
+            flags = L.F_ADD_SRC1 if self.residual_on_aggregate else L.F_ADD_SRC0
+            self._geom_cache["node"] = MlpGeometry(nsrc=2, flags=flags)
+        return self._geom_cache["node"]
+
+    def _check_inputs(self, send_rep, rec_rep, edge_rep):
+        n_rec = int(self.num_rec)
+        if rec_rep.shape[-2] != n_rec:
+            raise RuntimeError(f"rec_rep has {rec_rep.shape[-2]} rows, layer was built for num_rec={n_rec}")
+        if edge_rep.shape[-2] != self._edge_index_local.shape[1]:
+            raise RuntimeError("edge_rep rows do not match the number of edges")
+
+    def _messages_and_aggregate(self, send_rep, rec_rep, edge_rep, want_out: bool, add_edge: bool):
+        """-> (aggr, edge_out | None); edge_out = msg (+ edge_rep if add_edge), original edge order."""
+        self._check_inputs(send_rep, rec_rep, edge_rep)
+        csr = self._csr(send_rep.device, send_rep.shape[-2])
+        if isinstance(self.edge_mlp, SplitMLPs):
+            return self._messages_generic(csr, send_rep, rec_rep, edge_rep, want_out, add_edge)
+        geom = self._edge_geom(csr, want_out, add_edge, (str(send_rep.device), send_rep.shape[-2]))
+        edge_out, aggr = self.edge_mlp.forward_fused(geom, edge_rep, send_rep, rec_rep)
+        return aggr, edge_out
+
+    def _messages_generic(self, csr, send_rep, rec_rep, edge_rep, want_out, add_edge):
+        # chunked edge MLPs (HiLAMParallel): per-chunk fused MLP kernels over an explicit
+        # gathered concat; aggregation by the CSR segment-sum kernel.
+        ei = self._edge_index_local.to(send_rep.device)
+        x_j = send_rep.index_select(-2, ei[0])
+        x_i = rec_rep.index_select(-2, ei[1])
+        msgs = self.edge_mlp(torch.cat((edge_rep.expand(*x_j.shape[:-2], -1, -1), x_j, x_i), dim=-1))
+        if self.propagates_sender:
+            msgs = x_j + msgs
+        aggr = _SegmentAggregate.apply(msgs, csr, self.aggr == "mean")
+        edge_out = None
+        if want_out:
+            edge_out = edge_rep + msgs if add_edge else msgs
+        return aggr, edge_out
+
+    def _node_update(self, rec_rep, aggr):
+        if isinstance(self.aggr_mlp, SplitMLPs):
+            rec_diff = self.aggr_mlp(torch.cat((rec_rep, aggr), dim=-1))
+            return self.node_residual_target(rec_rep, aggr) + rec_diff
+        out, _ = self.aggr_mlp.forward_fused(self._node_geom(), rec_rep, aggr)
+        return out
+
+    def forward(self, send_rep, rec_rep, edge_rep, need_edges: bool | None = None):
+        """``(send (..,N_s,d), rec (..,N_r,d), edge (..,E,d)) -> rec | (rec, edge)``
+        (gnn_layers.py:110-157).  ``need_edges=False`` lets a caller that discards
+        the edge output (graph_lam.py:185) skip writing it."""
+        if need_edges is None:
+            need_edges = self.update_edges
+        aggr, edge_out = self._messages_and_aggregate(send_rep, rec_rep, edge_rep, need_edges, True)
+        rec_out = self._node_update(rec_rep, aggr)
+        if self.update_edges:
+            return rec_out, edge_out
+        return rec_out
+
+    def propagate(self, edge_index, x, edge_attr):
+        """Compatibility shim for code that drives PyG's ``propagate`` directly
+        (tests/test_gnn_layers.py:249, 290, 380): ``x = cat(rec, send)`` ->
+        ``(aggregate, messages)``."""
+        n_rec = int(self.num_rec)
+        rec_rep, send_rep = x[..., :n_rec, :], x[..., n_rec:, :]
+        aggr, msgs = self._messages_and_aggregate(send_rep, rec_rep, edge_attr, True, False)
+        return aggr, msgs
+
+
+class PropagationNet(InteractionNet):
+    """gnn_layers.py:192-249: mean aggregation, ``x_j + edge_mlp(..)`` messages,
+    node residual onto the aggregate."""
+
+    propagates_sender = True
+    residual_on_aggregate = True
+
+    def __init__(
+        self,
+        edge_index,
+        input_dim,
+        update_edges=True,
+        hidden_layers=1,
+        hidden_dim=None,
+        edge_chunk_sizes=None,
+        aggr_chunk_sizes=None,
+        aggr="sum",
+    ):
+        super().__init__(
+            edge_index,
+            input_dim,
+            update_edges=update_edges,
+            hidden_layers=hidden_layers,
+            hidden_dim=hidden_dim,
+            edge_chunk_sizes=edge_chunk_sizes,
+            aggr_chunk_sizes=aggr_chunk_sizes,
+            aggr="mean",
+        )
+
+
+GNN_TYPES = {"InteractionNet": InteractionNet, "PropagationNet": PropagationNet}
+
+
+def get_gnn_class(gnn_type: str):
+    if gnn_type not in GNN_TYPES:
+        raise ValueError(f"Unknown GNN type '{gnn_type}'. Available types: {list(GNN_TYPES.keys())}")
+    return GNN_TYPES[gnn_type]
+
+
+class GNNSequential(nn.Module):
+    """Stack of same-edge-set layers ``(mesh, mesh, edge) -> (mesh, edge)``; child
+    names ``module_{i}`` follow ``pyg.nn.Sequential`` so checkpoint keys match."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self._n = len(layers)
+        for i, layer in enumerate(layers):
+            self.add_module(f"module_{i}", layer)
+
+    def forward(self, mesh_rep, edge_rep, need_last_edges: bool = True):
+        for i in range(self._n):
+            layer = getattr(self, f"module_{i}")
+            last = i == self._n - 1
+            if last and not need_last_edges:
+                mesh_rep, edge_rep = layer(mesh_rep, mesh_rep, edge_rep, need_edges=False)
+            else:
+                mesh_rep, edge_rep = layer(mesh_rep, mesh_rep, edge_rep)
+        return mesh_rep, edge_rep
+
+
+def make_gnn_seq(edge_index, num_gnn_layers, hidden_layers, hidden_dim, gnn_type="InteractionNet"):
+    """utils/networks.py:43-106."""
+    if num_gnn_layers < 1:
+        raise ValueError(
+            f"make_gnn_seq requires num_gnn_layers >= 1 (got {num_gnn_layers}); skip the stage for a no-op."
+        )
+    cls = get_gnn_class(gnn_type)
+    return GNNSequential([cls(edge_index, hidden_dim, hidden_layers=hidden_layers) for _ in range(num_gnn_layers)])

@@ -392,3 +392,51 @@ def graph_summary(raw: dict) -> dict:
     if "mesh_up_edge_index" in raw:
         s["up_edges"] = [int(e.shape[1]) for e in raw["mesh_up_edge_index"]]
     return s
+
+
+# --------------------------------------------------------------------------
+# wave-tile schedule (consumed by csrc/nlam_hip.hip through nlam_tile_t)
+# --------------------------------------------------------------------------
+TILE_ROWS = 32  # columns of v_mfma_f32_32x32x2_f32 = rows (edges) one wave owns
+TILE_SPLIT = 1 << 30
+
+
+def build_tile_schedule(rowptr: torch.Tensor, tile_rows: int = TILE_ROWS):
+    """Partition the receivers into tiles of whole receivers with <= ``tile_rows``
+    edges (and <= ``tile_rows`` receivers).  A receiver with more in-edges than a
+    tile holds is split over several tiles flagged ``TILE_SPLIT`` (the kernel
+    adds those partial sums atomically; everything else uses plain stores).
+
+    Returns (int32 tensor (ntiles, 4) = [row0, nrows, seg0, nseg|flag], has_split).
+    """
+    rp = rowptr.detach().cpu().numpy().astype(np.int64)
+    nrec = rp.shape[0] - 1
+    tiles = []
+    has_split = False
+    cur_r0, cur_e0, cur_ne, cur_nr = 0, 0, 0, 0
+
+    def flush():
+        nonlocal cur_ne, cur_nr
+        if cur_nr > 0:
+            tiles.append((cur_e0, cur_ne, cur_r0, cur_nr))
+        cur_ne, cur_nr = 0, 0
+
+    for r in range(nrec):
+        deg = int(rp[r + 1] - rp[r])
+        if deg > tile_rows:
+            flush()
+            has_split = True
+            for e in range(int(rp[r]), int(rp[r + 1]), tile_rows):
+                tiles.append((e, min(tile_rows, int(rp[r + 1]) - e), r, 1 | TILE_SPLIT))
+            cur_r0, cur_e0 = r + 1, int(rp[r + 1])
+            continue
+        if cur_nr == 0:
+            cur_r0, cur_e0 = r, int(rp[r])
+        elif cur_ne + deg > tile_rows or cur_nr == tile_rows:
+            flush()
+            cur_r0, cur_e0 = r, int(rp[r])
+        cur_ne += deg
+        cur_nr += 1
+    flush()
+    t = torch.tensor(tiles, dtype=torch.int64).reshape(-1, 4).to(torch.int32)
+    return t.contiguous(), has_split

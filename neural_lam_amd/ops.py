@@ -1,0 +1,307 @@
+"""Autograd operators over the C-ABI of include/nlam_hip.h.
+
+PyTorch is used for device memory (caching allocator), the current HIP stream
+and the autograd graph; every FLOP of the hot path runs in libnlam_hip.so.
+There is deliberately no eager / CPU fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib as L
+
+_VEC_W = 64  # kMaxWidth of the kernels: row width of the vector-partials buffer
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "neural_lam_amd operators run on MI355X only: got a CPU tensor "
+                "(there is no CPU/eager fallback; use the oracle/ package for a CPU reference)"
+            )
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"neural_lam_amd operators are fp32: got {t.dtype}")
+
+
+def as_batched(x: torch.Tensor):
+    """(..., N, w) -> (tensor whose storage the kernel reads, B, bstride, lead_shape).
+
+    A batch that is a stride-0 expansion (``StepPredictor.expand_to_batch``,
+    step_predictors/base.py:122-139) is *not* materialised: the kernel gets
+    bstride = 0 and reads the single copy.
+    """
+    lead = x.shape[:-2]
+    N, w = x.shape[-2], x.shape[-1]
+    B = 1
+    for s in lead:
+        B *= s
+    if len(lead) > 0 and B > 1 and all(st == 0 for st, sz in zip(x.stride()[:-2], lead) if sz > 1):
+        base = x[(0,) * len(lead)]
+        if not base.is_contiguous():
+            base = base.contiguous()
+        return base, B, 0, lead
+    xc = x if x.is_contiguous() else x.contiguous()
+    return xc, B, N * w, lead
+
+
+@dataclass
+class MlpGeometry:
+    """Static description of one fused-MLP call site (built once per module)."""
+
+    nsrc: int
+    flags: int = 0
+    src_idx: list = field(default_factory=lambda: [None, None, None])  # int32 device tensors or None
+    rows: int | None = None          # tile-rows per batch item (None: rows of source 0)
+    tiles: torch.Tensor | None = None  # (ntiles, 4) int32 on device
+    out_idx: torch.Tensor | None = None
+    out_rows: int | None = None
+    want_out: bool = True
+    aggregate: bool = False
+    rowptr: torch.Tensor | None = None
+    inv_deg: torch.Tensor | None = None
+    seg_of_row: torch.Tensor | None = None
+    nseg_total: int = 0
+    has_split: bool = False
+    dmode: list = field(default_factory=lambda: [1, 1, 1])
+    # for dmode == 2: CSC structure to finish the scatter-by-sender as a segment sum
+    colptr: torch.Tensor | None = None
+    cperm: torch.Tensor | None = None
+    num_send: int = 0
+
+
+def _fill_src(dst, tensor, bstride, width, idx):
+    dst.ptr = _ptr(tensor)
+    dst.idx = _ptr(idx)
+    dst.bstride = bstride
+    dst.width = width
+
+
+def segment_sum(inp, in_bstride, ptr, order, scale, nseg, width, batch, out=None):
+    """out[b, s] = scale[s] * sum_{q in ptr[s]:ptr[s+1]} inp[b, order[q]]"""
+    _require_gpu(inp)
+    if out is None:
+        out = torch.empty((batch, nseg, width), device=inp.device, dtype=torch.float32)
+    rc = L.load().nlam_segment_sum(
+        _ptr(inp), in_bstride, _ptr(ptr), _ptr(order), _ptr(scale), _ptr(out), nseg, width, batch, _stream()
+    )
+    L.check(rc, "nlam_segment_sum")
+    return out
+
+
+class FusedMLPFunction(torch.autograd.Function):
+    """[gather|concat] -> Linear -> SiLU -> Linear -> [LayerNorm] -> residuals / aggregation.
+
+    forward(geom, W1, b1, W2, b2, ln_w, ln_b, *sources) -> (out | None, aggr | None)
+    """
+
+    @staticmethod
+    def forward(ctx, geom: MlpGeometry, W1, b1, W2, b2, ln_w, ln_b, *srcs):
+        lib = L.load()
+        _require_gpu(W1, b1, W2, b2, ln_w, ln_b, *srcs)
+        assert len(srcs) == geom.nsrc
+        hid, kin = W1.shape
+        dout = W2.shape[0]
+        binfo = [as_batched(s) for s in srcs]
+        B = max(bi[1] for bi in binfo)
+        lead = max((bi[3] for bi in binfo), key=len)
+        for (t, b_, _, _), s in zip(binfo, srcs):
+            if b_ not in (1, B):
+                raise RuntimeError(f"inconsistent batch sizes among sources: {b_} vs {B}")
+        widths = [s.shape[-1] for s in srcs]
+        if sum(widths) != kin:
+            raise RuntimeError(f"source widths {widths} do not add up to the first Linear's in_features {kin}")
+        rows = geom.rows if geom.rows is not None else srcs[0].shape[-2]
+        ntiles = geom.tiles.shape[0] if geom.tiles is not None else (rows + 31) // 32
+        dev = srcs[0].device
+        need_grad = any(ctx.needs_input_grad[1:])
+
+        p = L.MlpFwd()
+        for k in range(geom.nsrc):
+            t, b_, bstride, _ = binfo[k]
+            _fill_src(p.src[k], t, bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k])
+        p.nsrc, p.batch, p.rows, p.ntiles = geom.nsrc, B, rows, ntiles
+        p.tiles = _ptr(geom.tiles)
+        W1c, b1c, W2c, b2c = W1.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous()
+        p.W1, p.b1, p.W2, p.b2 = _ptr(W1c), _ptr(b1c), _ptr(W2c), _ptr(b2c)
+        p.ln_w, p.ln_b = _ptr(ln_w), _ptr(ln_b)
+        p.eps, p.hid, p.dout, p.flags = 1e-5, hid, dout, geom.flags
+        out = aggr = None
+        if geom.want_out:
+            out_rows = geom.out_rows if geom.out_rows is not None else rows
+            out = torch.empty((B, out_rows, dout), device=dev, dtype=torch.float32)
+            p.out, p.out_idx, p.out_bstride = _ptr(out), _ptr(geom.out_idx), out_rows * dout
+        if geom.aggregate:
+            alloc = torch.zeros if geom.has_split else torch.empty
+            aggr = alloc((B, geom.nseg_total, dout), device=dev, dtype=torch.float32)
+            p.aggr, p.rowptr, p.inv_deg, p.nseg_total = _ptr(aggr), _ptr(geom.rowptr), _ptr(geom.inv_deg), geom.nseg_total
+        z1 = xhat = rstd = None
+        if need_grad:
+            z1 = torch.empty((B, rows, hid), device=dev, dtype=torch.float32)
+            p.z1 = _ptr(z1)
+            if ln_w is not None:
+                xhat = torch.empty((B, rows, dout), device=dev, dtype=torch.float32)
+                rstd = torch.empty((B, rows), device=dev, dtype=torch.float32)
+                p.xhat, p.rstd = _ptr(xhat), _ptr(rstd)
+        L.check(lib.nlam_mlp_fwd(C.byref(p), _stream()), "nlam_mlp_fwd")
+
+        if need_grad:
+            ctx.geom, ctx.B, ctx.rows, ctx.ntiles = geom, B, rows, ntiles
+            ctx.binfo = [(b_, bstride) for (_, b_, bstride, _) in binfo]
+            ctx.src_shapes = [tuple(s.shape) for s in srcs]
+            ctx.has_ln = ln_w is not None
+            ctx.save_for_backward(W1c, W2c, ln_w, z1, xhat, rstd, *[bi[0] for bi in binfo])
+            ctx.set_materialize_grads(False)
+        if out is not None:
+            out = out.reshape(*lead, out.shape[-2], dout) if len(lead) != 1 else out
+        if aggr is not None:
+            aggr = aggr.reshape(*lead, geom.nseg_total, dout) if len(lead) != 1 else aggr
+        return out, aggr
+
+    @staticmethod
+    def backward(ctx, g_out, g_aggr):
+        lib = L.load()
+        geom: MlpGeometry = ctx.geom
+        W1, W2, ln_w, z1, xhat, rstd, *bases = ctx.saved_tensors
+        B, rows, ntiles = ctx.B, ctx.rows, ctx.ntiles
+        hid, kin = W1.shape
+        dout = W2.shape[0]
+        dev = W1.device
+        nsrc = geom.nsrc
+        widths = [s[-1] for s in ctx.src_shapes]
+        n_fixed = 7
+        if g_out is None and g_aggr is None:
+            return (None,) * (n_fixed + nsrc)
+        if g_out is not None:
+            g_out = g_out.reshape(B, -1, dout).contiguous()
+        if g_aggr is not None:
+            g_aggr = g_aggr.reshape(B, -1, dout).contiguous()
+
+        p = L.MlpBwd()
+        for k in range(nsrc):
+            b_, bstride = ctx.binfo[k]
+            _fill_src(p.src[k], bases[k], bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k])
+        p.nsrc, p.batch, p.rows, p.ntiles = nsrc, B, rows, ntiles
+        p.tiles = _ptr(geom.tiles)
+        p.W1, p.W2, p.ln_w = _ptr(W1), _ptr(W2), _ptr(ln_w) if ctx.has_ln else None
+        p.hid, p.dout, p.flags, p.nseg_total = hid, dout, geom.flags, geom.nseg_total
+        if g_out is not None:
+            p.g_out, p.out_idx, p.out_bstride = _ptr(g_out), _ptr(geom.out_idx), g_out.shape[1] * dout
+        if g_aggr is not None:
+            p.g_aggr, p.seg_of_row = _ptr(g_aggr), _ptr(geom.seg_of_row)
+        p.rowptr, p.inv_deg = _ptr(geom.rowptr), _ptr(geom.inv_deg)
+        p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
+        dz1 = torch.empty((B * rows, hid), device=dev, dtype=torch.float32)
+        dz2 = torch.empty((B * rows, dout), device=dev, dtype=torch.float32)
+        p.dz1, p.dz2 = _ptr(dz1), _ptr(dz2)
+        dsrc = [None] * nsrc
+        tmp2 = [None] * nsrc
+        for k in range(nsrc):
+            if not ctx.needs_input_grad[n_fixed + k]:
+                p.dmode[k] = 0
+                continue
+            mode = geom.dmode[k]
+            w = widths[k]
+            n_src_rows = ctx.src_shapes[k][-2]
+            p.dmode[k] = mode
+            if mode == 1:
+                # rows scattered through the (unique, covering) gather index, or identity
+                dsrc[k] = torch.empty((B, n_src_rows, w), device=dev, dtype=torch.float32)
+                p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), n_src_rows * w
+            elif mode == 2:
+                tmp2[k] = torch.empty((B, rows, w), device=dev, dtype=torch.float32)
+                p.dsrc[k], p.dsrc_bstride[k] = _ptr(tmp2[k]), rows * w
+            elif mode == 3:
+                alloc = torch.zeros if geom.has_split else torch.empty
+                dsrc[k] = alloc((B, geom.nseg_total, w), device=dev, dtype=torch.float32)
+                p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), geom.nseg_total * w
+        grid_waves = lib.nlam_grid_waves()
+        vecp = torch.empty((grid_waves, 4, _VEC_W), device=dev, dtype=torch.float32)
+        p.vec_partials, p.vec_partials_rows = _ptr(vecp), grid_waves
+        L.check(lib.nlam_mlp_bwd(C.byref(p), _stream()), "nlam_mlp_bwd")
+
+        for k in range(nsrc):
+            if tmp2[k] is not None:  # finish scatter-by-sender as a CSC segment sum
+                dsrc[k] = segment_sum(
+                    tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B
+                )
+
+        # ---- weight gradients: two TN GEMMs with deterministic two-stage reduction ----
+        total_chunks = B * ((rows + 31) // 32)
+        nparts = max(1, min(512, total_chunks // 2))
+
+        def wgrad(A, m, src_list, n, flags):
+            q = L.Wgrad()
+            q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(src_list), flags, n
+            for k, (t, bstride, w, idx) in enumerate(src_list):
+                _fill_src(q.src[k], t, bstride, w, idx)
+            partials = torch.empty((nparts, m, n), device=dev, dtype=torch.float32)
+            q.partials, q.nparts = _ptr(partials), nparts
+            L.check(lib.nlam_wgrad(C.byref(q), _stream()), "nlam_wgrad")
+            outw = torch.empty((m, n), device=dev, dtype=torch.float32)
+            L.check(
+                lib.nlam_reduce_partials(_ptr(partials), nparts, m * n, m * n, _ptr(outw), 0, _stream()),
+                "nlam_reduce_partials",
+            )
+            return outw
+
+        src_list = []
+        for k in range(nsrc):
+            b_, bstride = ctx.binfo[k]
+            src_list.append((bases[k], bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k]))
+        dW1 = wgrad(dz1, hid, src_list, kin, 0) if ctx.needs_input_grad[1] else None
+        dW2 = wgrad(dz2, dout, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if ctx.needs_input_grad[3] else None
+        vec = torch.empty((4, _VEC_W), device=dev, dtype=torch.float32)
+        L.check(
+            lib.nlam_reduce_partials(_ptr(vecp), grid_waves, 4 * _VEC_W, 4 * _VEC_W, _ptr(vec), 0, _stream()),
+            "nlam_reduce_partials",
+        )
+        db1, db2 = vec[0, :hid], vec[1, :dout]
+        dg = vec[2, :dout] if ctx.has_ln else None
+        dbt = vec[3, :dout] if ctx.has_ln else None
+
+        grads_src = []
+        for k in range(nsrc):
+            g = dsrc[k]
+            if g is not None:
+                b_, _ = ctx.binfo[k]
+                shape = ctx.src_shapes[k]
+                lead_numel = 1
+                for s in shape[:-2]:
+                    lead_numel *= s
+                if lead_numel != B:  # source had no batch dim of its own
+                    g = g.sum(0) if B > 1 else g[0]
+                g = g.reshape(shape)
+            grads_src.append(g)
+        return (None, dW1, db1, dW2, db2, dg, dbt, *grads_src)
+
+
+class AdamWFlat:
+    """torch.optim.AdamW(lr, betas=(0.9, 0.95)) semantics (models/module.py:293-304)
+    on one flat fp32 buffer: a single HBM-bound kernel per step."""
+
+    def __init__(self, flat_param, flat_grad, lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-2):
+        self.p, self.g = flat_param, flat_grad
+        self.m = torch.zeros_like(flat_param)
+        self.v = torch.zeros_like(flat_param)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.t = 0
+
+    def step(self, grad_scale: float = 1.0):
+        self.t += 1
+        rc = L.load().nlam_adamw_step(
+            _ptr(self.p), _ptr(self.g), _ptr(self.m), _ptr(self.v), self.p.numel(), self.lr, self.betas[0],
+            self.betas[1], self.eps, self.wd, self.t, grad_scale, _stream(),
+        )
+        L.check(rc, "nlam_adamw_step")
