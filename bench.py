@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py -- training-step throughput of the GraphCast-LAM hot path on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (for N > 1
+launched under torch.distributed.run, one rank per GPU over RCCL).  W untimed
+warm-up steps, then exactly K training steps bracketed by barrier +
+synchronize; the max over ranks is the job time; rank 0 prints ONE JSON line.
+
+A step = ``ForecasterModule.training_step``-equivalent on one pre-resident
+synthetic batch per GPU: standardised inputs -> AR rollout
+(ar_steps) through GraphLAM -> masked wmse -> backward -> gradient all-reduce
+(N > 1) -> AdamW.  Workload at N = 1 = BASELINE.json configs[1]: GraphCast-LAM
+multiscale mesh on the synthetic MEPS-shaped 238x268 grid, 17 state variables,
+hidden_dim 64, 4 processor layers, batch 1 per GPU, ar_steps 1, fp32.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel = mlp_fwd_kernel<2,2> on the m2g edge set
+                (255 136 edges): algorithmic FLOPs 8*E*d^2 / measured launch time
+                (HIP events on the launch stream, averaged over the K timed steps
+                of a second, instrumented pass) vs. the fp32-MFMA peak.
+  cpu_baseline  the oracle (pure-torch restatement of the reference) timed on this
+                box's host cores on the same workload, bounded to a few steps.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+CONFIGS = {
+    # name: (nx, ny, n_state, n_forcing, n_static, hidden, proc_layers, ar_steps, batch_per_gpu, model, graph kwargs)
+    "cfg2": dict(nx=238, ny=268, ns=17, nf=6, nst=4, d=64, L=4, T=1, B=1, model="graph_lam",
+                 graph=dict(n_max_levels=None, hierarchical=False), boundary="frame"),
+    "cfg1": dict(nx=64, ny=64, ns=5, nf=2, nst=1, d=16, L=4, T=1, B=2, model="graph_lam",
+                 graph=dict(n_max_levels=1, hierarchical=False), boundary="random"),
+}
+
+
+def build(cfg, device, seed_offset=0, oracle=False):
+    from neural_lam_amd import graph as G
+    from neural_lam_amd.datastore import SyntheticDatastore
+
+    ds = SyntheticDatastore(cfg["nx"], cfg["ny"], cfg["ns"], cfg["nf"], cfg["nst"], root_path="/tmp/nlam_bench",
+                            boundary=cfg["boundary"], seed=0)
+    ext = ds.get_xy_extent("state")
+    raw = G.create_regular_grid_graph(ds.get_xy("state"), **cfg["graph"])
+    graph = G.normalise_graph(raw, max(ext[1] - ext[0], ext[3] - ext[2]))
+    torch.manual_seed(42)  # weights: default init under seed 42
+    if oracle:
+        from oracle import models as om
+
+        predictor = om.MODELS[cfg["model"]](ds, graph, hidden_dim=cfg["d"], processor_layers=cfg["L"])
+        forecaster = om.ARForecaster(predictor, ds)
+        step = None
+    else:
+        from neural_lam_amd import models as hm
+
+        predictor = hm.MODELS[cfg["model"]](ds, graph=graph, hidden_dim=cfg["d"], processor_layers=cfg["L"])
+        forecaster = hm.ARForecaster(predictor, ds)
+        step = hm.ForecasterStep(forecaster, ds).to(device)
+    N, B, T = ds.num_grid_points, cfg["B"], cfg["T"]
+    g = torch.Generator().manual_seed(123 + seed_offset)  # inputs ~ N(0,1), seed 123 (+rank)
+    init = torch.randn(B, 2, N, cfg["ns"], generator=g)
+    target = torch.randn(B, T, N, cfg["ns"], generator=g)
+    forcing = torch.randn(B, T, N, cfg["nf"] * 3, generator=g)
+    batch = tuple(t.to(device) for t in (init, target, forcing))
+    return ds, graph, raw, forecaster, step, batch
+
+
+def cpu_baseline(cfg, budget_s=25.0):
+    """Oracle training step (fwd + wmse + bwd + AdamW) on the host cores."""
+    from oracle import models as om
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ds, _, _, forecaster, _, batch = build(cfg, torch.device("cpu"), oracle=True)
+    pvs, mask = om.per_var_std_uniform(ds), om.interior_mask_bool(ds)
+    opt = torch.optim.AdamW(forecaster.parameters(), lr=1e-3, betas=(0.9, 0.95))
+
+    def one():
+        opt.zero_grad(set_to_none=True)
+        _, loss = om.training_loss(forecaster, batch, pvs, mask)
+        loss.backward()
+        opt.step()
+
+    one()  # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {
+        "value": cfg["B"] * cfg["T"] / med,
+        "unit": "sample-steps/s",
+        "ms_per_step": med * 1e3,
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{len(times)} full training steps of the same workload (median), oracle = PyG-free torch fp32 "
+                  f"restatement of the reference, torch.set_num_threads({cores})",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback); CPU numbers come from the cpu_baseline leg only")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    from neural_lam_amd import ops
+    from neural_lam_amd.trainer import Trainer
+
+    ds, graph, raw, forecaster, step, batch = build(cfg, device, seed_offset=rank)
+    trainer = Trainer(step, lr=1e-3)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(*batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(*batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * cfg["B"] * cfg["T"] * args.steps / elapsed
+
+    # forecast throughput (inference rollout, no grad), reported alongside
+    with torch.no_grad():
+        for _ in range(2):
+            step.forecaster(batch[0], batch[2], batch[1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step.forecaster(batch[0], batch[2], batch[1])
+        torch.cuda.synchronize()
+        fc_elapsed = time.perf_counter() - t0
+    forecast_steps_per_s = world * cfg["B"] * cfg["T"] * args.steps / fc_elapsed
+
+    roofline = None
+    if not args.no_roofline:
+        # second, instrumented pass: HIP events (on the launch stream = torch's current
+        # stream) around every nlam_mlp_fwd launch; pick the m2g edge launch (largest E)
+        ops.PROFILE.reset(enabled=True)
+        for _ in range(args.steps):
+            trainer.step(*batch)
+        torch.cuda.synchronize()
+        recs = ops.PROFILE.collect()
+        ops.PROFILE.reset(enabled=False)
+        E = int(raw["m2g_edge_index"].shape[1])
+        d = cfg["d"]
+        key = ("mlp_fwd", E * cfg["B"], 3 * d, d, d)
+        if key in recs and recs[key]:
+            avg_ms = sum(recs[key]) / len(recs[key])
+            flops = 8.0 * E * cfg["B"] * d * d  # edge MLP: 2*E*(3d*d + d*d)
+            achieved = flops / (avg_ms * 1e-3) / 1e12
+            roofline = {
+                "bound": "mfma",
+                "kernel": "mlp_fwd_kernel<2,2> (m2g edge set: gather+edge MLP+LN+aggregate)",
+                "achieved": achieved,
+                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "avg_launch_ms": avg_ms,
+                "launches": len(recs[key]),
+                "traffic": None,
+            }
+
+    if rank == 0:
+        out = {
+            "metric": "training sample-steps/s (fwd+wmse+bwd+allreduce+AdamW), GraphCast-LAM, MEPS-shaped grid",
+            "value": value,
+            "unit": "sample-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "forecast_steps_per_s": forecast_steps_per_s,
+            "final_loss": float(loss),
+            "config": {
+                "workload": f"{args.config}: GraphLAM multiscale, grid {cfg['nx']}x{cfg['ny']} ({ds.num_grid_points} nodes), "
+                            f"{cfg['ns']} state vars, hidden_dim {cfg['d']}, {cfg['L']} processor layers, "
+                            f"ar_steps {cfg['T']}, batch {cfg['B']}/GPU, g2m/m2m/m2g edges "
+                            f"{raw['g2m_edge_index'].shape[1]}/{raw['m2m_edge_index'][0].shape[1]}/{raw['m2g_edge_index'].shape[1]}",
+                "global_batch": world * cfg["B"],
+                "parallelism": f"dp{world}",
+            },
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

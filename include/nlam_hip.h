@@ -137,8 +137,8 @@ typedef struct {
                                       | 2 tile-row order (rows, width) for a later segment sum
                                       | 3 segment-summed over the tile's receivers -> (nseg_total, width) */
     int32_t _pad;
-    float* vec_partials;   /* (nwaves, 4, DP): db1, db2, dgamma, dbeta partial sums */
-    int32_t vec_partials_rows; /* out: capacity in rows; must be >= nlam_grid_waves() */
+    float* vec_partials;   /* (nblocks, 4, 64): per-workgroup db1, db2, dgamma, dbeta partial sums */
+    int32_t vec_partials_rows; /* capacity in rows; must be >= nlam_num_blocks(ntiles * batch) */
     int32_t _pad2;
 } nlam_mlp_bwd_t;
 
@@ -159,6 +159,8 @@ typedef struct {
 /* number of persistent waves the fwd/bwd kernels launch (for sizing vec_partials) */
 int32_t nlam_grid_waves(void);
 int32_t nlam_abi_version(void);
+/* workgroups nlam_mlp_fwd / nlam_mlp_bwd launch for `total_tiles` = ntiles * batch */
+int32_t nlam_num_blocks(int64_t total_tiles);
 /* widest hidden/output width the fused kernels of this build instantiate */
 int32_t nlam_max_width(void);
 

@@ -20,6 +20,7 @@ TILE_SPLIT = 1 << 30
 EXPORTS = [
     "nlam_abi_version",
     "nlam_grid_waves",
+    "nlam_num_blocks",
     "nlam_max_width",
     "nlam_mlp_fwd",
     "nlam_mlp_bwd",
@@ -153,6 +154,8 @@ def load():
     lib.nlam_abi_version.restype = i32
     lib.nlam_grid_waves.restype = i32
     lib.nlam_max_width.restype = i32
+    lib.nlam_num_blocks.argtypes = [i64]
+    lib.nlam_num_blocks.restype = i32
     lib.nlam_mlp_fwd.argtypes = [C.POINTER(MlpFwd), vp]
     lib.nlam_mlp_fwd.restype = i32
     lib.nlam_mlp_bwd.argtypes = [C.POINTER(MlpBwd), vp]

@@ -684,15 +684,20 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_kernel(const nlam_mlp_b
         }
     }
 
-    // ---- flush the per-wave vector partials ----
+    // ---- combine the 8 waves' vector partials through LDS; one row per workgroup ----
     if (p.vec_partials != nullptr) {
-        const int gw = blockIdx.x * kWavesPerBlock + wave;
-        float* dst = p.vec_partials + (size_t)gw * 4 * kMaxWidth;
-        if (lane < kMaxWidth) {
-            dst[0 * kMaxWidth + lane] = acc_db1;
-            dst[1 * kMaxWidth + lane] = acc_db2;
-            dst[2 * kMaxWidth + lane] = acc_dg;
-            dst[3 * kMaxWidth + lane] = acc_dbt;
+        __syncthreads();  // every wave is done with its staging area
+        float* red = stg_all;  // kWavesPerBlock x 4 x 64 floats (fits: staging is 8 x 32 x 68)
+        red[(wave * 4 + 0) * 64 + lane] = acc_db1;
+        red[(wave * 4 + 1) * 64 + lane] = acc_db2;
+        red[(wave * 4 + 2) * 64 + lane] = acc_dg;
+        red[(wave * 4 + 3) * 64 + lane] = acc_dbt;
+        __syncthreads();
+        if (wave < 4) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; ++w) s += red[(w * 4 + wave) * 64 + lane];
+            p.vec_partials[((size_t)blockIdx.x * 4 + wave) * kMaxWidth + lane] = s;
         }
     }
 }
@@ -827,11 +832,28 @@ __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32
     }
 }
 
-__global__ void reduce_partials_kernel(const float* partials, int nparts, long stride, int n, float* out, int accumulate) {
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+// out[idx] (+)= sum_p partials[p][idx]: lane -> idx, the block's 4 waves split the parts,
+// fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partials, int nparts, long stride, int n,
+                                                              float* out, int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
+        const int idx = base + lane;
         float s = 0.f;
-        for (int q = 0; q < nparts; ++q) s += partials[(size_t)q * stride + idx];
-        out[idx] = accumulate ? out[idx] + s : s;
+        if (idx < n) {
+            const int per = (nparts + 3) / 4;
+            const int q0 = wave * per, q1 = min(nparts, q0 + per);
+#pragma unroll 8
+            for (int q = q0; q < q1; ++q) s += partials[(size_t)q * stride + idx];
+        }
+        red[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && idx < n) {
+            const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            out[idx] = accumulate ? out[idx] + t : t;
+        }
+        __syncthreads();
     }
 }
 
@@ -899,6 +921,7 @@ extern "C" {
 
 int32_t nlam_abi_version(void) { return NLAM_ABI_VERSION; }
 int32_t nlam_grid_waves(void) { return kMaxGridBlocks * kWavesPerBlock; }
+int32_t nlam_num_blocks(int64_t total_tiles) { return grid_blocks((long)total_tiles); }
 int32_t nlam_max_width(void) { return kMaxWidth; }
 
 #define NLAM_LAUNCH_FWD(HB_, OB_)                                                                      \
@@ -949,15 +972,10 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
         if (p->dmode[s] != 0 && p->dsrc[s] == nullptr) return NLAM_EINVAL;
         if (p->dmode[s] == 3 && (p->rowptr == nullptr || p->tiles == nullptr)) return NLAM_EINVAL;
     }
-    if (p->vec_partials != nullptr && p->vec_partials_rows < nlam_grid_waves()) return NLAM_EINVAL;
+    if (p->vec_partials != nullptr && p->vec_partials_rows < nlam_num_blocks((int64_t)p->ntiles * p->batch)) return NLAM_EINVAL;
     if (p->rows == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
     const int blocks = grid_blocks((long)p->ntiles * p->batch);
-    if (p->vec_partials != nullptr) {
-        // waves of blocks that are not launched contribute zeros
-        hipError_t e = hipMemsetAsync(p->vec_partials, 0, (size_t)nlam_grid_waves() * 4 * kMaxWidth * sizeof(float), stream);
-        if (e != hipSuccess) return (int)e;
-    }
     const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
     if (HB == 1 && OB == 1) NLAM_LAUNCH_BWD(1, 1);
     else if (HB == 2 && OB == 1) NLAM_LAUNCH_BWD(2, 1);
@@ -1005,7 +1023,7 @@ int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr
 int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stride, int32_t n, float* out,
                              int32_t accumulate, void* hip_stream) {
     if (partials == nullptr || out == nullptr || nparts < 1 || n < 1) return NLAM_EINVAL;
-    int blocks = (n + 255) / 256;
+    int blocks = (n + 63) / 64;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream, partials, nparts,
                        (long)stride, n, out, accumulate);

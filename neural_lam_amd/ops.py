@@ -20,6 +20,40 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _LaunchProfile:
+    """Optional HIP-event bracketing of individual kernel launches (bench.py's
+    roofline leg).  Events are recorded on torch's current stream, which is the
+    stream every launch of this module uses."""
+
+    def __init__(self):
+        self.enabled = False
+        self._pairs = []
+
+    def reset(self, enabled: bool):
+        self.enabled = enabled
+        self._pairs = []
+
+    def launch(self, key, fn):
+        if not self.enabled:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        self._pairs.append((key, e0, e1))
+        return rc
+
+    def collect(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, e0, e1 in self._pairs:
+            out.setdefault(key, []).append(e0.elapsed_time(e1))
+        return out
+
+
+PROFILE = _LaunchProfile()
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -154,7 +188,8 @@ class FusedMLPFunction(torch.autograd.Function):
                 xhat = torch.empty((B, rows, dout), device=dev, dtype=torch.float32)
                 rstd = torch.empty((B, rows), device=dev, dtype=torch.float32)
                 p.xhat, p.rstd = _ptr(xhat), _ptr(rstd)
-        L.check(lib.nlam_mlp_fwd(C.byref(p), _stream()), "nlam_mlp_fwd")
+        key = ("mlp_fwd", rows * B, kin, hid, dout)
+        L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_fwd(C.byref(p), _stream())), "nlam_mlp_fwd")
 
         if need_grad:
             ctx.geom, ctx.B, ctx.rows, ctx.ntiles = geom, B, rows, ntiles
@@ -226,10 +261,11 @@ class FusedMLPFunction(torch.autograd.Function):
                 alloc = torch.zeros if geom.has_split else torch.empty
                 dsrc[k] = alloc((B, geom.nseg_total, w), device=dev, dtype=torch.float32)
                 p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), geom.nseg_total * w
-        grid_waves = lib.nlam_grid_waves()
-        vecp = torch.empty((grid_waves, 4, _VEC_W), device=dev, dtype=torch.float32)
-        p.vec_partials, p.vec_partials_rows = _ptr(vecp), grid_waves
-        L.check(lib.nlam_mlp_bwd(C.byref(p), _stream()), "nlam_mlp_bwd")
+        nblk = lib.nlam_num_blocks(ntiles * B)
+        vecp = torch.empty((nblk, 4, _VEC_W), device=dev, dtype=torch.float32)
+        p.vec_partials, p.vec_partials_rows = _ptr(vecp), nblk
+        key = ("mlp_bwd", rows * B, kin, hid, dout)
+        L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_bwd(C.byref(p), _stream())), "nlam_mlp_bwd")
 
         for k in range(nsrc):
             if tmp2[k] is not None:  # finish scatter-by-sender as a CSC segment sum
@@ -239,7 +275,7 @@ class FusedMLPFunction(torch.autograd.Function):
 
         # ---- weight gradients: two TN GEMMs with deterministic two-stage reduction ----
         total_chunks = B * ((rows + 31) // 32)
-        nparts = max(1, min(512, total_chunks // 2))
+        nparts = max(1, min(256, total_chunks // 4))
 
         def wgrad(A, m, src_list, n, flags):
             q = L.Wgrad()
@@ -248,7 +284,8 @@ class FusedMLPFunction(torch.autograd.Function):
                 _fill_src(q.src[k], t, bstride, w, idx)
             partials = torch.empty((nparts, m, n), device=dev, dtype=torch.float32)
             q.partials, q.nparts = _ptr(partials), nparts
-            L.check(lib.nlam_wgrad(C.byref(q), _stream()), "nlam_wgrad")
+            key = ("wgrad", rows * B, m, n)
+            L.check(PROFILE.launch(key, lambda: lib.nlam_wgrad(C.byref(q), _stream())), "nlam_wgrad")
             outw = torch.empty((m, n), device=dev, dtype=torch.float32)
             L.check(
                 lib.nlam_reduce_partials(_ptr(partials), nparts, m * n, m * n, _ptr(outw), 0, _stream()),
@@ -264,7 +301,7 @@ class FusedMLPFunction(torch.autograd.Function):
         dW2 = wgrad(dz2, dout, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if ctx.needs_input_grad[3] else None
         vec = torch.empty((4, _VEC_W), device=dev, dtype=torch.float32)
         L.check(
-            lib.nlam_reduce_partials(_ptr(vecp), grid_waves, 4 * _VEC_W, 4 * _VEC_W, _ptr(vec), 0, _stream()),
+            lib.nlam_reduce_partials(_ptr(vecp), nblk, 4 * _VEC_W, 4 * _VEC_W, _ptr(vec), 0, _stream()),
             "nlam_reduce_partials",
         )
         db1, db2 = vec[0, :hid], vec[1, :dout]

@@ -1,0 +1,135 @@
+"""C-ABI / drop-in boundary checks that need no GPU: the library loads and exports
+every symbol include/nlam_hip.h declares, ctypes mirrors the C struct layout, the
+product never routes through the oracle or a CPU fallback, and the host classes
+keep the reference's constructor conventions (tests/test_gnn_layers.py:134-181)."""
+import ctypes as C
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+from conftest import ROOT
+from neural_lam_amd import _lib as L
+from neural_lam_amd import gnn_layers as hl
+from neural_lam_amd import graph as G
+from oracle import gnn_layers as og
+
+
+def _edge_index(ns=5, nr=4, e=10, seed=0):
+    torch.manual_seed(seed)
+    ei = torch.stack([torch.randint(0, ns, (e,)), torch.randint(0, nr, (e,))])
+    ei[1, -1] = nr - 1
+    return ei
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "nlam_hip.h").read_text()
+    declared = set(re.findall(r"^int32_t\s+(nlam_\w+)\s*\(", header, flags=re.M))
+    assert declared and declared == set(L.EXPORTS)
+    lib = L.load()  # raises if the .so is missing
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.nlam_abi_version() == 1
+    assert lib.nlam_max_width() >= 64
+    assert lib.nlam_num_blocks(1) == 1 and lib.nlam_num_blocks(10**6) == 256
+
+
+def test_ctypes_structs_match_c_layout(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "nlam_hip.h"\n'
+        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nlam_src_t), sizeof(nlam_mlp_fwd_t),'
+        " sizeof(nlam_mlp_bwd_t), sizeof(nlam_wgrad_t), offsetof(nlam_mlp_fwd_t, rstd),"
+        " offsetof(nlam_mlp_bwd_t, vec_partials), offsetof(nlam_wgrad_t, partials)); return 0;}\n"
+    )
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [
+        C.sizeof(L.Src), C.sizeof(L.MlpFwd), C.sizeof(L.MlpBwd), C.sizeof(L.Wgrad),
+        L.MlpFwd.rstd.offset, L.MlpBwd.vec_partials.offset, L.Wgrad.partials.offset,
+    ]
+
+
+def test_product_never_imports_oracle():
+    for py in (ROOT / "neural_lam_amd").rglob("*.py"):
+        text = py.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), py
+    # and importing the product does not pull the oracle in
+    code = "import sys; sys.path.insert(0, %r); import neural_lam_amd.models, neural_lam_amd.trainer; " \
+           "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)" % str(ROOT)
+    subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_cpu_tensors_fail_loudly():
+    net = hl.InteractionNet(_edge_index(), 8)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        net(torch.randn(5, 8), torch.randn(4, 8), torch.randn(10, 8))
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        hl.make_mlp([3, 8, 8])(torch.randn(7, 3))
+
+
+def test_constructor_conventions_match_reference():
+    ei = _edge_index()
+    assert issubclass(hl.PropagationNet, hl.InteractionNet)
+    pnet = hl.PropagationNet(ei, 8, aggr="sum")
+    assert pnet.aggr == "mean"  # forced mean aggregation (gnn_layers.py:217-227)
+    inet = hl.InteractionNet(ei, 8)
+    assert inet.aggr == "sum" and inet.update_edges
+    assert inet.edge_mlp[0].in_features == 24 and inet.aggr_mlp[0].in_features == 16
+    assert int(inet.num_rec) == int(ei[1].max()) + 1
+    assert torch.equal(inet.edge_index[0], ei[0] + inet.num_rec) and torch.equal(inet.edge_index[1], ei[1])
+    assert "edge_index" not in inet.state_dict()  # non-persistent buffer (gnn_layers.py:86)
+    with pytest.raises(ValueError):
+        hl.InteractionNet(ei, 8, aggr="max")
+    with pytest.raises(ValueError):
+        hl.get_gnn_class("Nope")
+    assert hl.get_gnn_class("PropagationNet") is hl.PropagationNet
+
+
+@pytest.mark.parametrize("kw", [{}, {"edge_chunk_sizes": [4, 6], "aggr_chunk_sizes": [1, 3]}, {"update_edges": False}])
+def test_state_dict_keys_and_shapes_equal_oracle(kw):
+    ei = _edge_index()
+    a, b = hl.InteractionNet(ei, 8, **kw).state_dict(), og.InteractionNet(ei, 8, **kw).state_dict()
+    assert list(a.keys()) == list(b.keys())
+    assert all(a[k].shape == b[k].shape for k in a)
+
+
+def test_sequential_child_names_follow_pyg():
+    seq = hl.make_gnn_seq(_edge_index(5, 5), 3, 1, 8)
+    keys = list(seq.state_dict().keys())
+    assert keys[0] == "module_0.edge_mlp.0.weight" and any(k.startswith("module_2.aggr_mlp.3") for k in keys)
+    with pytest.raises(ValueError):
+        hl.make_gnn_seq(_edge_index(5, 5), 0, 1, 8)
+
+
+def test_unsupported_depth_raises():
+    with pytest.raises(NotImplementedError):
+        hl.make_mlp([8, 8, 8, 8])
+
+
+def test_tile_schedule_covers_every_edge_and_receiver_once():
+    g = torch.Generator().manual_seed(3)
+    ns, nr, E = 40, 25, 900  # some receivers exceed 32 in-edges -> split tiles
+    ei = torch.stack([torch.randint(0, ns, (E,), generator=g), (torch.rand(E, generator=g) ** 3 * nr).long()])
+    ei[1, -1] = nr - 1
+    csr = G.build_edge_csr(ei, num_send=ns)
+    tiles, has_split = G.build_tile_schedule(csr.rowptr)
+    assert has_split == (csr.max_in_degree > 32)
+    cov_e = torch.zeros(E, dtype=torch.int32)
+    cov_r = torch.zeros(csr.num_rec, dtype=torch.int32)
+    for row0, nrows, seg0, nseg in tiles.tolist():
+        split = bool(nseg & G.TILE_SPLIT)
+        nseg &= ~G.TILE_SPLIT
+        assert 0 <= nrows <= 32 and 1 <= nseg <= 32
+        cov_e[row0 : row0 + nrows] += 1
+        if split:
+            assert nseg == 1 and int(csr.rowptr[seg0]) <= row0 and row0 + nrows <= int(csr.rowptr[seg0 + 1])
+            cov_r[seg0] = 1
+        else:
+            assert int(csr.rowptr[seg0]) == row0 and int(csr.rowptr[seg0 + nseg]) == row0 + nrows
+            cov_r[seg0 : seg0 + nseg] += 1
+    assert torch.all(cov_e == 1) and torch.all(cov_r == 1)
