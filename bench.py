@@ -83,8 +83,7 @@ def cpu_baseline(cfg, budget_s=25.0):
     """Oracle training step (fwd + wmse + bwd + AdamW) on the host cores."""
     from oracle import models as om
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     ds, _, _, forecaster, _, batch = build(cfg, torch.device("cpu"), oracle=True)
     pvs, mask = om.per_var_std_uniform(ds), om.interior_mask_bool(ds)
     opt = torch.optim.AdamW(forecaster.parameters(), lr=1e-3, betas=(0.9, 0.95))
@@ -95,6 +94,19 @@ def cpu_baseline(cfg, budget_s=25.0):
         loss.backward()
         opt.step()
 
+    # torch's CPU scatter/index_add paths degrade badly when oversubscribed on a
+    # many-core host: probe a few thread counts (one step each) and keep the best.
+    best, cores = None, 1
+    for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(n)
+        t0 = time.perf_counter()
+        one()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, n
+        if time.perf_counter() - t0 > budget_s / 3:
+            break
+    torch.set_num_threads(cores)
     one()  # warm-up
     times = []
     t_start = time.perf_counter()
@@ -110,7 +122,8 @@ def cpu_baseline(cfg, budget_s=25.0):
         "cores": cores,
         "kind": "port",
         "sample": f"{len(times)} full training steps of the same workload (median), oracle = PyG-free torch fp32 "
-                  f"restatement of the reference, torch.set_num_threads({cores})",
+                  f"restatement of the reference, torch.set_num_threads({cores}) = best of a {{8,16,32,64}}-thread probe "
+                  f"on a {ncpu}-core host",
     }
 
 

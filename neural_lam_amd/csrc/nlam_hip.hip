@@ -44,10 +44,12 @@ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m *
 // Order the wave's own LDS traffic (cross-lane exchange through LDS inside one
 // wave; other waves of the block are at unrelated points, so no s_barrier).
 __device__ __forceinline__ void wave_lds_sync() {
-    // LDS instructions of one wave are issued and serviced in order; the asm is a
-    // compiler barrier for memory operations and drains the wave's own LDS queue.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // LDS instructions of one wave are issued and serviced in order, so a wave-scope
+    // fence restricted to the LDS address space is all the ordering needed; unlike a
+    // "memory" clobber it lets the compiler keep global loads in flight across it.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 // ---------------------------------------------------------------------------
@@ -58,6 +60,21 @@ __device__ __forceinline__ void wave_lds_sync() {
 // ---------------------------------------------------------------------------
 __device__ void stage_packed(float* dst, int T, int t0, const float* W, long ldm, long ldk, int M, int MB, int Kw) {
     const int nt = (Kw + 7) >> 3;
+    if (ldk == 1 && (Kw & 3) == 0 && (ldm & 3) == 0 && ((uintptr_t)W & 15) == 0) {
+        // row-major weights: consecutive threads walk along a row (coalesced 16-B reads);
+        // float4 q of row m holds k = 4q .. 4q+3 = chunk (t = q >> 1, hi = q & 1), c = 0..3
+        const int q_per_row = nt * 2;
+        const int total = MB * 32 * q_per_row;
+        for (int s = threadIdx.x; s < total; s += blockDim.x) {
+            const int q = s % q_per_row;
+            const int m = s / q_per_row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < M && 4 * q < Kw) v = *reinterpret_cast<const f32x4*>(W + (long)m * ldm + 4 * q);
+            const int mb = m >> 5, i = m & 31, t = q >> 1, hi = q & 1;
+            *reinterpret_cast<f32x4*>(&dst[((((size_t)mb * T + (t0 + t)) * 2 + hi) * 32 + i) * 4]) = v;
+        }
+        return;
+    }
     const int total = MB * nt * 64;
     for (int s = threadIdx.x; s < total; s += blockDim.x) {
         const int i = s & 31;
@@ -173,17 +190,19 @@ __device__ __forceinline__ TileInfo get_tile(const nlam_tile_t* tiles, int ti, i
 __device__ __forceinline__ void tile_segment_reduce(const float* stg, int S, const TileInfo& tl, const int32_t* rowptr,
                                                     const float* inv_deg, float* out_b /* (nseg_total, w) */, int w,
                                                     int lane) {
+    // one coalesced fetch of the tile's <= 33 row pointers (and scales); broadcast per segment below
+    int my_ptr = 0;
+    float my_scale = 1.f;
+    if (!tl.split && lane <= tl.nseg) my_ptr = rowptr[tl.seg0 + lane] - tl.row0;
+    if (inv_deg != nullptr && lane < tl.nseg) my_scale = inv_deg[tl.seg0 + lane];
     for (int sg = 0; sg < tl.nseg; ++sg) {
         const int r = tl.seg0 + sg;
-        int lo, hi_;
+        int lo = __shfl(my_ptr, sg, 64), hi_ = __shfl(my_ptr, sg + 1, 64);
         if (tl.split) {
             lo = 0;
             hi_ = tl.nrows;
-        } else {
-            lo = rowptr[r] - tl.row0;
-            hi_ = rowptr[r + 1] - tl.row0;
         }
-        const float scale = inv_deg != nullptr ? inv_deg[r] : 1.f;
+        const float scale = __shfl(my_scale, sg, 64);
         for (int c = lane; c < w; c += 64) {
             float s = 0.f;
             for (int q = lo; q < hi_; ++q) s += stg[q * S + c];
@@ -271,20 +290,39 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[hb][r] = 0.f;
 
+        // All chunks of a source (<= 8: widths <= 64) are requested before the first
+        // MFMA that needs them, and source s+1 is in flight while source s is consumed.
         const float* srow[NLAM_MAX_SRC] = {nullptr, nullptr, nullptr};
-        int tg = 0;
-        for (int s = 0; s < p.nsrc; ++s) {
-            const nlam_src_t S = p.src[s];
-            long ridx = prow;
-            if (valid && S.idx != nullptr) ridx = S.idx[prow];
-            const float* row = S.ptr + (long)b * S.bstride + (valid ? ridx : 0) * (long)S.width;
-            srow[s] = row;
-            const int nt = (S.width + 7) >> 3;
-            for (int t = 0; t < nt; ++t) {
-                const f32x4 x = load_chunk(row, S.width, t, hi, valid);
-                mma_chunk<HB>(acc1, W1p, T1, tg + t, x, lane);
+        int swidth[NLAM_MAX_SRC] = {0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+            if (s < p.nsrc) {
+                const nlam_src_t S = p.src[s];
+                long ridx = prow;
+                if (valid && S.idx != nullptr) ridx = S.idx[prow];
+                srow[s] = S.ptr + (long)b * S.bstride + (valid ? ridx : 0) * (long)S.width;
+                swidth[s] = S.width;
             }
-            tg += nt;
+        }
+        f32x4 xa[8], xb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) xa[t] = load_chunk(srow[0], swidth[0], t, hi, valid);
+        int tg = 0;
+#pragma unroll
+        for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+            if (s < p.nsrc) {
+                f32x4(&cur)[8] = (s & 1) ? xb : xa;
+                f32x4(&nxt)[8] = (s & 1) ? xa : xb;
+                if (s + 1 < p.nsrc) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) nxt[t] = load_chunk(srow[s + 1], swidth[s + 1], t, hi, valid);
+                }
+                const int nt = (swidth[s] + 7) >> 3;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (t < nt) mma_chunk<HB>(acc1, W1p, T1, tg + t, cur[t], lane);
+                tg += nt;
+            }
         }
 
         // ---- bias, save pre-activation, SiLU -> B operand of GEMM2 ----
@@ -709,16 +747,147 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_kernel(const nlam_mlp_b
 // ---------------------------------------------------------------------------
 constexpr int kWgradThreads = 256;
 constexpr int kWgradRows = 32;
+constexpr int kWgTile = kWgradRows * 64;  // floats in one [32 rows][64 cols] LDS tile
 
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// Fast path: m <= 64, every source width <= 64, all multiples of 4.
+// LDS holds, per buffer, one [32][64] tile for A and one per source, filled by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers, 1 KiB = 4 rows per
+// wave-instruction, per-lane gathered source address, lane-linear destination).
+// Two buffers: chunk k+1 streams in while chunk k feeds the MFMAs; one barrier
+// per chunk.  MFMA operands are k-major b32 reads of the row-major tiles
+// (consecutive lanes = consecutive columns: conflict-free, the two half-waves read
+// adjacent rows).
+template <int NBW>
+__global__ __launch_bounds__(kWgradThreads) void wgrad_dma_kernel(const nlam_wgrad_t p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ntile = 1 + p.nsrc;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, hi = lane >> 5;
+    const int MB = (p.m + 31) >> 5;
+
+    // this wave's output blocks: q -> (mb, source tile, 32-column block inside the source)
+    int blk_mb[NBW], blk_tile[NBW], blk_nb[NBW], blk_col0[NBW], blk_w[NBW];
+    {
+        int nb_total = 0;
+        for (int s = 0; s < p.nsrc; ++s) nb_total += (p.src[s].width + 31) >> 5;
+#pragma unroll
+        for (int q = 0; q < NBW; ++q) {
+            const int blk = wave + 4 * q;
+            blk_mb[q] = -1;
+            blk_tile[q] = 1;
+            blk_nb[q] = 0;
+            blk_col0[q] = 0;
+            blk_w[q] = 0;
+            if (blk < MB * nb_total) {
+                blk_mb[q] = blk / nb_total;
+                int nbg = blk % nb_total, off = 0;
+                for (int s = 0; s < p.nsrc; ++s) {
+                    const int nbs = (p.src[s].width + 31) >> 5;
+                    if (nbg < nbs) {
+                        blk_tile[q] = 1 + s;
+                        blk_nb[q] = nbg;
+                        blk_col0[q] = off + nbg * 32;
+                        blk_w[q] = off + p.src[s].width;
+                        break;
+                    }
+                    nbg -= nbs;
+                    off += p.src[s].width;
+                }
+            }
+        }
+    }
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int q = 0; q < NBW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int chunks_per_batch = (p.rows + kWgradRows - 1) / kWgradRows;
+    const long total_chunks = (long)chunks_per_batch * p.batch;
+    const int lrow = lane >> 4, lcol = (lane & 15) << 2;  // lane -> (row within the 4-row group, first column)
+
+    auto issue = [&](long ch, int buf) {
+        const int b = (int)(ch / chunks_per_batch);
+        const int r0 = (int)(ch % chunks_per_batch) * kWgradRows;
+        const int nr = min(kWgradRows, p.rows - r0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int r = wave * 8 + g * 4 + lrow;   // tile row this lane fetches
+            const bool rv = r < nr;
+            const long prow = r0 + (rv ? r : 0);
+            // tile 0: A
+            {
+                const float* src = (rv && lcol < p.m) ? p.A + ((size_t)b * p.rows + prow) * p.m + lcol : g_zero16;
+                float* dst = smem + ((size_t)(buf * ntile) * kWgTile) + (wave * 8 + g * 4) * 64;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+            for (int s = 0; s < p.nsrc; ++s) {
+                const nlam_src_t S = p.src[s];
+                const float* src = g_zero16;
+                if (rv && lcol < S.width) {
+                    const long ridx = S.idx != nullptr ? S.idx[prow] : prow;
+                    src = S.ptr + (long)b * S.bstride + ridx * S.width + lcol;
+                }
+                float* dst = smem + ((size_t)(buf * ntile + 1 + s) * kWgTile) + (wave * 8 + g * 4) * 64;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+
+    long ch = blockIdx.x;
+    int buf = 0;
+    if (ch < total_chunks) issue(ch, 0);
+    for (; ch < total_chunks; ch += gridDim.x) {
+        __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)); everyone is done reading buf ^ 1
+        if (ch + gridDim.x < total_chunks) issue(ch + gridDim.x, buf ^ 1);
+        const float* At = smem + (size_t)(buf * ntile) * kWgTile;
+#pragma unroll
+        for (int q = 0; q < NBW; ++q) {
+            if (blk_mb[q] >= 0) {
+                const float* Bt = smem + (size_t)(buf * ntile + blk_tile[q]) * kWgTile;
+                const int ac = blk_mb[q] * 32 + i, bc = blk_nb[q] * 32 + i;
+#pragma unroll
+                for (int ks = 0; ks < kWgradRows / 2; ++ks) {
+                    const float a = At[(2 * ks + hi) * 64 + ac];
+                    float bv = Bt[(2 * ks + hi) * 64 + bc];
+                    if (p.flags & NLAM_F_SILU_B) bv = silu_f(bv);
+                    acc[q] = MFMA32(a, bv, acc[q]);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    // ---- write this workgroup's partial (m x n) ----
+    float* P = p.partials + (size_t)blockIdx.x * p.m * p.n;
+#pragma unroll
+    for (int q = 0; q < NBW; ++q) {
+        if (blk_mb[q] >= 0) {
+            const int n = blk_col0[q] + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = blk_mb[q] * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < p.m && n < blk_w[q]) P[(size_t)m * p.n + n] = acc[q][r];
+            }
+        }
+    }
+}
+
+// Generic widths: element-wise staging (small / odd shapes only).
 template <int NBW>
 __global__ __launch_bounds__(kWgradThreads) void wgrad_kernel(const nlam_wgrad_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int MP = round_up(p.m, 32), NP = round_up(p.n, 32);
-    const int SA = MP + 4, SB = NP + 4;  // +4: row r and r+1 land 4 banks apart
+    const int SA = MP + 4, SB = NP + 4;
     float* As = smem;                    // kWgradRows x SA
     float* Bs = As + kWgradRows * SA;    // kWgradRows x SB
-    const int MB = MP / 32, NB = NP / 32;
-    const int nblocks = MB * NB;
+    const int NB = NP / 32;
+    const int nblocks = (MP / 32) * NB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, hi = lane >> 5;
 
@@ -728,9 +897,7 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_kernel(const nlam_wgrad_t
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
-    // zero the padding columns once (never overwritten)
-    for (int s = threadIdx.x; s < kWgradRows * SA; s += blockDim.x) As[s] = 0.f;
-    for (int s = threadIdx.x; s < kWgradRows * SB; s += blockDim.x) Bs[s] = 0.f;
+    for (int s = threadIdx.x; s < kWgradRows * (SA + SB); s += blockDim.x) smem[s] = 0.f;  // padding stays zero
     __syncthreads();
 
     const int chunks_per_batch = (p.rows + kWgradRows - 1) / kWgradRows;
@@ -739,12 +906,10 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_kernel(const nlam_wgrad_t
         const int b = (int)(ch / chunks_per_batch);
         const int r0 = (int)(ch % chunks_per_batch) * kWgradRows;
         const int nr = min(kWgradRows, p.rows - r0);
-        // ---- stage A rows (zero-fill rows >= nr) ----
         for (int s = threadIdx.x; s < kWgradRows * p.m; s += blockDim.x) {
             const int r = s / p.m, c = s % p.m;
             As[r * SA + c] = (r < nr) ? p.A[((size_t)b * p.rows + r0 + r) * p.m + c] : 0.f;
         }
-        // ---- stage B rows: gathered concat ----
         int off = 0;
         for (int q = 0; q < p.nsrc; ++q) {
             const nlam_src_t S = p.src[q];
@@ -763,7 +928,6 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_kernel(const nlam_wgrad_t
             off += w;
         }
         __syncthreads();
-        // ---- MFMA: K = the 32 staged rows ----
 #pragma unroll
         for (int q = 0; q < NBW; ++q) {
             const int blk = wave + 4 * q;
@@ -779,7 +943,6 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_kernel(const nlam_wgrad_t
         }
         __syncthreads();
     }
-    // ---- write this workgroup's partial (m x n) ----
     float* P = p.partials + (size_t)blockIdx.x * p.m * p.n;
 #pragma unroll
     for (int q = 0; q < NBW; ++q) {
@@ -991,6 +1154,28 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     for (int s = 0; s < p->nsrc; ++s) n += p->src[s].width;
     if (n != p->n || p->m < 1 || p->nparts < 1) return NLAM_EINVAL;
     hipStream_t stream = (hipStream_t)hip_stream;
+    bool dma = (p->m % 4 == 0) && p->m <= 64;
+    int nb_total = 0;
+    for (int s = 0; s < p->nsrc; ++s) {
+        dma = dma && (p->src[s].width % 4 == 0) && p->src[s].width <= 64;
+        nb_total += (p->src[s].width + 31) / 32;
+    }
+    if (dma) {
+        const int nblocks = ((p->m + 31) / 32) * nb_total;
+        const int nbw = (nblocks + 3) / 4;
+        const size_t lds = (size_t)2 * (1 + p->nsrc) * kWgTile * sizeof(float);
+#define NLAM_LAUNCH_WGD(N_)                                                                               \
+    do {                                                                                                  \
+        int rc = set_lds(wgrad_dma_kernel<N_>, lds);                                                      \
+        if (rc != 0) return rc;                                                                           \
+        hipLaunchKernelGGL((wgrad_dma_kernel<N_>), dim3(p->nparts), dim3(kWgradThreads), lds, stream, *p); \
+    } while (0)
+        if (nbw <= 1) NLAM_LAUNCH_WGD(1);
+        else if (nbw <= 2) NLAM_LAUNCH_WGD(2);
+        else if (nbw <= 3) NLAM_LAUNCH_WGD(3);
+        else return NLAM_EUNSUP;
+        return (int32_t)hipGetLastError();
+    }
     const int MP = (p->m + 31) / 32 * 32, NP = (p->n + 31) / 32 * 32;
     const int nblocks = (MP / 32) * (NP / 32);
     const size_t lds = (size_t)kWgradRows * (MP + 4 + NP + 4) * sizeof(float);

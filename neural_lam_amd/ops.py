@@ -275,7 +275,7 @@ class FusedMLPFunction(torch.autograd.Function):
 
         # ---- weight gradients: two TN GEMMs with deterministic two-stage reduction ----
         total_chunks = B * ((rows + 31) // 32)
-        nparts = max(1, min(256, total_chunks // 4))
+        nparts = max(1, min(512, total_chunks // 4))
 
         def wgrad(A, m, src_list, n, flags):
             q = L.Wgrad()
