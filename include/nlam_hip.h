@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define NLAM_ABI_VERSION 1
+#define NLAM_ABI_VERSION 2
 #define NLAM_MAX_SRC 3
 
 #define NLAM_EINVAL (-1)   /* inconsistent sizes / null pointers        */
@@ -102,6 +102,9 @@ typedef struct {
     float* z1;             /* (batch, rows, hid)  pre-activation  */
     float* xhat;           /* (batch, rows, dout) normalised, pre-affine (LN only) */
     float* rstd;           /* (batch, rows) */
+    /* ---- scratch for the wide kernels (hid or dout or a source wider than 64) ---- */
+    float* wpack;          /* >= nlam_mlp_fwd_wpack_floats(p) floats, or NULL when that is 0 */
+    int64_t wpack_floats;  /* capacity of wpack */
 } nlam_mlp_fwd_t;
 
 typedef struct {
@@ -137,9 +140,11 @@ typedef struct {
                                       | 2 tile-row order (rows, width) for a later segment sum
                                       | 3 segment-summed over the tile's receivers -> (nseg_total, width) */
     int32_t _pad;
-    float* vec_partials;   /* (nblocks, 4, 64): per-workgroup db1, db2, dgamma, dbeta partial sums */
-    int32_t vec_partials_rows; /* capacity in rows; must be >= nlam_num_blocks(ntiles * batch) */
-    int32_t _pad2;
+    float* vec_partials;   /* (nblocks, 4, vec_stride): per-workgroup db1, db2, dgamma, dbeta partial sums */
+    int32_t vec_partials_rows; /* capacity in rows; must be >= nlam_mlp_bwd_blocks(p) */
+    int32_t vec_stride;    /* row stride of vec_partials: multiple of 64, >= max(hid, dout) */
+    float* wpack;          /* >= nlam_mlp_bwd_wpack_floats(p) floats, or NULL when that is 0 */
+    int64_t wpack_floats;
 } nlam_mlp_bwd_t;
 
 typedef struct {
@@ -163,6 +168,14 @@ int32_t nlam_abi_version(void);
 int32_t nlam_num_blocks(int64_t total_tiles);
 /* widest hidden/output width the fused kernels of this build instantiate */
 int32_t nlam_max_width(void);
+/* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this
+ * call; 0 when the call runs on the narrow (weights-in-LDS) kernels. */
+int64_t nlam_mlp_fwd_wpack_floats(const nlam_mlp_fwd_t* p);
+int64_t nlam_mlp_bwd_wpack_floats(const nlam_mlp_bwd_t* p);
+/* workgroups nlam_mlp_bwd launches for this call (rows of vec_partials it writes) */
+int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p);
+/* number of row slices (p->nparts) that fills the chip for this weight-gradient shape */
+int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p);
 
 int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream);
 int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream);

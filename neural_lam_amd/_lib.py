@@ -22,6 +22,10 @@ EXPORTS = [
     "nlam_grid_waves",
     "nlam_num_blocks",
     "nlam_max_width",
+    "nlam_mlp_fwd_wpack_floats",
+    "nlam_mlp_bwd_wpack_floats",
+    "nlam_mlp_bwd_blocks",
+    "nlam_wgrad_nparts",
     "nlam_mlp_fwd",
     "nlam_mlp_bwd",
     "nlam_wgrad",
@@ -70,6 +74,8 @@ class MlpFwd(C.Structure):
         ("z1", C.c_void_p),
         ("xhat", C.c_void_p),
         ("rstd", C.c_void_p),
+        ("wpack", C.c_void_p),
+        ("wpack_floats", C.c_int64),
     ]
 
 
@@ -106,7 +112,9 @@ class MlpBwd(C.Structure):
         ("_pad", C.c_int32),
         ("vec_partials", C.c_void_p),
         ("vec_partials_rows", C.c_int32),
-        ("_pad2", C.c_int32),
+        ("vec_stride", C.c_int32),
+        ("wpack", C.c_void_p),
+        ("wpack_floats", C.c_int64),
     ]
 
 
@@ -156,6 +164,14 @@ def load():
     lib.nlam_max_width.restype = i32
     lib.nlam_num_blocks.argtypes = [i64]
     lib.nlam_num_blocks.restype = i32
+    lib.nlam_mlp_fwd_wpack_floats.argtypes = [C.POINTER(MlpFwd)]
+    lib.nlam_mlp_fwd_wpack_floats.restype = i64
+    lib.nlam_mlp_bwd_wpack_floats.argtypes = [C.POINTER(MlpBwd)]
+    lib.nlam_mlp_bwd_wpack_floats.restype = i64
+    lib.nlam_mlp_bwd_blocks.argtypes = [C.POINTER(MlpBwd)]
+    lib.nlam_mlp_bwd_blocks.restype = i32
+    lib.nlam_wgrad_nparts.argtypes = [C.POINTER(Wgrad)]
+    lib.nlam_wgrad_nparts.restype = i32
     lib.nlam_mlp_fwd.argtypes = [C.POINTER(MlpFwd), vp]
     lib.nlam_mlp_fwd.restype = i32
     lib.nlam_mlp_bwd.argtypes = [C.POINTER(MlpBwd), vp]
@@ -168,7 +184,7 @@ def load():
     lib.nlam_reduce_partials.restype = i32
     lib.nlam_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
     lib.nlam_adamw_step.restype = i32
-    if lib.nlam_abi_version() != 1:
+    if lib.nlam_abi_version() != 2:
         raise RuntimeError("libnlam_hip.so ABI version mismatch")
     _lib = lib
     return lib

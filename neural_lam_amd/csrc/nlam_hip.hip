@@ -37,9 +37,9 @@ constexpr int kWavesPerBlock = 8;                  // 512 threads: two waves per
 constexpr int kBlockThreads = kWavesPerBlock * 64;
 constexpr int kNumCUs = 256;
 constexpr int kMaxGridBlocks = kNumCUs;            // one persistent workgroup per CU
-constexpr int kMaxWidth = 64;                      // widest hidden/output width instantiated
+constexpr int kMaxWidth = 64;                      // widest hidden/output width of the narrow (weights-in-LDS) kernels
 
-__device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Order the wave's own LDS traffic (cross-lane exchange through LDS inside one
 // wave; other waves of the block are at unrelated points, so no s_barrier).
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_kernel(const nlam_mlp_b
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < kWavesPerBlock; ++w) s += red[(w * 4 + wave) * 64 + lane];
-            p.vec_partials[((size_t)blockIdx.x * 4 + wave) * kMaxWidth + lane] = s;
+            p.vec_partials[((size_t)blockIdx.x * 4 + wave) * p.vec_stride + lane] = s;
         }
     }
 }
@@ -1035,6 +1035,8 @@ __global__ void adamw_kernel(float* param, const float* grad, float* m, float* v
     }
 }
 
+#include "nlam_wide.inc"
+
 // ---------------------------------------------------------------------------
 // host side helpers
 // ---------------------------------------------------------------------------
@@ -1075,6 +1077,101 @@ int grid_blocks(long total_tiles) {
     return (int)(need < kMaxGridBlocks ? need : kMaxGridBlocks);
 }
 
+// ---- wide-path dispatch helpers ----
+struct WideCfg {
+    int nwv, fb;   // waves per workgroup, 32-feature blocks per wave; 0 = not covered
+};
+
+WideCfg wide_cfg(int maxw) {
+    if (maxw <= 128) return {4, 1};
+    if (maxw <= 256) return {8, 1};
+    if (maxw <= kMaxWide) return {8, 2};
+    return {0, 0};
+}
+
+bool fwd_is_wide(const nlam_mlp_fwd_t* p) {
+    if (p->hid > kMaxWidth || p->dout > kMaxWidth) return true;
+    for (int s = 0; s < p->nsrc; ++s)
+        if (p->src[s].width > kMaxWidth) return true;
+    return false;
+}
+
+bool bwd_is_wide(const nlam_mlp_bwd_t* p) {
+    if (p->hid > kMaxWidth || p->dout > kMaxWidth) return true;
+    for (int s = 0; s < p->nsrc; ++s)
+        if (p->src[s].width > kMaxWidth) return true;
+    return false;
+}
+
+int bwd_wide_maxw(const nlam_mlp_bwd_t* p) {
+    int w = p->hid > p->dout ? p->hid : p->dout;
+    for (int s = 0; s < p->nsrc; ++s)
+        if (p->dmode[s] != 0 && p->src[s].width > w) w = p->src[s].width;
+    return w;
+}
+
+int fwd_nq1(const nlam_mlp_fwd_t* p) {
+    int q = 0;
+    for (int s = 0; s < p->nsrc; ++s) q += (p->src[s].width + 31) / 32;
+    return q;
+}
+
+size_t fwd_wide_lds(const nlam_mlp_fwd_t* p, int nwv) {
+    const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
+    const int WS = (HBT > OBT ? HBT : OBT) * 32 + 4;
+    return ((size_t)2 * 32 * kXS + (size_t)32 * WS + (size_t)2 * nwv * 32 + NLAM_MAX_SRC * 32) * sizeof(float);
+}
+
+size_t bwd_wide_lds(const nlam_mlp_bwd_t* p, int nwv) {
+    int maxb = ((p->hid > p->dout ? p->hid : p->dout) + 31) / 32;
+    for (int s = 0; s < p->nsrc; ++s)
+        if (p->dmode[s] == 3 && (p->src[s].width + 31) / 32 > maxb) maxb = (p->src[s].width + 31) / 32;
+    const int WS = maxb * 32 + 4;
+    return ((size_t)2 * 32 * WS + (size_t)2 * nwv * 32) * sizeof(float);
+}
+
+int wide_grid(long total_tiles, size_t lds, int nwv) {
+    int occ = (int)(kMaxLds / lds);
+    const int wave_cap = 16 / nwv;          // at most 4 waves per SIMD
+    if (occ > wave_cap) occ = wave_cap;
+    if (occ < 1) occ = 1;
+    long g = (long)kNumCUs * occ;
+    if (total_tiles < g) g = total_tiles;
+    return (int)(g < 1 ? 1 : g);
+}
+
+void launch_pack(const pack_jobs_t& jobs, hipStream_t stream) {
+    long most = 0;
+    for (int k = 0; k < jobs.njobs; ++k) {
+        const long ng = round_up((jobs.job[k].Kw + 7) / 8, 4);
+        const long tot = (long)jobs.job[k].MB * ng * 64;
+        if (tot > most) most = tot;
+    }
+    long blocks = (most + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_a_kernel, dim3((int)blocks, jobs.njobs), dim3(256), 0, stream, jobs);
+}
+
+bool wgrad_is_narrow_dma(const nlam_wgrad_t* p) {
+    bool dma = (p->m % 4 == 0) && p->m <= 64;
+    for (int s = 0; s < p->nsrc; ++s) dma = dma && (p->src[s].width % 4 == 0) && p->src[s].width <= 64;
+    return dma;
+}
+
+bool wgrad_is_wide(const nlam_wgrad_t* p) {
+    if (wgrad_is_narrow_dma(p)) return false;
+    bool ok = (p->m % 4 == 0);
+    for (int s = 0; s < p->nsrc; ++s) ok = ok && (p->src[s].width % 4 == 0);
+    return ok;
+}
+
+int wgrad_windows(const nlam_wgrad_t* p) {
+    int nw = 0;
+    for (int s = 0; s < p->nsrc; ++s) nw += (p->src[s].width + kWWin - 1) / kWWin;
+    return nw * ((p->m + kWWin - 1) / kWWin);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1085,7 +1182,44 @@ extern "C" {
 int32_t nlam_abi_version(void) { return NLAM_ABI_VERSION; }
 int32_t nlam_grid_waves(void) { return kMaxGridBlocks * kWavesPerBlock; }
 int32_t nlam_num_blocks(int64_t total_tiles) { return grid_blocks((long)total_tiles); }
-int32_t nlam_max_width(void) { return kMaxWidth; }
+int32_t nlam_max_width(void) { return kMaxWide; }
+
+int64_t nlam_mlp_fwd_wpack_floats(const nlam_mlp_fwd_t* p) {
+    if (p == nullptr || !fwd_is_wide(p)) return 0;
+    const int64_t HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
+    return (HBT * fwd_nq1(p) + OBT * HBT) * 1024;
+}
+
+int64_t nlam_mlp_bwd_wpack_floats(const nlam_mlp_bwd_t* p) {
+    if (p == nullptr || !bwd_is_wide(p)) return 0;
+    const int64_t HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
+    int64_t f = HBT * OBT * 1024;
+    for (int s = 0; s < p->nsrc; ++s)
+        if (p->dmode[s] != 0) f += (int64_t)((p->src[s].width + 31) / 32) * HBT * 1024;
+    return f;
+}
+
+int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p) {
+    if (p == nullptr) return 0;
+    const long total = (long)p->ntiles * p->batch;
+    if (!bwd_is_wide(p)) return grid_blocks(total);
+    const WideCfg cfg = wide_cfg(bwd_wide_maxw(p));
+    if (cfg.nwv == 0) return 0;
+    return wide_grid(total, bwd_wide_lds(p, cfg.nwv), cfg.nwv);
+}
+
+int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
+    if (p == nullptr) return 0;
+    const long total_chunks = (long)p->batch * ((p->rows + kWgradRows - 1) / kWgradRows);
+    long np = total_chunks / 4;
+    long cap = 512;
+    if (wgrad_is_wide(p)) {
+        cap = 1024 / wgrad_windows(p);
+        if (cap < 4) cap = 4;
+    }
+    if (np > cap) np = cap;
+    return (int32_t)(np < 1 ? 1 : np);
+}
 
 #define NLAM_LAUNCH_FWD(HB_, OB_)                                                                      \
     do {                                                                                               \
@@ -1098,13 +1232,45 @@ int32_t nlam_max_width(void) { return kMaxWidth; }
 int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
     if (p == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
     if (p->batch < 1 || p->rows < 0 || p->hid < 1 || p->dout < 1) return NLAM_EINVAL;
-    if (p->hid > kMaxWidth || p->dout > kMaxWidth) return NLAM_EUNSUP;
     if (p->aggr != nullptr && (p->rowptr == nullptr || p->tiles == nullptr)) return NLAM_EINVAL;
     if ((p->flags & NLAM_F_MEAN) && p->inv_deg == nullptr) return NLAM_EINVAL;
     if ((p->flags & NLAM_F_ADD_SRC0) && p->src[0].width != p->dout) return NLAM_EINVAL;
     if ((p->flags & NLAM_F_ADD_SRC1) && (p->nsrc < 2 || p->src[1].width != p->dout)) return NLAM_EINVAL;
     if (p->rows == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
+    if (fwd_is_wide(p)) {
+        const WideCfg cfg = wide_cfg(p->hid > p->dout ? p->hid : p->dout);
+        if (cfg.nwv == 0) return NLAM_EUNSUP;
+        const int64_t need = nlam_mlp_fwd_wpack_floats(p);
+        if (p->wpack == nullptr || p->wpack_floats < need) return NLAM_EINVAL;
+        const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32, NQ1 = fwd_nq1(p);
+        int kin = 0;
+        for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
+        pack_jobs_t jobs;
+        jobs.njobs = 0;
+        int off = 0, q0 = 0;
+        for (int s = 0; s < p->nsrc; ++s) {
+            const int w = p->src[s].width;
+            jobs.job[jobs.njobs++] = {p->W1 + off, (long)kin, 1L, p->hid, HBT, w, NQ1 * 4, q0 * 4, p->wpack};
+            off += w;
+            q0 += (w + 31) / 32;
+        }
+        jobs.job[jobs.njobs++] = {p->W2, (long)p->hid, 1L, p->dout, OBT, p->hid, HBT * 4, 0,
+                                  p->wpack + (size_t)HBT * NQ1 * 1024};
+        launch_pack(jobs, stream);
+        const size_t lds = fwd_wide_lds(p, cfg.nwv);
+        const int wblocks = wide_grid((long)p->ntiles * p->batch, lds, cfg.nwv);
+#define NLAM_LAUNCH_FWD_WIDE(NWV_, FB_)                                                                       \
+    do {                                                                                                      \
+        int rc = set_lds(mlp_fwd_wide_kernel<NWV_, FB_>, lds);                                                \
+        if (rc != 0) return rc;                                                                               \
+        hipLaunchKernelGGL((mlp_fwd_wide_kernel<NWV_, FB_>), dim3(wblocks), dim3(NWV_ * 64), lds, stream, *p); \
+    } while (0)
+        if (cfg.nwv == 4) NLAM_LAUNCH_FWD_WIDE(4, 1);
+        else if (cfg.fb == 1) NLAM_LAUNCH_FWD_WIDE(8, 1);
+        else NLAM_LAUNCH_FWD_WIDE(8, 2);
+        return (int32_t)hipGetLastError();
+    }
     const int blocks = grid_blocks((long)p->ntiles * p->batch);
     const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
     if (HB == 1 && OB == 1) NLAM_LAUNCH_FWD(1, 1);
@@ -1125,19 +1291,59 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
 
 int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
     if (p == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
-    if (p->hid > kMaxWidth || p->dout > kMaxWidth) return NLAM_EUNSUP;
     if (p->z1 == nullptr) return NLAM_EINVAL;
     if (p->ln_w != nullptr && (p->xhat == nullptr || p->rstd == nullptr)) return NLAM_EINVAL;
     if (p->g_aggr != nullptr && p->seg_of_row == nullptr) return NLAM_EINVAL;
     if ((p->flags & NLAM_F_MEAN) && p->g_aggr != nullptr && p->inv_deg == nullptr) return NLAM_EINVAL;
     for (int s = 0; s < p->nsrc; ++s) {
-        if (p->src[s].width > kMaxWidth && p->dmode[s] != 0) return NLAM_EUNSUP;
         if (p->dmode[s] != 0 && p->dsrc[s] == nullptr) return NLAM_EINVAL;
         if (p->dmode[s] == 3 && (p->rowptr == nullptr || p->tiles == nullptr)) return NLAM_EINVAL;
     }
-    if (p->vec_partials != nullptr && p->vec_partials_rows < nlam_num_blocks((int64_t)p->ntiles * p->batch)) return NLAM_EINVAL;
+    if (p->vec_partials != nullptr) {
+        const int wmax = p->hid > p->dout ? p->hid : p->dout;
+        if (p->vec_partials_rows < nlam_mlp_bwd_blocks(p) || p->vec_stride < wmax || p->vec_stride < 64 || p->vec_stride % 64 != 0)
+            return NLAM_EINVAL;
+    }
     if (p->rows == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
+    if (bwd_is_wide(p)) {
+        const WideCfg cfg = wide_cfg(bwd_wide_maxw(p));
+        if (cfg.nwv == 0) return NLAM_EUNSUP;
+        const int64_t need = nlam_mlp_bwd_wpack_floats(p);
+        if (p->wpack == nullptr || p->wpack_floats < need) return NLAM_EINVAL;
+        const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
+        int kin = 0;
+        for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
+        pack_jobs_t jobs;
+        jobs.njobs = 0;
+        // A[m = hidden][k = out] = W2[k][m]
+        jobs.job[jobs.njobs++] = {p->W2, 1L, (long)p->hid, p->hid, HBT, p->dout, OBT * 4, 0, p->wpack};
+        size_t woff = (size_t)HBT * OBT * 1024;
+        int off = 0;
+        for (int s = 0; s < p->nsrc; ++s) {
+            const int w = p->src[s].width;
+            if (p->dmode[s] != 0) {
+                const int SB = (w + 31) / 32;
+                // A[m = source column][k = hidden] = W1[k][off + m]
+                jobs.job[jobs.njobs++] = {p->W1 + off, 1L, (long)kin, w, SB, p->hid, HBT * 4, 0, p->wpack + woff};
+                woff += (size_t)SB * HBT * 1024;
+            }
+            off += w;
+        }
+        launch_pack(jobs, stream);
+        const size_t lds = bwd_wide_lds(p, cfg.nwv);
+        const int wblocks = nlam_mlp_bwd_blocks(p);
+#define NLAM_LAUNCH_BWD_WIDE(NWV_, FB_)                                                                       \
+    do {                                                                                                      \
+        int rc = set_lds(mlp_bwd_wide_kernel<NWV_, FB_>, lds);                                                \
+        if (rc != 0) return rc;                                                                               \
+        hipLaunchKernelGGL((mlp_bwd_wide_kernel<NWV_, FB_>), dim3(wblocks), dim3(NWV_ * 64), lds, stream, *p); \
+    } while (0)
+        if (cfg.nwv == 4) NLAM_LAUNCH_BWD_WIDE(4, 1);
+        else if (cfg.fb == 1) NLAM_LAUNCH_BWD_WIDE(8, 1);
+        else NLAM_LAUNCH_BWD_WIDE(8, 2);
+        return (int32_t)hipGetLastError();
+    }
     const int blocks = grid_blocks((long)p->ntiles * p->batch);
     const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
     if (HB == 1 && OB == 1) NLAM_LAUNCH_BWD(1, 1);
@@ -1154,11 +1360,15 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     for (int s = 0; s < p->nsrc; ++s) n += p->src[s].width;
     if (n != p->n || p->m < 1 || p->nparts < 1) return NLAM_EINVAL;
     hipStream_t stream = (hipStream_t)hip_stream;
-    bool dma = (p->m % 4 == 0) && p->m <= 64;
+    const bool dma = wgrad_is_narrow_dma(p);
     int nb_total = 0;
-    for (int s = 0; s < p->nsrc; ++s) {
-        dma = dma && (p->src[s].width % 4 == 0) && p->src[s].width <= 64;
-        nb_total += (p->src[s].width + 31) / 32;
+    for (int s = 0; s < p->nsrc; ++s) nb_total += (p->src[s].width + 31) / 32;
+    if (wgrad_is_wide(p)) {
+        const size_t lds = (size_t)4 * kWWTile * sizeof(float);
+        int rc = set_lds(wgrad_wide_kernel, lds);
+        if (rc != 0) return rc;
+        hipLaunchKernelGGL(wgrad_wide_kernel, dim3(p->nparts, wgrad_windows(p)), dim3(kWgradThreads), lds, stream, *p);
+        return (int32_t)hipGetLastError();
     }
     if (dma) {
         const int nblocks = ((p->m + 31) / 32) * nb_total;
@@ -1189,6 +1399,7 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     if (nbw <= 1) NLAM_LAUNCH_WG(1);
     else if (nbw <= 2) NLAM_LAUNCH_WG(2);
     else if (nbw <= 3) NLAM_LAUNCH_WG(3);
+    else if (nbw <= 4) NLAM_LAUNCH_WG(4);
     else return NLAM_EUNSUP;
     return (int32_t)hipGetLastError();
 }

@@ -13,7 +13,11 @@ import torch
 
 from . import _lib as L
 
-_VEC_W = 64  # kMaxWidth of the kernels: row width of the vector-partials buffer
+
+def _vec_stride(hid: int, dout: int) -> int:
+    """Row stride of the (db1, db2, dgamma, dbeta) partial-sum buffer: a multiple of 64 >= max(hid, dout)."""
+    return max(64, (max(hid, dout) + 63) // 64 * 64)
+
 
 
 def _stream():
@@ -188,6 +192,10 @@ class FusedMLPFunction(torch.autograd.Function):
                 xhat = torch.empty((B, rows, dout), device=dev, dtype=torch.float32)
                 rstd = torch.empty((B, rows), device=dev, dtype=torch.float32)
                 p.xhat, p.rstd = _ptr(xhat), _ptr(rstd)
+        nwp = lib.nlam_mlp_fwd_wpack_floats(C.byref(p))
+        if nwp > 0:  # wide kernels: scratch for the weights in MFMA A-operand order
+            wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+            p.wpack, p.wpack_floats = _ptr(wpack), nwp
         key = ("mlp_fwd", rows * B, kin, hid, dout)
         L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_fwd(C.byref(p), _stream())), "nlam_mlp_fwd")
 
@@ -261,9 +269,14 @@ class FusedMLPFunction(torch.autograd.Function):
                 alloc = torch.zeros if geom.has_split else torch.empty
                 dsrc[k] = alloc((B, geom.nseg_total, w), device=dev, dtype=torch.float32)
                 p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), geom.nseg_total * w
-        nblk = lib.nlam_num_blocks(ntiles * B)
-        vecp = torch.empty((nblk, 4, _VEC_W), device=dev, dtype=torch.float32)
-        p.vec_partials, p.vec_partials_rows = _ptr(vecp), nblk
+        nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
+        if nwp > 0:
+            wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+            p.wpack, p.wpack_floats = _ptr(wpack), nwp
+        nblk = lib.nlam_mlp_bwd_blocks(C.byref(p))
+        vs = _vec_stride(hid, dout)
+        vecp = torch.empty((nblk, 4, vs), device=dev, dtype=torch.float32)
+        p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(vecp), nblk, vs
         key = ("mlp_bwd", rows * B, kin, hid, dout)
         L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_bwd(C.byref(p), _stream())), "nlam_mlp_bwd")
 
@@ -274,14 +287,12 @@ class FusedMLPFunction(torch.autograd.Function):
                 )
 
         # ---- weight gradients: two TN GEMMs with deterministic two-stage reduction ----
-        total_chunks = B * ((rows + 31) // 32)
-        nparts = max(1, min(512, total_chunks // 4))
-
         def wgrad(A, m, src_list, n, flags):
             q = L.Wgrad()
             q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(src_list), flags, n
             for k, (t, bstride, w, idx) in enumerate(src_list):
                 _fill_src(q.src[k], t, bstride, w, idx)
+            nparts = lib.nlam_wgrad_nparts(C.byref(q))
             partials = torch.empty((nparts, m, n), device=dev, dtype=torch.float32)
             q.partials, q.nparts = _ptr(partials), nparts
             key = ("wgrad", rows * B, m, n)
@@ -299,9 +310,9 @@ class FusedMLPFunction(torch.autograd.Function):
             src_list.append((bases[k], bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k]))
         dW1 = wgrad(dz1, hid, src_list, kin, 0) if ctx.needs_input_grad[1] else None
         dW2 = wgrad(dz2, dout, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if ctx.needs_input_grad[3] else None
-        vec = torch.empty((4, _VEC_W), device=dev, dtype=torch.float32)
+        vec = torch.empty((4, vs), device=dev, dtype=torch.float32)
         L.check(
-            lib.nlam_reduce_partials(_ptr(vecp), nblk, 4 * _VEC_W, 4 * _VEC_W, _ptr(vec), 0, _stream()),
+            lib.nlam_reduce_partials(_ptr(vecp), nblk, 4 * vs, 4 * vs, _ptr(vec), 0, _stream()),
             "nlam_reduce_partials",
         )
         db1, db2 = vec[0, :hid], vec[1, :dout]

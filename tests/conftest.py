@@ -20,7 +20,9 @@ def load_golden(name):
 
 @pytest.fixture(scope="session")
 def golden_layers():
-    return load_golden("layers")["cases"]
+    cases = dict(load_golden("layers")["cases"])
+    cases.update(load_golden("layers_wide")["cases"])  # d = 128 / 256 (wide kernels)
+    return cases
 
 
 def to64(t):

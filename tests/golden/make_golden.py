@@ -111,6 +111,17 @@ def make_layers(ref):
     torch.save({"note": NOTE, "cases": cases}, HERE / "layers.pt")
 
 
+def make_layers_wide(ref):
+    """d in {128, 256}: the workgroup-cooperative ("wide") kernels of csrc/nlam_wide.inc."""
+    cases = {}
+    cases["inet_sum_update_b2_d128"] = layer_case(ref, "inet_sum_update_b2_d128", "InteractionNet", 40, 30, 200, 128, 2, 80)
+    cases["propnet_d256"] = layer_case(ref, "propnet_d256", "PropagationNet", 30, 25, 150, 256, None, 90)
+    cases["inet_mean_noupdate_d128"] = layer_case(
+        ref, "inet_mean_noupdate_d128", "InteractionNet", 300, 5, 400, 128, None, 95, update_edges=False, aggr="mean"
+    )
+    torch.save({"note": NOTE, "cases": cases}, HERE / "layers_wide.pt")
+
+
 def compress_graph(raw):
     out = {}
     for k, v in raw.items():
@@ -183,13 +194,22 @@ def model_case(ref, name, model_name, ds_kwargs, graph_kwargs, model_kwargs, B, 
     print(f"  model case {name}: loss={float(loss):.6f} params={sum(p.numel() for p in forecaster.parameters())}")
 
 
+DS_SMALL = dict(nx=30, ny=27, num_state=5, num_forcing=2, num_static=1, boundary="random", seed=3,
+                state_stats={"state_mean": [0.1, -0.2, 0.3, 0.0, 0.5], "state_std": [1.0, 2.0, 0.5, 1.5, 1.0],
+                             "state_diff_mean_standardized": [0.01, -0.02, 0.0, 0.03, 0.0],
+                             "state_diff_std_standardized": [0.5, 0.8, 1.0, 1.2, 0.9]})
+
+
 def main():
     ref = rh.load_reference()
+    if "--wide-only" in sys.argv:
+        make_layers_wide(ref)
+        model_case(ref, "graphlam_30x27_d128", "GraphLAM", DS_SMALL, dict(n_max_levels=None, hierarchical=False),
+                   dict(hidden_dim=128, hidden_layers=1, processor_layers=1), B=1, T=1, seed=46)
+        return
     make_layers(ref)
-    ds_small = dict(nx=30, ny=27, num_state=5, num_forcing=2, num_static=1, boundary="random", seed=3,
-                    state_stats={"state_mean": [0.1, -0.2, 0.3, 0.0, 0.5], "state_std": [1.0, 2.0, 0.5, 1.5, 1.0],
-                                 "state_diff_mean_standardized": [0.01, -0.02, 0.0, 0.03, 0.0],
-                                 "state_diff_std_standardized": [0.5, 0.8, 1.0, 1.2, 0.9]})
+    make_layers_wide(ref)
+    ds_small = DS_SMALL
     model_case(ref, "graphlam_30x27", "GraphLAM", ds_small, dict(n_max_levels=None, hierarchical=False),
                dict(hidden_dim=16, hidden_layers=1, processor_layers=2), B=2, T=2, seed=42)
     model_case(ref, "graphlam_30x27_variants", "GraphLAM", ds_small, dict(n_max_levels=1, hierarchical=False),
@@ -198,6 +218,8 @@ def main():
                     output_clamping_lower={"state_var_0": 0.0, "state_var_2": 0.0},
                     output_clamping_upper={"state_var_2": 1.0, "state_var_3": 5.0}), B=1, T=3, seed=43)
     ds_hi = dict(nx=81, ny=30, num_state=5, num_forcing=2, num_static=1, boundary="frame", boundary_width=4, seed=5)
+    model_case(ref, "graphlam_30x27_d128", "GraphLAM", ds_small, dict(n_max_levels=None, hierarchical=False),
+               dict(hidden_dim=128, hidden_layers=1, processor_layers=1), B=1, T=1, seed=46)
     model_case(ref, "hilam_81x30", "HiLAM", ds_hi, dict(n_max_levels=3, hierarchical=True),
                dict(hidden_dim=8, hidden_layers=1, processor_layers=1), B=1, T=1, seed=44)
     model_case(ref, "hilam_parallel_81x30", "HiLAMParallel", ds_hi, dict(n_max_levels=3, hierarchical=True),

@@ -27,12 +27,12 @@ def _edge_index(ns=5, nr=4, e=10, seed=0):
 
 def test_library_exports_every_declared_symbol():
     header = (ROOT / "include" / "nlam_hip.h").read_text()
-    declared = set(re.findall(r"^int32_t\s+(nlam_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^int(?:32|64)_t\s+(nlam_\w+)\s*\(", header, flags=re.M))
     assert declared and declared == set(L.EXPORTS)
     lib = L.load()  # raises if the .so is missing
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nlam_abi_version() == 1
+    assert lib.nlam_abi_version() == 2
     assert lib.nlam_max_width() >= 64
     assert lib.nlam_num_blocks(1) == 1 and lib.nlam_num_blocks(10**6) == 256
 

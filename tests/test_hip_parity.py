@@ -36,6 +36,7 @@ def _hl():
 LAYER_CASES = [
     "inet_sum_update_d8", "inet_mean_noupdate_b2_d8", "propnet_b2_d8", "propnet_noupdate_d16",
     "inet_chunked_d8", "inet_100to10_gap_d16", "inet_sum_update_b2_d64", "inet_highdeg_d32", "inet_hidden12_d8",
+    "inet_sum_update_b2_d128", "propnet_d256", "inet_mean_noupdate_d128",
 ]
 
 
@@ -60,7 +61,7 @@ def test_layer_matches_reference_golden(dev, golden_layers, name):
         assert rel_err(p.grad.cpu(), case["ref_grad_params"][k]) < TOL, k
 
 
-MODEL_CASES = ["graphlam_30x27", "graphlam_30x27_variants", "hilam_81x30", "hilam_parallel_81x30"]
+MODEL_CASES = ["graphlam_30x27", "graphlam_30x27_variants", "graphlam_30x27_d128", "hilam_81x30", "hilam_parallel_81x30"]
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
@@ -132,7 +133,44 @@ def test_layer_matches_oracle(dev, cls_name, d, update_edges):
         assert rel_err(p.grad.cpu(), q.grad) < TOL, k
 
 
-@pytest.mark.parametrize("kin,hid,dout,ln", [(3, 64, 64, True), (56, 64, 64, True), (64, 64, 17, False), (2, 16, 16, True), (7, 12, 5, False)])
+# cfg3 / cfg4 / cfg5 widths (BASELINE.json configs[2..4]) run on the workgroup-cooperative kernels
+@pytest.mark.parametrize("cls_name,d,update_edges", [
+    ("InteractionNet", 128, True), ("PropagationNet", 128, False), ("InteractionNet", 256, True),
+    ("PropagationNet", 256, True), ("InteractionNet", 512, True), ("InteractionNet", 96, False),
+    ("InteractionNet", 200, True),
+])
+def test_wide_layer_matches_oracle(dev, cls_name, d, update_edges):
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    ns, nr, e, B = 61, 47, 501, 2
+    ei = _rand_ei(ns, nr, e, seed=d)
+    torch.manual_seed(d)
+    ref = getattr(og, cls_name)(ei, d, update_edges=update_edges)
+    net = getattr(hl, cls_name)(ei, d, update_edges=update_edges)
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    send, rec, edge = torch.randn(B, ns, d), torch.randn(B, nr, d), torch.randn(B, e, d)
+    s1, r1, e1 = (t.clone().requires_grad_() for t in (send, rec, edge))
+    s2, r2, e2 = (t.to(dev).requires_grad_() for t in (send, rec, edge))
+    o1, o2 = ref(s1, r1, e1), net(s2, r2, e2)
+    o1 = o1 if isinstance(o1, tuple) else (o1,)
+    o2 = o2 if isinstance(o2, tuple) else (o2,)
+    for a, b in zip(o2, o1):
+        assert rel_err(a.cpu(), b) < TOL
+    sum(o.square().sum() for o in o1).backward()
+    sum(o.square().sum() for o in o2).backward()
+    for a, b in ((s2, s1), (r2, r1), (e2, e1)):
+        assert rel_err(a.grad.cpu(), b.grad) < TOL
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < TOL, k
+
+
+@pytest.mark.parametrize("kin,hid,dout,ln", [
+    (3, 64, 64, True), (56, 64, 64, True), (64, 64, 17, False), (2, 16, 16, True), (7, 12, 5, False),
+    (56, 256, 256, True), (256, 256, 17, False), (3, 128, 128, True), (128, 64, 64, True), (130, 96, 40, True),
+    (512, 512, 34, False), (18, 512, 512, True),
+])
 def test_plain_mlp_matches_oracle(dev, kin, hid, dout, ln):
     from oracle import gnn_layers as og
 

@@ -22,6 +22,7 @@ def _build_layer(case):
 LAYER_CASES = [
     "inet_sum_update_d8", "inet_mean_noupdate_b2_d8", "propnet_b2_d8", "propnet_noupdate_d16",
     "inet_chunked_d8", "inet_100to10_gap_d16", "inet_sum_update_b2_d64", "inet_highdeg_d32", "inet_hidden12_d8",
+    "inet_sum_update_b2_d128", "propnet_d256", "inet_mean_noupdate_d128",
 ]
 
 
@@ -46,7 +47,7 @@ def test_layer_forward_backward_matches_reference(golden_layers, name):
         assert rel_err(p.grad, case["ref_grad_params"][k]) < TOL, k
 
 
-MODEL_CASES = ["graphlam_30x27", "graphlam_30x27_variants", "hilam_81x30", "hilam_parallel_81x30"]
+MODEL_CASES = ["graphlam_30x27", "graphlam_30x27_variants", "graphlam_30x27_d128", "hilam_81x30", "hilam_parallel_81x30"]
 ORACLE_CLS = {"GraphLAM": om.GraphLAM, "HiLAM": om.HiLAM, "HiLAMParallel": om.HiLAMParallel}
 
 

@@ -30,7 +30,8 @@ def report(name, a, b):
 
 
 def layer_cases():
-    cases = load_golden("layers")["cases"]
+    cases = dict(load_golden("layers")["cases"])
+    cases.update(load_golden("layers_wide")["cases"])
     for name, case in cases.items():
         print(f"[layer] {name}")
         try:
@@ -57,7 +58,7 @@ def layer_cases():
 
 def model_cases():
     cls = {"GraphLAM": hm.GraphLAM, "HiLAM": hm.HiLAM, "HiLAMParallel": hm.HiLAMParallel}
-    for name in ["graphlam_30x27", "graphlam_30x27_variants", "hilam_81x30", "hilam_parallel_81x30"]:
+    for name in ["graphlam_30x27", "graphlam_30x27_variants", "graphlam_30x27_d128", "hilam_81x30", "hilam_parallel_81x30"]:
         print(f"[model] {name}")
         try:
             case = load_golden(name)
@@ -92,9 +93,74 @@ def model_cases():
             traceback.print_exc()
 
 
+def oracle_cases():
+    """HIP vs CPU oracle on seeded inputs: the wide (d > 64) kernels and odd MLP shapes."""
+    from oracle import gnn_layers as og
+
+    def rand_ei(ns, nr, e, seed):
+        g = torch.Generator().manual_seed(seed)
+        ei = torch.stack([torch.randint(0, ns, (e,), generator=g), torch.randint(0, nr, (e,), generator=g)])
+        ei[1, -1] = nr - 1
+        return ei
+
+    for cls_name, d, upd in [("InteractionNet", 128, True), ("PropagationNet", 128, False), ("InteractionNet", 256, True),
+                             ("PropagationNet", 256, True), ("InteractionNet", 512, True), ("InteractionNet", 96, False),
+                             ("InteractionNet", 200, True)]:
+        print(f"[oracle layer] {cls_name} d={d} update_edges={upd}")
+        try:
+            ns, nr, e, B = 61, 47, 501, 2
+            ei = rand_ei(ns, nr, e, d)
+            torch.manual_seed(d)
+            ref = getattr(og, cls_name)(ei, d, update_edges=upd)
+            net = getattr(hl, cls_name)(ei, d, update_edges=upd)
+            net.load_state_dict(ref.state_dict())
+            net.to(dev)
+            send, rec, edge = torch.randn(B, ns, d), torch.randn(B, nr, d), torch.randn(B, e, d)
+            s1, r1, e1 = (t.clone().requires_grad_() for t in (send, rec, edge))
+            s2, r2, e2 = (t.to(dev).requires_grad_() for t in (send, rec, edge))
+            o1, o2 = ref(s1, r1, e1), net(s2, r2, e2)
+            o1 = o1 if isinstance(o1, tuple) else (o1,)
+            o2 = o2 if isinstance(o2, tuple) else (o2,)
+            for k, (a, b) in enumerate(zip(o2, o1)):
+                report(f"out[{k}]", a, b)
+            sum(o.square().sum() for o in o1).backward()
+            sum(o.square().sum() for o in o2).backward()
+            for nm, a, b in (("grad_send", s2, s1), ("grad_rec", r2, r1), ("grad_edge", e2, e1)):
+                report(nm, a.grad, b.grad)
+            for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+                report(f"grad {k}", p.grad, q.grad)
+        except Exception:
+            traceback.print_exc()
+    for kin, hid, dout, ln in [(56, 256, 256, True), (256, 256, 17, False), (3, 128, 128, True), (128, 64, 64, True),
+                               (130, 96, 40, True), (512, 512, 34, False), (18, 512, 512, True)]:
+        print(f"[oracle mlp] {kin}->{hid}->{dout} ln={ln}")
+        try:
+            torch.manual_seed(kin)
+            ref = og.make_mlp([kin, hid, dout], layer_norm=ln)
+            net = hl.make_mlp([kin, hid, dout], layer_norm=ln)
+            net.load_state_dict(ref.state_dict())
+            net.to(dev)
+            x = torch.randn(2, 1000, kin)
+            x1, x2 = x.clone().requires_grad_(), x.to(dev).requires_grad_()
+            y1, y2 = ref(x1), net(x2)
+            report("out", y2, y1)
+            y1.sin().sum().backward()
+            y2.sin().sum().backward()
+            report("grad_x", x2.grad, x1.grad)
+            for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+                report(f"grad {k}", p.grad, q.grad)
+        except Exception:
+            traceback.print_exc()
+
+
 if __name__ == "__main__":
     print(torch.__version__, torch.cuda.get_device_name(0))
     t0 = time.time()
-    layer_cases()
-    model_cases()
+    only = sys.argv[1:]
+    if not only or "layers" in only:
+        layer_cases()
+    if not only or "oracle" in only:
+        oracle_cases()
+    if not only or "models" in only:
+        model_cases()
     print(f"worst rel err {worst:.3e}   ({time.time() - t0:.1f}s)")

@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 raw = G.create_regular_grid_graph(G.regular_grid_xy(238, 268))
 ei = raw[f"{which}_edge_index"] if which != "m2m" else raw["m2m_edge_index"][0]
 ns, nr, E = int(ei[0].max()) + 1, int(ei[1].max()) + 1, ei.shape[1]
-d = 64
+d = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 torch.manual_seed(0)
 net = hl.InteractionNet(ei, d, update_edges=(which == "m2m")).to(dev)
 send = torch.randn(1, ns, d, device=dev, requires_grad=True)
@@ -29,7 +29,7 @@ for _ in range(reps):
     outs = out if isinstance(out, tuple) else (out,)
     sum(o.sum() for o in outs).backward()
 recs = ops.PROFILE.collect()
-print(f"{which}: E={E} Ns={ns} Nr={nr}")
+print(f"{which}: E={E} Ns={ns} Nr={nr} d={d}")
 for key, v in recs.items():
     v = sorted(v[2:])
     med = v[len(v) // 2]
