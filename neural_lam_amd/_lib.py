@@ -11,7 +11,8 @@ import os
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libnlam_hip.so"
+# NLAM_LIB lets the profiling tools load an instrumented build (tools/phase_timing.py); the product default is the in-tree library
+LIB_PATH = Path(os.environ["NLAM_LIB"]) if os.environ.get("NLAM_LIB") else HERE / "libnlam_hip.so"
 
 NLAM_MAX_SRC = 3
 F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B = 1, 2, 4, 8
@@ -198,14 +199,15 @@ def check(rc: int, what: str):
         raise RuntimeError(f"{what} failed: {kind}")
 
 
-def build(verbose: bool = False) -> Path:
+def build(verbose: bool = False, out: Path | None = None, defines=()) -> Path:
     """Compile csrc/nlam_hip.hip for gfx950 into the in-tree shared library."""
     import subprocess
 
     src = HERE / "csrc" / "nlam_hip.hip"
+    out = Path(out) if out is not None else HERE / "libnlam_hip.so"
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", str(src), "-o", str(LIB_PATH)]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", *[f"-D{d}" for d in defines], str(src), "-o", str(out)]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return out

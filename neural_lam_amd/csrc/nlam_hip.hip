@@ -31,6 +31,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// ---------------------------------------------------------------------------
+// optional per-phase cycle accounting (tools/phase_timing.py builds a second
+// library with -DNLAM_TIMING; the shipped library has none of this)
+// ---------------------------------------------------------------------------
+#ifdef NLAM_TIMING
+__device__ unsigned long long g_phase_cycles[16];
+#define NLAM_T_DECL unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); \
+    unsigned int t_a0_ = 0, t_a1_ = 0, t_a2_ = 0, t_a3_ = 0, t_a4_ = 0, t_a5_ = 0, t_a6_ = 0, t_a7_ = 0;
+#define NLAM_T_DRAIN asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#define NLAM_T_MARK(k) { const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); t_a##k##_ += (unsigned int)(t_now_ - t_prev_); t_prev_ = t_now_; }
+#define NLAM_T_FLUSH(ntiles_) if ((threadIdx.x & 63) == 0) { \
+    atomicAdd(&g_phase_cycles[0], (unsigned long long)t_a0_); atomicAdd(&g_phase_cycles[1], (unsigned long long)t_a1_); \
+    atomicAdd(&g_phase_cycles[2], (unsigned long long)t_a2_); atomicAdd(&g_phase_cycles[3], (unsigned long long)t_a3_); \
+    atomicAdd(&g_phase_cycles[4], (unsigned long long)t_a4_); atomicAdd(&g_phase_cycles[5], (unsigned long long)t_a5_); \
+    atomicAdd(&g_phase_cycles[6], (unsigned long long)t_a6_); atomicAdd(&g_phase_cycles[7], (unsigned long long)t_a7_); \
+    atomicAdd(&g_phase_cycles[12], (unsigned long long)(ntiles_)); atomicAdd(&g_phase_cycles[13], 1ULL); }
+#else
+#define NLAM_T_DECL
+#define NLAM_T_DRAIN
+#define NLAM_T_MARK(k)
+#define NLAM_T_FLUSH(ntiles_)
+#endif
+
 namespace {
 
 constexpr int kWavesPerBlock = 8;                  // 512 threads: two waves per SIMD
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
     float* gml = b2l + OP;                            // OP
     float* btl = gml + OP;                            // OP
     float* stg_all = btl + OP;                        // kWavesPerBlock x 32 x STG (only when aggr)
-
+    NLAM_T_DECL
     int kin = 0;
     for (int s = 0; s < p.nsrc; ++s) kin += p.src[s].width;
     {
@@ -267,6 +290,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
     stage_vec(gml, p.ln_w, p.dout, OP, 1.f);
     stage_vec(btl, p.ln_b, p.dout, OP, 0.f);
     __syncthreads();
+    NLAM_T_MARK(0)
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -274,9 +298,15 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
     float* stg = stg_all + (size_t)wave * 32 * STG;
     const bool has_ln = p.ln_w != nullptr;
     const float inv_dout = 1.f / (float)p.dout;
+#ifdef NLAM_TIMING
+    int t_ntiles_ = 0;
+#endif
 
     const long total_tiles = (long)p.ntiles * p.batch;
     for (long gt = (long)blockIdx.x * kWavesPerBlock + wave; gt < total_tiles; gt += (long)gridDim.x * kWavesPerBlock) {
+#ifdef NLAM_TIMING
+        ++t_ntiles_;
+#endif
         const int b = (int)(gt / p.ntiles);
         const int ti = (int)(gt % p.ntiles);
         const TileInfo tl = get_tile(p.tiles, ti, p.rows);
@@ -307,6 +337,8 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
         f32x4 xa[8], xb[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) xa[t] = load_chunk(srow[0], swidth[0], t, hi, valid);
+        NLAM_T_DRAIN
+        NLAM_T_MARK(1)
         int tg = 0;
 #pragma unroll
         for (int s = 0; s < NLAM_MAX_SRC; ++s) {
@@ -325,6 +357,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
             }
         }
 
+        NLAM_T_MARK(2)
         // ---- bias, save pre-activation, SiLU -> B operand of GEMM2 ----
         float* z1row = p.z1 != nullptr ? p.z1 + ((size_t)b * p.rows + prow) * p.hid : nullptr;
 #pragma unroll
@@ -340,6 +373,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
             }
         }
 
+        NLAM_T_MARK(3)
         // ---- GEMM2 straight from the accumulators ----
         f32x16 acc2[OB];
 #pragma unroll
@@ -351,6 +385,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) mma_chunk<OB>(acc2, W2p, T2, hb * 4 + tt, acc_chunk(acc1[hb], tt), lane);
 
+        NLAM_T_MARK(4)
         // ---- bias 2 + LayerNorm over the real dout features ----
         float sum = 0.f;
 #pragma unroll
@@ -424,13 +459,18 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
                     store_chunk(orow, p.dout, t, hi, valid, m);
                 }
             }
+        NLAM_T_MARK(5)
         if (p.aggr != nullptr) {
             wave_lds_sync();
             tile_segment_reduce(stg, STG, tl, p.rowptr, (p.flags & NLAM_F_MEAN) ? p.inv_deg : nullptr,
                                 p.aggr + (size_t)b * p.nseg_total * p.dout, p.dout, lane);
             wave_lds_sync();
         }
+        NLAM_T_MARK(6)
     }
+    NLAM_T_DRAIN
+    NLAM_T_MARK(7)
+    NLAM_T_FLUSH(t_ntiles_)
 }
 
 // ---------------------------------------------------------------------------
@@ -930,7 +970,7 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_kernel(const nlam_wgrad_t
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NBW; ++q) {
-            const int blk = wave + 4 * q;
+            const int blk = wave + 4 * q + 4 * NBW * blockIdx.y;
             if (blk < nblocks) {
                 const int mb = blk / NB, nb = blk % NB;
 #pragma unroll
@@ -946,7 +986,7 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_kernel(const nlam_wgrad_t
     float* P = p.partials + (size_t)blockIdx.x * p.m * p.n;
 #pragma unroll
     for (int q = 0; q < NBW; ++q) {
-        const int blk = wave + 4 * q;
+        const int blk = wave + 4 * q + 4 * NBW * blockIdx.y;
         if (blk < nblocks) {
             const int mb = blk / NB, nb = blk % NB;
             const int n = nb * 32 + i;
@@ -1179,6 +1219,17 @@ int wgrad_windows(const nlam_wgrad_t* p) {
 // ---------------------------------------------------------------------------
 extern "C" {
 
+#ifdef NLAM_TIMING
+/* debug build only: read and clear the per-phase cycle counters */
+int32_t nlam_debug_phase_cycles(unsigned long long* out16) {
+    hipDeviceSynchronize();
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long));
+    unsigned long long zero[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof(zero));
+    return (int32_t)e;
+}
+#endif
+
 int32_t nlam_abi_version(void) { return NLAM_ABI_VERSION; }
 int32_t nlam_grid_waves(void) { return kMaxGridBlocks * kWavesPerBlock; }
 int32_t nlam_num_blocks(int64_t total_tiles) { return grid_blocks((long)total_tiles); }
@@ -1390,17 +1441,17 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     const int nblocks = (MP / 32) * (NP / 32);
     const size_t lds = (size_t)kWgradRows * (MP + 4 + NP + 4) * sizeof(float);
     const int nbw = (nblocks + 3) / 4;
-#define NLAM_LAUNCH_WG(N_)                                                                             \
-    do {                                                                                               \
-        int rc = set_lds(wgrad_kernel<N_>, lds);                                                       \
-        if (rc != 0) return rc;                                                                        \
-        hipLaunchKernelGGL((wgrad_kernel<N_>), dim3(p->nparts), dim3(kWgradThreads), lds, stream, *p); \
+    const int ywin = (nblocks + 11) / 12;   // blockIdx.y windows of 12 blocks when one workgroup cannot hold them all
+#define NLAM_LAUNCH_WG(N_, Y_)                                                                                \
+    do {                                                                                                      \
+        int rc = set_lds(wgrad_kernel<N_>, lds);                                                              \
+        if (rc != 0) return rc;                                                                               \
+        hipLaunchKernelGGL((wgrad_kernel<N_>), dim3(p->nparts, Y_), dim3(kWgradThreads), lds, stream, *p);    \
     } while (0)
-    if (nbw <= 1) NLAM_LAUNCH_WG(1);
-    else if (nbw <= 2) NLAM_LAUNCH_WG(2);
-    else if (nbw <= 3) NLAM_LAUNCH_WG(3);
-    else if (nbw <= 4) NLAM_LAUNCH_WG(4);
-    else return NLAM_EUNSUP;
+    if (nbw <= 1) NLAM_LAUNCH_WG(1, 1);
+    else if (nbw <= 2) NLAM_LAUNCH_WG(2, 1);
+    else if (nbw <= 3) NLAM_LAUNCH_WG(3, 1);
+    else NLAM_LAUNCH_WG(3, ywin);
     return (int32_t)hipGetLastError();
 }
 
