@@ -56,7 +56,13 @@ __device__ unsigned long long g_phase_cycles[16];
 
 namespace {
 
-constexpr int kWavesPerBlock = 8;                  // 512 threads: two waves per SIMD
+constexpr int kWavesPerBlock = 8;                  // backward kernels: 512 threads, two waves per SIMD
+#ifndef NLAM_FWD_WAVES
+#define NLAM_FWD_WAVES 8
+#endif
+constexpr int kFwdWaves = NLAM_FWD_WAVES;          // forward kernels: most waves per workgroup (small launches use fewer, see fwd_launch_shape)
+constexpr int kFwdThreads = kFwdWaves * 64;
+constexpr int kStgStride = 36;                     // per-wave [32][36] staging block (32 columns + 4 pad)
 constexpr int kBlockThreads = kWavesPerBlock * 64;
 constexpr int kNumCUs = 256;
 constexpr int kMaxGridBlocks = kNumCUs;            // one persistent workgroup per CU
@@ -175,9 +181,10 @@ __device__ __forceinline__ f32x4 acc_chunk(const f32x16& a, int tt) {
     return v;
 }
 
-__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence
+__device__ __forceinline__ float silu_f(float z) { return z * __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
 __device__ __forceinline__ float silu_grad_f(float z) {
-    const float s = 1.f / (1.f + __expf(-z));
+    const float s = __builtin_amdgcn_rcpf(1.f + __expf(-z));
     return s * (1.f + z * (1.f - s));
 }
 
@@ -212,7 +219,7 @@ __device__ __forceinline__ TileInfo get_tile(const nlam_tile_t* tiles, int ti, i
 // receivers and write (or atomically add, for split receivers) the result.
 __device__ __forceinline__ void tile_segment_reduce(const float* stg, int S, const TileInfo& tl, const int32_t* rowptr,
                                                     const float* inv_deg, float* out_b /* (nseg_total, w) */, int w,
-                                                    int lane) {
+                                                    int wb /* columns staged */, int lane) {
     // one coalesced fetch of the tile's <= 33 row pointers (and scales); broadcast per segment below
     int my_ptr = 0;
     float my_scale = 1.f;
@@ -226,7 +233,7 @@ __device__ __forceinline__ void tile_segment_reduce(const float* stg, int S, con
             hi_ = tl.nrows;
         }
         const float scale = __shfl(my_scale, sg, 64);
-        for (int c = lane; c < w; c += 64) {
+        for (int c = lane; c < wb; c += 64) {
             float s = 0.f;
             for (int q = lo; q < hi_; ++q) s += stg[q * S + c];
             s *= scale;
@@ -239,16 +246,82 @@ __device__ __forceinline__ void tile_segment_reduce(const float* stg, int S, con
     }
 }
 
+// A 32-column block of the wave's tile, staged as stg[row][36], -> global rows with
+// whole-line coalescing: lane -> (row, float4 column), 8 rows x 128 B per store instruction
+// (the accumulator layout itself would store 32-B pieces of 32 different rows).
+// wb = real columns of the block (multiple of 4), dst(r) = pointer to the block's first
+// column in the destination row of tile-row r.
+template <typename FD>
+__device__ __forceinline__ void block_rows_out(const float* stg, int nrows, int wb, int lane, FD&& dst) {
+    const int vpr = wb >> 2;
+    const int total = nrows * vpr;
+    // wave-uniform trip count: dst() may shuffle across lanes, so every lane evaluates it
+    for (int base = 0; base < total; base += 64) {
+        const int item = base + lane;
+        const int r = min((vpr == 8) ? (item >> 3) : item / vpr, 31);
+        const int c4 = item - r * vpr;
+        float* d = dst(r);
+        if (item < total) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&stg[r * kStgStride + 4 * c4]);
+            *reinterpret_cast<f32x4*>(d + 4 * c4) = v;
+        }
+    }
+}
+
+// Segment-sum of a staged 32-column block over the tile's receivers.  Lane l holds
+// raw_ptr = rowptr[seg0 + l] (l <= nseg) and the scale of segment l in registers, so there
+// is no dependent global load here.  lane -> (segment of this pass, float4 column).
+__device__ __forceinline__ void block_segment_reduce(const float* stg, const TileInfo& tl, int raw_ptr, float my_scale,
+                                                     float* out_b /* + column offset */, int w, int wb, int lane) {
+    const int vpr = wb >> 2;
+    const int spp = 64 / vpr;                    // segments per pass
+    const int sl = (vpr == 8) ? (lane >> 3) : lane / vpr;
+    const int c4 = lane - sl * vpr;
+    for (int s0 = 0; s0 < tl.nseg; s0 += spp) {
+        const int sg = s0 + sl;
+        int lo = __shfl(raw_ptr, sg & 63, 64) - tl.row0, hi_ = __shfl(raw_ptr, (sg + 1) & 63, 64) - tl.row0;
+        const float scale = __shfl(my_scale, sg & 63, 64);
+        if (tl.split) {
+            lo = 0;
+            hi_ = tl.nrows;
+        }
+        if (sl < spp && sg < tl.nseg) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int q = lo; q < hi_; ++q) s += *reinterpret_cast<const f32x4*>(&stg[q * kStgStride + 4 * c4]);
+            s *= scale;
+            float* dst = out_b + (size_t)(tl.seg0 + sg) * w + 4 * c4;
+            if (tl.split) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) atomicAdd(dst + c, s[c]);
+            } else {
+                *reinterpret_cast<f32x4*>(dst) = s;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // forward:  [gather | concat] -> Linear -> SiLU -> Linear -> [LayerNorm]
 //           -> [+src1] -> {segment-reduce -> aggr} -> [+src0] -> out
 // HB = padded hidden width / 32, OB = padded output width / 32
+//
+// Latency hiding is by occupancy: 16 waves per workgroup = 4 per SIMD (<= 128 VGPRs), one
+// tile per wave at a time.  A tile's life has ~16k cycles of MFMA issue and several
+// dependent memory waits (descriptor -> gather index -> rows; gfx950 retires loads and
+// stores through ONE in-order counter, so every load behind a store also waits for that
+// store's L2 acknowledgement, ~5-20k cycles here); with two waves per SIMD (round-1 design)
+// the MFMA pipe idled 60 % of the time, measured with tools/phase_timing.py.
+// Inputs stream through two half-source register buffers (16 VGPRs each); outputs leave
+// through a per-wave [32][36] LDS block so every store instruction writes whole 128-B lines.
 // ---------------------------------------------------------------------------
-template <int HB, int OB>
-__global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_fwd_t p) {
+// FAST = every source width is a multiple of 8, hid == 32*HB and dout == 32*OB: no
+// per-element bounds, no scalar tails, no masked loads (rows past the tile's end read a
+// clamped row and are discarded) -- the shape of every InteractionNet / PropagationNet
+// layer and of the d -> d -> d grid MLPs.  The generic instantiation keeps all checks.
+template <int HB, int OB, bool FAST>
+__global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int DPH = HB * 32, OP = OB * 32;
-    constexpr int STG = OP + 4;  // staging row stride: conflict-free b128 writes, b32 column reads
 
     int T1 = 0;
     for (int s = 0; s < p.nsrc; ++s) T1 += (p.src[s].width + 7) >> 3;
@@ -260,7 +333,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
     float* b2l = b1l + DPH;                           // OP
     float* gml = b2l + OP;                            // OP
     float* btl = gml + OP;                            // OP
-    float* stg_all = btl + OP;                        // kWavesPerBlock x 32 x STG (only when aggr)
+    float* stg_all = btl + OP;                        // kFwdWaves x 32 x kStgStride
     NLAM_T_DECL
     int kin = 0;
     for (int s = 0; s < p.nsrc; ++s) kin += p.src[s].width;
@@ -274,8 +347,8 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
         }
     }
     stage_packed(W2p, T2, 0, p.W2, p.hid, 1, p.dout, OB, p.hid);
-    // columns >= hid of W2p beyond (hid+7)/8 chunks must be zero too
-    {
+    if constexpr (!FAST) {
+        // columns >= hid of W2p beyond (hid+7)/8 chunks must be zero too
         const int nt_used = (p.hid + 7) >> 3;
         for (int s = threadIdx.x; s < OB * (T2 - nt_used) * 64; s += blockDim.x) {
             const int l = s & 63;
@@ -295,85 +368,122 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int j = lane & 31, hi = lane >> 5;
-    float* stg = stg_all + (size_t)wave * 32 * STG;
+    float* stg = stg_all + (size_t)wave * 32 * kStgStride;
     const bool has_ln = p.ln_w != nullptr;
     const float inv_dout = 1.f / (float)p.dout;
+    const bool hid_vec = FAST || (p.hid & 3) == 0, out_vec = FAST || (p.dout & 3) == 0;
 #ifdef NLAM_TIMING
     int t_ntiles_ = 0;
 #endif
 
     const long total_tiles = (long)p.ntiles * p.batch;
-    for (long gt = (long)blockIdx.x * kWavesPerBlock + wave; gt < total_tiles; gt += (long)gridDim.x * kWavesPerBlock) {
+    const int nwaves = blockDim.x >> 6;   // 1..kFwdWaves, chosen per launch so that small problems still cover the chip
+    for (long gt = (long)blockIdx.x * nwaves + wave; gt < total_tiles; gt += (long)gridDim.x * nwaves) {
 #ifdef NLAM_TIMING
         ++t_ntiles_;
 #endif
         const int b = (int)(gt / p.ntiles);
-        const int ti = (int)(gt % p.ntiles);
-        const TileInfo tl = get_tile(p.tiles, ti, p.rows);
+        const TileInfo tl = get_tile(p.tiles, (int)(gt % p.ntiles), p.rows);
         const bool valid = j < tl.nrows;
         const int prow = tl.row0 + j;
+        // FAST: lanes past the tile's end read a real (clamped) row; their results are never stored
+        const int prow_c = FAST ? min(tl.row0 + max(min(j, tl.nrows - 1), 0), p.rows - 1) : prow;
+        const bool ldv = FAST ? true : valid;
 
-        // ---- GEMM1 over the concatenated, gathered sources ----
-        f32x16 acc1[HB];
-#pragma unroll
-        for (int hb = 0; hb < HB; ++hb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[hb][r] = 0.f;
-
-        // All chunks of a source (<= 8: widths <= 64) are requested before the first
-        // MFMA that needs them, and source s+1 is in flight while source s is consumed.
+        // ---- every index the tile needs, requested together ----
         const float* srow[NLAM_MAX_SRC] = {nullptr, nullptr, nullptr};
         int swidth[NLAM_MAX_SRC] = {0, 0, 0};
 #pragma unroll
         for (int s = 0; s < NLAM_MAX_SRC; ++s) {
             if (s < p.nsrc) {
                 const nlam_src_t S = p.src[s];
-                long ridx = prow;
-                if (valid && S.idx != nullptr) ridx = S.idx[prow];
-                srow[s] = S.ptr + (long)b * S.bstride + (valid ? ridx : 0) * (long)S.width;
+                long ridx = prow_c;
+                if (ldv && S.idx != nullptr) ridx = S.idx[prow_c];
+                srow[s] = S.ptr + (long)b * S.bstride + (ldv ? ridx : 0) * (long)S.width;
                 swidth[s] = S.width;
             }
         }
-        f32x4 xa[8], xb[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) xa[t] = load_chunk(srow[0], swidth[0], t, hi, valid);
-        NLAM_T_DRAIN
+        int oidx = prow;
+        if (p.out != nullptr && valid && p.out_idx != nullptr) oidx = p.out_idx[prow];
+        int raw_ptr = 0;                                       // lane l: rowptr[seg0 + l]
+        float my_scale = 1.f;
+        if (p.aggr != nullptr) {
+            if (!tl.split && lane <= tl.nseg) raw_ptr = p.rowptr[tl.seg0 + lane];
+            if ((p.flags & NLAM_F_MEAN) && lane < tl.nseg) my_scale = p.inv_deg[tl.seg0 + lane];
+        }
+        auto ldc = [&](const float* row, int w, int t) -> f32x4 {
+            if constexpr (FAST)
+                return *reinterpret_cast<const f32x4*>(row + 8 * t + 4 * hi);
+            else
+                return load_chunk(row, w, t, hi, valid);
+        };
         NLAM_T_MARK(1)
-        int tg = 0;
+
+        // ---- GEMM1: units of half a source (4 chunks = 16 MFMAs per block) through two register buffers ----
+        f32x16 acc1[HB];
 #pragma unroll
-        for (int s = 0; s < NLAM_MAX_SRC; ++s) {
-            if (s < p.nsrc) {
-                f32x4(&cur)[8] = (s & 1) ? xb : xa;
-                f32x4(&nxt)[8] = (s & 1) ? xa : xb;
-                if (s + 1 < p.nsrc) {
+        for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) nxt[t] = load_chunk(srow[s + 1], swidth[s + 1], t, hi, valid);
-                }
+            for (int r = 0; r < 16; ++r) acc1[hb][r] = 0.f;
+        {
+            f32x4 xbuf[2][4];
+            auto load_unit = [&](int u, f32x4(&x)[4]) {
+                const int s = u >> 1, h = u & 1;
                 const int nt = (swidth[s] + 7) >> 3;
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    if (t < nt) mma_chunk<HB>(acc1, W1p, T1, tg + t, cur[t], lane);
-                tg += nt;
+                for (int q = 0; q < 4; ++q) {
+                    if (FAST && 4 * h + q >= nt) continue;   // lane-uniform: widths are multiples of 8
+                    x[q] = ldc(srow[s], swidth[s], 4 * h + q);
+                }
+            };
+            load_unit(0, xbuf[0]);
+            load_unit(1, xbuf[1]);
+            int tg = 0;
+#pragma unroll
+            for (int u = 0; u < 2 * NLAM_MAX_SRC; ++u) {
+                const int s = u >> 1, h = u & 1;
+                if (s < p.nsrc) {
+                    const int nt = (swidth[s] + 7) >> 3;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (4 * h + q < nt) mma_chunk<HB>(acc1, W1p, T1, tg + 4 * h + q, xbuf[u & 1][q], lane);
+                    if (h == 1) tg += nt;
+                    if (((u + 2) >> 1) < p.nsrc) load_unit(u + 2, xbuf[u & 1]);
+                }
             }
         }
-
         NLAM_T_MARK(2)
+
         // ---- bias, save pre-activation, SiLU -> B operand of GEMM2 ----
-        float* z1row = p.z1 != nullptr ? p.z1 + ((size_t)b * p.rows + prow) * p.hid : nullptr;
+        {
+            float* z1row = (p.z1 != nullptr && !hid_vec) ? p.z1 + ((size_t)b * p.rows + prow) * p.hid : nullptr;
+            float* zbase = p.z1 != nullptr ? p.z1 + ((size_t)b * p.rows + tl.row0) * p.hid : nullptr;
 #pragma unroll
-        for (int hb = 0; hb < HB; ++hb) {
+            for (int hb = 0; hb < HB; ++hb) {
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int t = hb * 4 + tt;
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(&b1l[8 * t + 4 * hi]);
-                f32x4 z = acc_chunk(acc1[hb], tt) + bias;
-                if (z1row != nullptr) store_chunk(z1row, p.hid, t, hi, valid, z);
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int t = hb * 4 + tt;
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(&b1l[8 * t + 4 * hi]);
+                    f32x4 z = acc_chunk(acc1[hb], tt) + bias;
+                    if (p.z1 != nullptr) {
+                        if (hid_vec)
+                            *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = z;
+                        else
+                            store_chunk(z1row, p.hid, t, hi, valid, z);
+                    }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc1[hb][4 * tt + c] = silu_f(z[c]);
+                    for (int c = 0; c < 4; ++c) acc1[hb][4 * tt + c] = silu_f(z[c]);
+                }
+                const int wb = FAST ? 32 : min(32, p.hid - 32 * hb);
+                if (p.z1 != nullptr && hid_vec && wb > 0) {
+                    wave_lds_sync();
+                    block_rows_out(stg, tl.nrows, wb, lane, [&](int r) { return zbase + (size_t)r * p.hid + 32 * hb; });
+                    wave_lds_sync();
+                }
             }
         }
-
         NLAM_T_MARK(3)
+
         // ---- GEMM2 straight from the accumulators ----
         f32x16 acc2[OB];
 #pragma unroll
@@ -384,8 +494,8 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) mma_chunk<OB>(acc2, W2p, T2, hb * 4 + tt, acc_chunk(acc1[hb], tt), lane);
-
         NLAM_T_MARK(4)
+
         // ---- bias 2 + LayerNorm over the real dout features ----
         float sum = 0.f;
 #pragma unroll
@@ -398,7 +508,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
                 for (int c = 0; c < 4; ++c) {
                     const float v = acc2[ob][4 * tt + c] + bias[c];
                     acc2[ob][4 * tt + c] = v;
-                    sum += (c0 + c < p.dout) ? v : 0.f;
+                    sum += (FAST || c0 + c < p.dout) ? v : 0.f;
                 }
             }
         if (has_ln) {
@@ -413,14 +523,15 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
                     for (int c = 0; c < 4; ++c) {
                         const float dlt = acc2[ob][4 * tt + c] - mean;
                         acc2[ob][4 * tt + c] = dlt;
-                        sq += (c0 + c < p.dout) ? dlt * dlt : 0.f;
+                        sq += (FAST || c0 + c < p.dout) ? dlt * dlt : 0.f;
                     }
                 }
             const float rstd = rsqrtf(row_allreduce(sq) * inv_dout + p.eps);
             if (p.rstd != nullptr && valid && hi == 0) p.rstd[(size_t)b * p.rows + prow] = rstd;
-            float* xrow = p.xhat != nullptr ? p.xhat + ((size_t)b * p.rows + prow) * p.dout : nullptr;
+            float* xrow = (p.xhat != nullptr && !out_vec) ? p.xhat + ((size_t)b * p.rows + prow) * p.dout : nullptr;
+            float* xbase = p.xhat != nullptr ? p.xhat + ((size_t)b * p.rows + tl.row0) * p.dout : nullptr;
 #pragma unroll
-            for (int ob = 0; ob < OB; ++ob)
+            for (int ob = 0; ob < OB; ++ob) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     const int t = ob * 4 + tt;
@@ -428,43 +539,72 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_fwd_kernel(const nlam_mlp_f
                     f32x4 xh;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) xh[c] = acc2[ob][4 * tt + c] * rstd;
-                    if (xrow != nullptr) store_chunk(xrow, p.dout, t, hi, valid, xh);
+                    if (p.xhat != nullptr) {
+                        if (out_vec)
+                            *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = xh;
+                        else
+                            store_chunk(xrow, p.dout, t, hi, valid, xh);
+                    }
                     const f32x4 g = *reinterpret_cast<const f32x4*>(&gml[c0]);
                     const f32x4 be = *reinterpret_cast<const f32x4*>(&btl[c0]);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc2[ob][4 * tt + c] = xh[c] * g[c] + be[c];
                 }
-        }
-
-        // ---- msg = mlp [+ src1]; aggregate; out = msg [+ src0] ----
-        float* orow = nullptr;
-        if (p.out != nullptr) {
-            long oidx = prow;
-            if (valid && p.out_idx != nullptr) oidx = p.out_idx[prow];
-            orow = p.out + (long)b * p.out_bstride + (valid ? oidx : 0) * (long)p.dout;
-        }
-#pragma unroll
-        for (int ob = 0; ob < OB; ++ob)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int t = ob * 4 + tt;
-                f32x4 m = acc_chunk(acc2[ob], tt);
-                if (p.flags & NLAM_F_ADD_SRC1) m += load_chunk(srow[1], p.dout, t, hi, valid);
-                if (p.aggr != nullptr) {
-                    if (!valid) m = f32x4{0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<f32x4*>(&stg[j * STG + 8 * t + 4 * hi]) = m;
-                }
-                if (orow != nullptr) {
-                    if (p.flags & NLAM_F_ADD_SRC0) m += load_chunk(srow[0], p.dout, t, hi, valid);
-                    store_chunk(orow, p.dout, t, hi, valid, m);
+                const int wb = FAST ? 32 : min(32, p.dout - 32 * ob);
+                if (p.xhat != nullptr && out_vec && wb > 0) {
+                    wave_lds_sync();
+                    block_rows_out(stg, tl.nrows, wb, lane, [&](int r) { return xbase + (size_t)r * p.dout + 32 * ob; });
+                    wave_lds_sync();
                 }
             }
+        }
         NLAM_T_MARK(5)
-        if (p.aggr != nullptr) {
-            wave_lds_sync();
-            tile_segment_reduce(stg, STG, tl, p.rowptr, (p.flags & NLAM_F_MEAN) ? p.inv_deg : nullptr,
-                                p.aggr + (size_t)b * p.nseg_total * p.dout, p.dout, lane);
-            wave_lds_sync();
+
+        // ---- msg = mlp [+ src1]; aggregate; out = msg [+ src0] ----
+        {
+            float* orow = (p.out != nullptr && !out_vec) ? p.out + (long)b * p.out_bstride + (valid ? (long)oidx : 0L) * (long)p.dout : nullptr;
+            float* obase = p.out != nullptr ? p.out + (long)b * p.out_bstride : nullptr;
+            float* abase = p.aggr != nullptr ? p.aggr + (size_t)b * p.nseg_total * p.dout : nullptr;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob) {
+                const int wb = FAST ? 32 : min(32, p.dout - 32 * ob);
+                f32x4 m[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    m[tt] = acc_chunk(acc2[ob], tt);
+                    if (p.flags & NLAM_F_ADD_SRC1) m[tt] += ldc(srow[1], p.dout, ob * 4 + tt);
+                    if (!valid) m[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (p.aggr != nullptr && wb > 0) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = m[tt];
+                    wave_lds_sync();
+                    if (out_vec) {
+                        block_segment_reduce(stg, tl, raw_ptr, my_scale, abase + 32 * ob, p.dout, wb, lane);
+                    } else {
+                        if constexpr (!FAST)
+                            tile_segment_reduce(stg, kStgStride, tl, p.rowptr, (p.flags & NLAM_F_MEAN) ? p.inv_deg : nullptr,
+                                                abase + 32 * ob, p.dout, wb, lane);
+                    }
+                    wave_lds_sync();
+                }
+                if (p.out != nullptr && wb > 0) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        if (p.flags & NLAM_F_ADD_SRC0) m[tt] += ldc(srow[0], p.dout, ob * 4 + tt);
+                        if (out_vec)
+                            *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = m[tt];
+                        else
+                            store_chunk(orow, p.dout, ob * 4 + tt, hi, valid, m[tt]);
+                    }
+                    if (out_vec) {
+                        wave_lds_sync();
+                        block_rows_out(stg, tl.nrows, wb, lane,
+                                       [&](int r) { return obase + (long)__shfl(oidx, r, 64) * p.dout + 32 * ob; });
+                        wave_lds_sync();
+                    }
+                }
+            }
         }
         NLAM_T_MARK(6)
     }
@@ -756,7 +896,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_kernel(const nlam_mlp_b
             }
             if (mode == 3) {
                 wave_lds_sync();
-                tile_segment_reduce(stg, STG, tl, p.rowptr, nullptr, p.dsrc[s] + (long)b * p.dsrc_bstride[s], w, lane);
+                tile_segment_reduce(stg, STG, tl, p.rowptr, nullptr, p.dsrc[s] + (long)b * p.dsrc_bstride[s], w, w, lane);
                 wave_lds_sync();
             }
         }
@@ -1085,7 +1225,7 @@ size_t fwd_lds_bytes(const nlam_mlp_fwd_t* p, int HB, int OB) {
     size_t T1 = 0;
     for (int s = 0; s < p->nsrc; ++s) T1 += (p->src[s].width + 7) / 8;
     size_t f = (size_t)DPH * 8 * T1 + (size_t)OP * DPH + DPH + 3 * OP;
-    if (p->aggr != nullptr) f += (size_t)kWavesPerBlock * 32 * (OP + 4);
+    f += (size_t)kFwdWaves * 32 * kStgStride;
     return f * sizeof(float);
 }
 
@@ -1272,12 +1412,17 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     return (int32_t)(np < 1 ? 1 : np);
 }
 
-#define NLAM_LAUNCH_FWD(HB_, OB_)                                                                      \
-    do {                                                                                               \
-        const size_t lds = fwd_lds_bytes(p, HB_, OB_);                                                 \
-        int rc = set_lds(mlp_fwd_kernel<HB_, OB_>, lds);                                               \
-        if (rc != 0) return rc;                                                                        \
-        hipLaunchKernelGGL((mlp_fwd_kernel<HB_, OB_>), dim3(blocks), dim3(kBlockThreads), lds, stream, *p); \
+#define NLAM_LAUNCH_FWD1(HB_, OB_, FAST_)                                                                      \
+    do {                                                                                                       \
+        const size_t lds = fwd_lds_bytes(p, HB_, OB_);                                                         \
+        int rc = set_lds(mlp_fwd_kernel<HB_, OB_, FAST_>, lds);                                                \
+        if (rc != 0) return rc;                                                                                \
+        hipLaunchKernelGGL((mlp_fwd_kernel<HB_, OB_, FAST_>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p); \
+    } while (0)
+#define NLAM_LAUNCH_FWD(HB_, OB_)               \
+    do {                                        \
+        if (fast) NLAM_LAUNCH_FWD1(HB_, OB_, true);  \
+        else NLAM_LAUNCH_FWD1(HB_, OB_, false); \
     } while (0)
 
 int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
@@ -1322,8 +1467,16 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
         else NLAM_LAUNCH_FWD_WIDE(8, 2);
         return (int32_t)hipGetLastError();
     }
-    const int blocks = grid_blocks((long)p->ntiles * p->batch);
+    // launch shape: one persistent workgroup per CU with up to kFwdWaves waves; launches with fewer
+    // tiles than kNumCUs * kFwdWaves use fewer waves per workgroup so the tiles still spread over all CUs
+    const long ttiles = (long)p->ntiles * p->batch;
+    long nw_l = (ttiles + kNumCUs - 1) / kNumCUs;
+    const int nwaves = (int)(nw_l < 1 ? 1 : (nw_l > kFwdWaves ? kFwdWaves : nw_l));
+    long need = (ttiles + nwaves - 1) / nwaves;
+    const int blocks = (int)(need < 1 ? 1 : (need < kMaxGridBlocks ? need : kMaxGridBlocks));
     const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
+    bool fast = (p->hid % 32 == 0) && (p->dout % 32 == 0);
+    for (int s = 0; s < p->nsrc; ++s) fast = fast && (p->src[s].width % 8 == 0);
     if (HB == 1 && OB == 1) NLAM_LAUNCH_FWD(1, 1);
     else if (HB == 2 && OB == 1) NLAM_LAUNCH_FWD(2, 1);
     else if (HB == 1 && OB == 2) NLAM_LAUNCH_FWD(1, 2);
