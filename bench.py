@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying a HIP graph")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -155,7 +156,7 @@ def main():
     from neural_lam_amd.trainer import Trainer
 
     ds, graph, raw, forecaster, step, batch = build(cfg, device, seed_offset=rank)
-    trainer = Trainer(step, lr=1e-3)
+    trainer = Trainer(step, lr=1e-3, use_graph=not args.eager)
 
     def sync():
         if world > 1:
@@ -177,14 +178,23 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * cfg["B"] * cfg["T"] * args.steps / elapsed
 
-    # forecast throughput (inference rollout, no grad), reported alongside
+    # forecast throughput (inference rollout, no grad), reported alongside; same launch mode as training
     with torch.no_grad():
         for _ in range(2):
             step.forecaster(batch[0], batch[2], batch[1])
         torch.cuda.synchronize()
+        if args.eager:
+            run_forecast = lambda: step.forecaster(batch[0], batch[2], batch[1])  # noqa: E731
+        else:
+            fgraph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(fgraph):
+                step.forecaster(batch[0], batch[2], batch[1])
+            run_forecast = fgraph.replay
+        run_forecast()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step.forecaster(batch[0], batch[2], batch[1])
+            run_forecast()
         torch.cuda.synchronize()
         fc_elapsed = time.perf_counter() - t0
     forecast_steps_per_s = world * cfg["B"] * cfg["T"] * args.steps / fc_elapsed
@@ -194,6 +204,7 @@ def main():
         # second, instrumented pass: HIP events (on the launch stream = torch's current
         # stream) around every nlam_mlp_fwd launch; pick the m2g edge launch (largest E)
         ops.PROFILE.reset(enabled=True)
+        trainer.use_graph = False   # per-launch HIP events need eager launches
         for _ in range(args.steps):
             trainer.step(*batch)
         torch.cuda.synchronize()
@@ -232,6 +243,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "launch_mode": "eager" if args.eager else "hip_graph (zero-grad + fwd + loss + bwd captured once; all-reduce + AdamW after each replay)",
             "forecast_steps_per_s": forecast_steps_per_s,
             "final_loss": float(loss),
             "config": {

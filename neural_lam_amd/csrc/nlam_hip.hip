@@ -1240,14 +1240,28 @@ size_t bwd_lds_bytes(const nlam_mlp_bwd_t* p, int HB, int OB) {
 
 constexpr size_t kMaxLds = 160 * 1024;
 
+// Raise a kernel's dynamic-LDS limit once (and only upward): the attribute call is not a
+// stream operation, so launches stay capturable in a HIP graph without repeating it.
+struct LdsGrant {
+    const void* fn;
+    size_t bytes;
+};
+LdsGrant g_lds_grants[64];
+int g_lds_ngrants = 0;
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
     if (bytes > kMaxLds) return NLAM_EUNSUP;
-    if (bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return (int)e;
-    }
+    if (bytes <= 48 * 1024) return 0;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    int slot = -1;
+    for (int k = 0; k < g_lds_ngrants; ++k)
+        if (g_lds_grants[k].fn == fn) slot = k;
+    if (slot >= 0 && g_lds_grants[slot].bytes >= bytes) return 0;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    if (slot < 0 && g_lds_ngrants < 64) slot = g_lds_ngrants++;
+    if (slot >= 0) g_lds_grants[slot] = {fn, bytes};
     return 0;
 }
 

@@ -479,8 +479,11 @@ class ARForecaster(nn.Module):
 
 
 def mask_and_reduce_metric(vals, mask, average_grid, sum_vars):
+    """metrics.py:37-84.  ``mask`` may be the reference's boolean node mask or a precomputed
+    int64 index of the selected nodes (same entries in the same order, but a static gather:
+    no nonzero() -> no host synchronisation, so the step can live in a HIP graph)."""
     if mask is not None:
-        vals = vals[..., mask, :]
+        vals = vals[..., mask, :] if mask.dtype == torch.bool else vals.index_select(-2, mask)
     if average_grid:
         vals = torch.mean(vals, dim=-2)
     if sum_vars:
@@ -504,6 +507,7 @@ class ForecasterStep(nn.Module):
         self.forecaster = forecaster
         bm = torch.tensor(datastore.boundary_mask.values, dtype=torch.float32)
         self.register_buffer("interior_mask_bool", (1.0 - bm).to(torch.bool), persistent=False)
+        self.register_buffer("interior_index", torch.nonzero(1.0 - bm > 0.5).reshape(-1), persistent=False)
         st = datastore.get_standardization_dataarray("state")
         eps = torch.finfo(torch.float32).eps
         if not forecaster.predicts_std:
@@ -541,5 +545,5 @@ class ForecasterStep(nn.Module):
         prediction, pred_std = self.forecaster(init_states, forcing, target_states)
         if pred_std is None:
             pred_std = self.per_var_std
-        time_step_loss = torch.mean(wmse(prediction, target_states, pred_std, mask=self.interior_mask_bool), dim=0)
+        time_step_loss = torch.mean(wmse(prediction, target_states, pred_std, mask=self.interior_index), dim=0)
         return prediction, torch.mean(time_step_loss)

@@ -79,12 +79,15 @@ class GradBuckets:
         self.bucket_of = {i: b for b, (_, _, mem) in enumerate(self.bounds) for i in mem}
         self.pending = [0] * len(self.bounds)
         self.handles = []
+        self.enabled = True   # False while a HIP graph owns the step (collectives run after the replay)
         if self.world > 1:
             for i, p in enumerate(fp.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def _make_hook(self, i):
         def hook(_param):
+            if not self.enabled:
+                return
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0:
@@ -122,8 +125,12 @@ class Trainer:
     """
 
     def __init__(self, module: nn.Module, lr=1e-3, betas=(0.9, 0.95), weight_decay=1e-2, eps=1e-8,
-                 bucket_bytes: int = 32 << 20, optimizer_factory=None, group=None):
+                 bucket_bytes: int = 32 << 20, optimizer_factory=None, group=None, use_graph: bool = False):
         self.module = module
+        self.use_graph = use_graph
+        self._graph = None
+        self._static_in = None
+        self._static_loss = None
         self.fp = FlatParams(module)
         self.buckets = GradBuckets(self.fp, bucket_bytes, group)
         self.world = self.buckets.world
@@ -134,7 +141,47 @@ class Trainer:
         else:
             self.opt = optimizer_factory(self.fp.flat, self.fp.grad)
 
+    # ---- HIP-graph step: zero-grad + forward + loss + backward are ~330 launches of 3-150 us at cfg2,
+    # which eager Python cannot issue as fast as the GPU retires them; captured once, replayed per step ----
+    def _fwd_bwd(self):
+        out = self.module(*self._static_in)
+        loss = out[-1] if isinstance(out, tuple) else out
+        loss.backward()
+        return loss.detach()   # nothing that references the autograd graph survives this frame
+
+    def _capture(self, *batch):
+        self._static_in = [b.clone() for b in batch]
+        self.buckets.enabled = False
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):   # warm-up outside capture: lazy CSR builds, LDS-size attributes, allocator pool
+            for _ in range(2):
+                self.fp.zero_grad()
+                self._fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        # the warm-up's autograd graph (and its AccumulateGrad nodes, bound to the side stream) is gone here, so the
+        # capture creates its own on the capture stream and accumulates in place into the flat gradient views
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self.fp.grad.zero_()
+            self._static_loss = self._fwd_bwd()
+
+    def _graph_step(self, *batch):
+        if self._graph is None:
+            self._capture(*batch)
+        for s, b in zip(self._static_in, batch):
+            s.copy_(b)
+        self._graph.replay()
+        if self.world > 1:   # one flat buffer: a single collective (0.86 MB at cfg2, 20.6 MB at cfg3)
+            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.buckets.group)
+        self.opt.step(1.0 / self.world)
+        return self._static_loss
+
     def step(self, *batch):
+        if self.use_graph:
+            return self._graph_step(*batch)
+        self.buckets.enabled = True
         self.fp.zero_grad()
         self.buckets.begin_step()
         out = self.module(*batch)
