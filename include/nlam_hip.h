@@ -55,6 +55,15 @@ extern "C" {
 #define NLAM_F_ADD_SRC1   2u   /* msg  = mlp + src[1]   (PropagationNet sender / aggr residual) */
 #define NLAM_F_MEAN       4u   /* aggregate = mean over in-edges (sum otherwise)               */
 #define NLAM_F_SILU_B     8u   /* wgrad: apply SiLU to the B operand while loading             */
+/* matrix path of the GEMMs (bits 8-9): 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains);
+ * n = 1..3: operands split into n bf16 terms on the bf16 matrix cores, fp32 accumulate
+ * (1 = plain bf16 operands, 2 = ~2^-16 product error, 3 = fp32-class ~2^-24).  Shapes the
+ * split kernels do not cover (widths not multiples of 32) run the fp32 path. */
+#define NLAM_F_MM_SHIFT   8
+#define NLAM_F_MM_MASK    (3u << NLAM_F_MM_SHIFT)
+#define NLAM_F_MM_BF16X1  (1u << NLAM_F_MM_SHIFT)
+#define NLAM_F_MM_BF16X2  (2u << NLAM_F_MM_SHIFT)
+#define NLAM_F_MM_BF16X3  (3u << NLAM_F_MM_SHIFT)
 
 typedef struct {
     const float* ptr;     /* (batch|1, n_rows_of_source, width) */
@@ -189,6 +198,26 @@ int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr
 /* out[i] (+)= sum_p partials[p * stride + i], i < n ; accumulate != 0 adds into out */
 int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stride, int32_t n, float* out,
                              int32_t accumulate, void* hip_stream);
+
+/* Up to NLAM_MAX_REDUCE_JOBS reductions of the nlam_reduce_partials kind in ONE launch: the dW1, dW2,
+ * db1, db2, dgamma, dbeta of one fused-MLP backward (autograd's AccumulateGrad `grad += new`, folded in
+ * when accumulate != 0 and out points into the gradient buffer). */
+#define NLAM_MAX_REDUCE_JOBS 6
+typedef struct {
+    const float* partials;
+    float* out;
+    int64_t stride;        /* elements between partials */
+    int32_t nparts;
+    int32_t n;
+    int32_t accumulate;
+    int32_t _pad;
+} nlam_reduce_job_t;
+typedef struct {
+    nlam_reduce_job_t job[NLAM_MAX_REDUCE_JOBS];
+    int32_t njobs;
+    int32_t _pad;
+} nlam_reduce_jobs_t;
+int32_t nlam_reduce_jobs(const nlam_reduce_jobs_t* jobs, void* hip_stream);
 
 /* decoupled-weight-decay Adam on flat buffers; step_count is the 1-based step */
 int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

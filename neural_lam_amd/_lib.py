@@ -32,6 +32,7 @@ EXPORTS = [
     "nlam_wgrad",
     "nlam_segment_sum",
     "nlam_reduce_partials",
+    "nlam_reduce_jobs",
     "nlam_adamw_step",
 ]
 
@@ -135,6 +136,22 @@ class Wgrad(C.Structure):
     ]
 
 
+class ReduceJob(C.Structure):
+    _fields_ = [
+        ("partials", C.c_void_p),
+        ("out", C.c_void_p),
+        ("stride", C.c_int64),
+        ("nparts", C.c_int32),
+        ("n", C.c_int32),
+        ("accumulate", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+class ReduceJobs(C.Structure):
+    _fields_ = [("job", ReduceJob * 6), ("njobs", C.c_int32), ("_pad", C.c_int32)]
+
+
 _lib = None
 
 
@@ -183,6 +200,8 @@ def load():
     lib.nlam_segment_sum.restype = i32
     lib.nlam_reduce_partials.argtypes = [vp, i32, i64, i32, vp, i32, vp]
     lib.nlam_reduce_partials.restype = i32
+    lib.nlam_reduce_jobs.argtypes = [C.POINTER(ReduceJobs), vp]
+    lib.nlam_reduce_jobs.restype = i32
     lib.nlam_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
     lib.nlam_adamw_step.restype = i32
     if lib.nlam_abi_version() != 2:

@@ -314,22 +314,130 @@ __device__ __forceinline__ void block_segment_reduce(const float* stg, const Til
 // Inputs stream through two half-source register buffers (16 VGPRs each); outputs leave
 // through a per-wave [32][36] LDS block so every store instruction writes whole 128-B lines.
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// split-bf16 matrix path ("NS" terms per fp32 value)
+//
+// v_mfma_f32_32x32x2_f32 runs on the SIMD's fp32 vector lanes: it issues at the VALU rate
+// and does NOT overlap with VALU work (tools/probes/mfma_probe.hip: MFMA time + VALU time add
+// up at any occupancy).  The bf16 matrix cores are 16x faster and do co-issue with VALU.
+// So an fp32 operand x is split into NS bf16 terms x = x_0 + x_1 (+ x_2), each the
+// round-to-nearest bf16 of the remainder, and a product block becomes the MFMAs
+// sum_{p+q < NS} A_p B_q accumulated in fp32:
+//   NS = 1   plain bf16 operands (autocast-like),         1 MFMA / block-step
+//   NS = 2   ~2^-16 relative product error,               3 MFMAs
+//   NS = 3   ~2^-24 (fp32 class; drops only 2^-24 terms), 6 MFMAs = 192 cycles per K = 16
+//            vs 8 fp32 MFMAs = 512 cycles.
+// K order inside a 16-wide step is "slot" order: lane (j, hi) supplies slots q = 0..7 of
+// k = 8*hi + q; GEMM2 takes its B operand straight from GEMM1's accumulators by permuting
+// the K order of W2 when it is staged (slot q of half h of block hb <-> feature
+// 32*hb + 16*h + (q & 3) + 8*(q >> 2) + 4*hi).
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, (a)), __builtin_bit_cast(s16x8, (b)), (c), 0, 0, 0)
+
+template <int NS>
+struct BfFrag {
+    u32x4 t[NS];   // term p: 8 bf16 = slots 0..7
+};
+
+// two fp32 values -> NS packed bf16 pairs (v_cvt_pk_bf16_f32, shift/and, v_pk_add_f32 per extra term)
+template <int NS>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NS]) {
+    f32x2 v = {a, b};
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+        const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+        out[p] = bits;
+        if (p + 1 < NS) {
+            v[0] -= __builtin_bit_cast(float, bits << 16);
+            v[1] -= __builtin_bit_cast(float, bits & 0xffff0000u);
+        }
+    }
+}
+
+template <int NS>
+__device__ __forceinline__ BfFrag<NS> split8(const float (&x)[8]) {
+    BfFrag<NS> f;
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+        unsigned o[NS];
+        split_pair<NS>(x[2 * pr], x[2 * pr + 1], o);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) f.t[p][pr] = o[p];
+    }
+    return f;
+}
+
+// acc += sum_{p+q < NS} A_p B_q ; smallest terms first
+template <int NS>
+__device__ __forceinline__ void mma_split(f32x16& acc, const BfFrag<NS>& A, const BfFrag<NS>& B) {
+#pragma unroll
+    for (int ord = NS - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int pa = 0; pa <= ord; ++pa) acc = MFMA_BF16(A.t[pa], B.t[ord - pa], acc);
+}
+
+// Stage an (M x K) weight slice as split-bf16 A fragments:
+//   dst[((term * MB + mb) * S + s0 + s) * 64 + lane] (16 B) = slots q = 0..7 of row mb*32 + (lane & 31),
+//   k = perm2 ? 32*(s>>1) + 16*(s&1) + (q&3) + 8*(q>>2) + 4*hi : 16*s + 8*hi + q ;  A[m][k] = W[m*ldm + k]
+template <int NS>
+__device__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2) {
+    const int nst = K >> 4;
+    const int total = MB * nst * 64;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int lane = idx & 63;
+        const int rest = idx >> 6;
+        const int st = rest % nst, mb = rest / nst;
+        const int i = lane & 31, hi = lane >> 5;
+        const int m = mb * 32 + i;
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = perm2 ? 32 * (st >> 1) + 16 * (st & 1) + (q & 3) + 8 * (q >> 2) + 4 * hi : 16 * st + 8 * hi + q;
+            x[q] = (m < M && k < K) ? W[(long)m * ldm + k] : 0.f;
+        }
+        const BfFrag<NS> f = split8<NS>(x);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) dst[(((size_t)p * MB + mb) * S + s0 + st) * 64 + lane] = f.t[p];
+    }
+}
+
+template <int NS>
+__device__ __forceinline__ BfFrag<NS> load_afrag(const u32x4* Wp, int MB, int S, int mb, int st, int lane) {
+    BfFrag<NS> f;
+#pragma unroll
+    for (int p = 0; p < NS; ++p) f.t[p] = Wp[(((size_t)p * MB + mb) * S + st) * 64 + lane];
+    return f;
+}
+
 // FAST = every source width is a multiple of 8, hid == 32*HB and dout == 32*OB: no
 // per-element bounds, no scalar tails, no masked loads (rows past the tile's end read a
 // clamped row and are discarded) -- the shape of every InteractionNet / PropagationNet
 // layer and of the d -> d -> d grid MLPs.  The generic instantiation keeps all checks.
-template <int HB, int OB, bool FAST>
+// NS = 0: fp32 MFMA (exact fmaf chains); NS > 0: split-bf16 matrix path (FAST shapes whose
+// source widths are multiples of 32), see above.
+template <int HB, int OB, bool FAST, int NS>
 __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int DPH = HB * 32, OP = OB * 32;
+    constexpr int NSW = NS > 0 ? NS : 1;
+    static_assert(NS == 0 || FAST, "the split-bf16 path covers FAST shapes only");
 
     int T1 = 0;
     for (int s = 0; s < p.nsrc; ++s) T1 += (p.src[s].width + 7) >> 3;
     constexpr int T2 = DPH / 8;
+    const int S1 = T1 >> 1;                           // K = 16 steps of GEMM1 (split path)
+    constexpr int S2 = DPH / 16;
 
-    float* W1p = smem;                                // DPH x (8*T1)
-    float* W2p = W1p + (size_t)DPH * 8 * T1;          // OP x DPH
-    float* b1l = W2p + (size_t)OP * DPH;              // DPH
+    // weights: fp32 packed (NS = 0: DPH*8*T1 + OP*DPH floats) or NS split-bf16 copies (half the bytes each)
+    float* W1p = smem;
+    float* W2p = W1p + (NS > 0 ? (size_t)NS * DPH * 8 * T1 / 2 : (size_t)DPH * 8 * T1);
+    float* b1l = W2p + (NS > 0 ? (size_t)NS * OP * DPH / 2 : (size_t)OP * DPH);   // DPH
+    u32x4* W1s = reinterpret_cast<u32x4*>(W1p);       // [NS][HB][S1][64] x 16 B
+    u32x4* W2s = reinterpret_cast<u32x4*>(W2p);       // [NS][OB][S2][64] x 16 B
     float* b2l = b1l + DPH;                           // OP
     float* gml = b2l + OP;                            // OP
     float* btl = gml + OP;                            // OP
@@ -337,7 +445,16 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
     NLAM_T_DECL
     int kin = 0;
     for (int s = 0; s < p.nsrc; ++s) kin += p.src[s].width;
-    {
+    if constexpr (NS > 0) {
+        int s0 = 0, off = 0;
+        for (int s = 0; s < p.nsrc; ++s) {
+            const int w = p.src[s].width;
+            stage_split<NSW>(W1s, S1, s0, p.W1 + off, kin, p.hid, HB, w, false);
+            off += w;
+            s0 += w >> 4;
+        }
+        stage_split<NSW>(W2s, S2, 0, p.W2, p.hid, p.dout, OB, p.hid, true);
+    } else {
         int t0 = 0, off = 0;
         for (int s = 0; s < p.nsrc; ++s) {
             const int w = p.src[s].width;
@@ -345,8 +462,8 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
             off += w;
             t0 += (w + 7) >> 3;
         }
+        stage_packed(W2p, T2, 0, p.W2, p.hid, 1, p.dout, OB, p.hid);
     }
-    stage_packed(W2p, T2, 0, p.W2, p.hid, 1, p.dout, OB, p.hid);
     if constexpr (!FAST) {
         // columns >= hid of W2p beyond (hid+7)/8 chunks must be zero too
         const int nt_used = (p.hid + 7) >> 3;
@@ -425,7 +542,56 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[hb][r] = 0.f;
-        {
+        if constexpr (NS > 0) {
+            // units of 32 columns = two K = 16 steps; lane (j, hi) reads 8 consecutive floats per step
+            f32x4 xbuf[2][4];
+            auto load_unit = [&](const float* row, int c32, f32x4(&x)[4]) {
+                const float* r = row + 32 * c32 + 8 * hi;
+                x[0] = *reinterpret_cast<const f32x4*>(r);
+                x[1] = *reinterpret_cast<const f32x4*>(r + 4);
+                x[2] = *reinterpret_cast<const f32x4*>(r + 16);
+                x[3] = *reinterpret_cast<const f32x4*>(r + 20);
+            };
+            // flat list of units: (source, 32-column block)
+            int us = 0, uc = 0;           // next unit to load
+            auto advance = [&]() {
+                ++uc;
+                if (us < p.nsrc && 32 * uc >= (us == 0 ? swidth[0] : (us == 1 ? swidth[1] : swidth[2]))) {
+                    ++us;
+                    uc = 0;
+                }
+            };
+            auto load_next = [&](f32x4(&x)[4]) {
+                const float* base = us == 0 ? srow[0] : (us == 1 ? srow[1] : srow[2]);
+                load_unit(base, uc, x);
+                advance();
+            };
+            auto consume = [&](const f32x4(&x)[4], int u) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float xs8[8] = {x[2 * h][0], x[2 * h][1], x[2 * h][2], x[2 * h][3],
+                                          x[2 * h + 1][0], x[2 * h + 1][1], x[2 * h + 1][2], x[2 * h + 1][3]};
+                    const BfFrag<NSW> B = split8<NSW>(xs8);
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) {
+                        const BfFrag<NSW> A = load_afrag<NSW>(W1s, HB, S1, hb, 2 * u + h, lane);
+                        mma_split<NSW>(acc1[hb], A, B);
+                    }
+                }
+            };
+            int nunits = 0;
+            for (int s = 0; s < p.nsrc; ++s) nunits += swidth[s] >> 5;
+            load_next(xbuf[0]);
+            if (nunits > 1) load_next(xbuf[1]);
+            for (int u = 0; u < nunits; u += 2) {   // static buffer indices: the pair (u, u + 1)
+                consume(xbuf[0], u);
+                if (u + 2 < nunits) load_next(xbuf[0]);
+                if (u + 1 < nunits) {
+                    consume(xbuf[1], u + 1);
+                    if (u + 3 < nunits) load_next(xbuf[1]);
+                }
+            }
+        } else {
             f32x4 xbuf[2][4];
             auto load_unit = [&](int u, f32x4(&x)[4]) {
                 const int s = u >> 1, h = u & 1;
@@ -490,10 +656,27 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
         for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[ob][r] = 0.f;
+        if constexpr (NS > 0) {
 #pragma unroll
-        for (int hb = 0; hb < HB; ++hb)
+            for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) mma_chunk<OB>(acc2, W2p, T2, hb * 4 + tt, acc_chunk(acc1[hb], tt), lane);
+                for (int h = 0; h < 2; ++h) {
+                    float xs8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) xs8[q] = acc1[hb][8 * h + q];
+                    const BfFrag<NSW> B = split8<NSW>(xs8);
+#pragma unroll
+                    for (int ob = 0; ob < OB; ++ob) {
+                        const BfFrag<NSW> A = load_afrag<NSW>(W2s, OB, S2, ob, 2 * hb + h, lane);
+                        mma_split<NSW>(acc2[ob], A, B);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) mma_chunk<OB>(acc2, W2p, T2, hb * 4 + tt, acc_chunk(acc1[hb], tt), lane);
+        }
         NLAM_T_MARK(4)
 
         // ---- bias 2 + LayerNorm over the real dout features ----
@@ -1200,6 +1383,32 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* parti
     }
 }
 
+// several partial-sum reductions in one launch (blockIdx.y = job): the weight and vector
+// gradients of one fused-MLP backward, optionally accumulated straight into the flat gradient buffer
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(const nlam_reduce_jobs_t jobs) {
+    __shared__ float red[4][64];
+    if ((int)blockIdx.y >= jobs.njobs) return;
+    const nlam_reduce_job_t jb = jobs.job[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = blockIdx.x * 64; base < jb.n; base += gridDim.x * 64) {
+        const int idx = base + lane;
+        float s = 0.f;
+        if (idx < jb.n) {
+            const int per = (jb.nparts + 3) / 4;
+            const int q0 = wave * per, q1 = min(jb.nparts, q0 + per);
+#pragma unroll 8
+            for (int q = q0; q < q1; ++q) s += jb.partials[(size_t)q * jb.stride + idx];
+        }
+        red[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && idx < jb.n) {
+            const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            jb.out[idx] = jb.accumulate ? jb.out[idx] + t : t;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void adamw_kernel(float* param, const float* grad, float* m, float* v, long n, float lr, float b1, float b2,
                              float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
@@ -1220,11 +1429,13 @@ __global__ void adamw_kernel(float* param, const float* grad, float* m, float* v
 // ---------------------------------------------------------------------------
 // host side helpers
 // ---------------------------------------------------------------------------
-size_t fwd_lds_bytes(const nlam_mlp_fwd_t* p, int HB, int OB) {
+size_t fwd_lds_bytes(const nlam_mlp_fwd_t* p, int HB, int OB, int NS = 0) {
     const int DPH = HB * 32, OP = OB * 32;
     size_t T1 = 0;
     for (int s = 0; s < p->nsrc; ++s) T1 += (p->src[s].width + 7) / 8;
-    size_t f = (size_t)DPH * 8 * T1 + (size_t)OP * DPH + DPH + 3 * OP;
+    size_t wf = (size_t)DPH * 8 * T1 + (size_t)OP * DPH;   // weights, in floats
+    if (NS > 0) wf = wf * NS / 2;                            // NS bf16 copies
+    size_t f = wf + DPH + 3 * OP;
     f += (size_t)kFwdWaves * 32 * kStgStride;
     return f * sizeof(float);
 }
@@ -1426,17 +1637,20 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     return (int32_t)(np < 1 ? 1 : np);
 }
 
-#define NLAM_LAUNCH_FWD1(HB_, OB_, FAST_)                                                                      \
-    do {                                                                                                       \
-        const size_t lds = fwd_lds_bytes(p, HB_, OB_);                                                         \
-        int rc = set_lds(mlp_fwd_kernel<HB_, OB_, FAST_>, lds);                                                \
-        if (rc != 0) return rc;                                                                                \
-        hipLaunchKernelGGL((mlp_fwd_kernel<HB_, OB_, FAST_>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p); \
+#define NLAM_LAUNCH_FWD1(HB_, OB_, FAST_, NS_)                                                                        \
+    do {                                                                                                               \
+        const size_t lds = fwd_lds_bytes(p, HB_, OB_, NS_);                                                            \
+        int rc = set_lds(mlp_fwd_kernel<HB_, OB_, FAST_, NS_>, lds);                                                   \
+        if (rc != 0) return rc;                                                                                        \
+        hipLaunchKernelGGL((mlp_fwd_kernel<HB_, OB_, FAST_, NS_>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p);  \
     } while (0)
-#define NLAM_LAUNCH_FWD(HB_, OB_)               \
-    do {                                        \
-        if (fast) NLAM_LAUNCH_FWD1(HB_, OB_, true);  \
-        else NLAM_LAUNCH_FWD1(HB_, OB_, false); \
+#define NLAM_LAUNCH_FWD(HB_, OB_)                              \
+    do {                                                       \
+        if (ns == 3) NLAM_LAUNCH_FWD1(HB_, OB_, true, 3);      \
+        else if (ns == 2) NLAM_LAUNCH_FWD1(HB_, OB_, true, 2); \
+        else if (ns == 1) NLAM_LAUNCH_FWD1(HB_, OB_, true, 1); \
+        else if (fast) NLAM_LAUNCH_FWD1(HB_, OB_, true, 0);    \
+        else NLAM_LAUNCH_FWD1(HB_, OB_, false, 0);             \
     } while (0)
 
 int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
@@ -1490,7 +1704,15 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
     const int blocks = (int)(need < 1 ? 1 : (need < kMaxGridBlocks ? need : kMaxGridBlocks));
     const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
     bool fast = (p->hid % 32 == 0) && (p->dout % 32 == 0);
-    for (int s = 0; s < p->nsrc; ++s) fast = fast && (p->src[s].width % 8 == 0);
+    bool w32 = true;
+    for (int s = 0; s < p->nsrc; ++s) {
+        fast = fast && (p->src[s].width % 8 == 0);
+        w32 = w32 && (p->src[s].width % 32 == 0);
+    }
+    // matrix path: NLAM_F_MM_* asks for the split-bf16 cores; shapes they do not cover run the fp32 MFMA
+    int ns = 0;
+    if (fast && w32) ns = (int)((p->flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
+    if (ns > 3) return NLAM_EINVAL;
     if (HB == 1 && OB == 1) NLAM_LAUNCH_FWD(1, 1);
     else if (HB == 2 && OB == 1) NLAM_LAUNCH_FWD(2, 1);
     else if (HB == 1 && OB == 2) NLAM_LAUNCH_FWD(1, 2);
@@ -1641,6 +1863,20 @@ int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stri
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream, partials, nparts,
                        (long)stride, n, out, accumulate);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_reduce_jobs(const nlam_reduce_jobs_t* jobs, void* hip_stream) {
+    if (jobs == nullptr || jobs->njobs < 1 || jobs->njobs > NLAM_MAX_REDUCE_JOBS) return NLAM_EINVAL;
+    int nmax = 0;
+    for (int k = 0; k < jobs->njobs; ++k) {
+        const nlam_reduce_job_t& j = jobs->job[k];
+        if (j.partials == nullptr || j.out == nullptr || j.nparts < 1 || j.n < 1) return NLAM_EINVAL;
+        if (j.n > nmax) nmax = j.n;
+    }
+    int blocks = (nmax + 63) / 64;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3(blocks, jobs->njobs), dim3(256), 0, (hipStream_t)hip_stream, *jobs);
     return (int32_t)hipGetLastError();
 }
 

@@ -7,6 +7,7 @@ There is deliberately no eager / CPU fallback: CPU tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -18,6 +19,31 @@ def _vec_stride(hid: int, dout: int) -> int:
     """Row stride of the (db1, db2, dgamma, dbeta) partial-sum buffer: a multiple of 64 >= max(hid, dout)."""
     return max(64, (max(hid, dout) + 63) // 64 * 64)
 
+
+
+# Matrix path of the fused kernels (include/nlam_hip.h NLAM_F_MM_*): "f32" = fp32 MFMA (exact fmaf
+# chains), "bf16x3" / "bf16x2" = operands split into 3 / 2 bf16 terms on the bf16 matrix cores with fp32
+# accumulation (fp32-class / ~2^-16 product error), "bf16" = plain bf16 operands.
+_MM_FLAGS = {"f32": 0, "bf16": 1 << 8, "bf16x2": 2 << 8, "bf16x3": 3 << 8}
+MATMUL_MODE = os.environ.get("NLAM_MATMUL", "f32")
+
+
+def set_matmul_mode(mode: str):
+    global MATMUL_MODE
+    if mode not in _MM_FLAGS:
+        raise ValueError(f"unknown matmul mode {mode!r}; one of {sorted(_MM_FLAGS)}")
+    MATMUL_MODE = mode
+
+
+def _mm_flags() -> int:
+    return _MM_FLAGS[MATMUL_MODE]
+
+
+# When a trainer owns every parameter's .grad as a zero-initialised view of one flat buffer
+# (trainer.FlatParams), the backward of a fused MLP adds its weight / bias / LayerNorm gradients straight
+# into those views inside the partial-sum reduction and returns None for them: ~6 AccumulateGrad add
+# launches per MLP (~130 per step at cfg2) disappear.
+DIRECT_PARAM_GRADS = False
 
 
 def _stream():
@@ -174,7 +200,7 @@ class FusedMLPFunction(torch.autograd.Function):
         W1c, b1c, W2c, b2c = W1.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous()
         p.W1, p.b1, p.W2, p.b2 = _ptr(W1c), _ptr(b1c), _ptr(W2c), _ptr(b2c)
         p.ln_w, p.ln_b = _ptr(ln_w), _ptr(ln_b)
-        p.eps, p.hid, p.dout, p.flags = 1e-5, hid, dout, geom.flags
+        p.eps, p.hid, p.dout, p.flags = 1e-5, hid, dout, geom.flags | _mm_flags()
         out = aggr = None
         if geom.want_out:
             out_rows = geom.out_rows if geom.out_rows is not None else rows
@@ -204,6 +230,7 @@ class FusedMLPFunction(torch.autograd.Function):
             ctx.binfo = [(b_, bstride) for (_, b_, bstride, _) in binfo]
             ctx.src_shapes = [tuple(s.shape) for s in srcs]
             ctx.has_ln = ln_w is not None
+            ctx.param_refs = (W1, b1, W2, b2, ln_w, ln_b)   # for .grad views only (DIRECT_PARAM_GRADS)
             ctx.save_for_backward(W1c, W2c, ln_w, z1, xhat, rstd, *[bi[0] for bi in binfo])
             ctx.set_materialize_grads(False)
         if out is not None:
@@ -297,27 +324,55 @@ class FusedMLPFunction(torch.autograd.Function):
             q.partials, q.nparts = _ptr(partials), nparts
             key = ("wgrad", rows * B, m, n)
             L.check(PROFILE.launch(key, lambda: lib.nlam_wgrad(C.byref(q), _stream())), "nlam_wgrad")
-            outw = torch.empty((m, n), device=dev, dtype=torch.float32)
-            L.check(
-                lib.nlam_reduce_partials(_ptr(partials), nparts, m * n, m * n, _ptr(outw), 0, _stream()),
-                "nlam_reduce_partials",
-            )
-            return outw
+            return partials
 
         src_list = []
         for k in range(nsrc):
             b_, bstride = ctx.binfo[k]
             src_list.append((bases[k], bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k]))
-        dW1 = wgrad(dz1, hid, src_list, kin, 0) if ctx.needs_input_grad[1] else None
-        dW2 = wgrad(dz2, dout, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if ctx.needs_input_grad[3] else None
-        vec = torch.empty((4, vs), device=dev, dtype=torch.float32)
-        L.check(
-            lib.nlam_reduce_partials(_ptr(vecp), nblk, 4 * vs, 4 * vs, _ptr(vec), 0, _stream()),
-            "nlam_reduce_partials",
-        )
-        db1, db2 = vec[0, :hid], vec[1, :dout]
-        dg = vec[2, :dout] if ctx.has_ln else None
-        dbt = vec[3, :dout] if ctx.has_ln else None
+        part1 = wgrad(dz1, hid, src_list, kin, 0) if ctx.needs_input_grad[1] else None
+        part2 = wgrad(dz2, dout, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if ctx.needs_input_grad[3] else None
+
+        # ---- one launch reduces every partial sum; with DIRECT_PARAM_GRADS it accumulates into .grad ----
+        prm = ctx.param_refs
+        jobs = L.ReduceJobs()
+        results = [None] * 6   # dW1, db1, dW2, db2, dgamma, dbeta
+        keep = []
+
+        def add_job(slot, partials_ptr, nparts, stride, shape, param):
+            n = 1
+            for d_ in shape:
+                n *= d_
+            direct = (
+                DIRECT_PARAM_GRADS and param is not None and param.grad is not None and param.grad.is_contiguous()
+                and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32
+            )
+            if direct:
+                out = param.grad
+            else:
+                out = torch.empty(shape, device=dev, dtype=torch.float32)
+                results[slot] = out
+            keep.append(out)
+            j = jobs.job[jobs.njobs]
+            j.partials, j.out, j.stride, j.nparts, j.n, j.accumulate = partials_ptr, _ptr(out), stride, nparts, n, 1 if direct else 0
+            jobs.njobs += 1
+
+        vbase = vecp.data_ptr()
+        if part1 is not None:
+            add_job(0, _ptr(part1), part1.shape[0], hid * kin, (hid, kin), prm[0])
+        if ctx.needs_input_grad[2]:
+            add_job(1, vbase + 0 * vs * 4, nblk, 4 * vs, (hid,), prm[1])
+        if part2 is not None:
+            add_job(2, _ptr(part2), part2.shape[0], dout * hid, (dout, hid), prm[2])
+        if ctx.needs_input_grad[4]:
+            add_job(3, vbase + 1 * vs * 4, nblk, 4 * vs, (dout,), prm[3])
+        if ctx.has_ln and ctx.needs_input_grad[5]:
+            add_job(4, vbase + 2 * vs * 4, nblk, 4 * vs, (dout,), prm[4])
+        if ctx.has_ln and ctx.needs_input_grad[6]:
+            add_job(5, vbase + 3 * vs * 4, nblk, 4 * vs, (dout,), prm[5])
+        if jobs.njobs > 0:
+            L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
+        dW1, db1, dW2, db2, dg, dbt = results
 
         grads_src = []
         for k in range(nsrc):

@@ -128,6 +128,12 @@ class Trainer:
                  bucket_bytes: int = 32 << 20, optimizer_factory=None, group=None, use_graph: bool = False):
         self.module = module
         self.use_graph = use_graph
+        try:   # the fused-MLP backward may now add parameter gradients straight into the flat views
+            from . import ops
+
+            ops.DIRECT_PARAM_GRADS = True
+        except Exception:   # CPU-only test environments without the HIP library
+            pass
         self._graph = None
         self._static_in = None
         self._static_loss = None
