@@ -384,7 +384,7 @@ __device__ __forceinline__ void mma_split(f32x16& acc, const BfFrag<NS>& A, cons
 //   dst[((term * MB + mb) * S + s0 + s) * 64 + lane] (16 B) = slots q = 0..7 of row mb*32 + (lane & 31),
 //   k = perm2 ? 32*(s>>1) + 16*(s&1) + (q&3) + 8*(q>>2) + 4*hi : 16*s + 8*hi + q ;  A[m][k] = W[m*ldm + k]
 template <int NS>
-__device__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2) {
+__device__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2, long ldk = 1) {
     const int nst = K >> 4;
     const int total = MB * nst * 64;
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
@@ -397,7 +397,7 @@ __device__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm,
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int k = perm2 ? 32 * (st >> 1) + 16 * (st & 1) + (q & 3) + 8 * (q >> 2) + 4 * hi : 16 * st + 8 * hi + q;
-            x[q] = (m < M && k < K) ? W[(long)m * ldm + k] : 0.f;
+            x[q] = (m < M && k < K) ? W[(long)m * ldm + (long)k * ldk] : 0.f;
         }
         const BfFrag<NS> f = split8<NS>(x);
 #pragma unroll
@@ -1104,6 +1104,350 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_kernel(const nlam_mlp_b
 }
 
 // ---------------------------------------------------------------------------
+// backward, FAST shapes (hid == 32*HB, dout == 32*OB, every source with a data gradient
+// 32 or 64 wide): no bounds / scalar tails, rows leave through the per-wave [32][36] LDS
+// block as whole 128-B lines, column sums (bias / LayerNorm-affine gradients) are taken
+// from the same staged blocks, and the three GEMM groups (dh = W2^T dz2, dx_s = W1_s^T dz1)
+// run on the fp32 MFMA (NS = 0) or the split-bf16 matrix cores (NS = 1..3) with their B
+// operands taken straight from the accumulator registers (slot-permuted K order, see the
+// split-bf16 notes above).
+// ---------------------------------------------------------------------------
+// column sums of the wave's staged 32-column block: lane -> (column, half of the rows)
+__device__ __forceinline__ float block_colsum_half(const float* stg, int lane) {
+    const int c = lane & 31, r0 = (lane >> 5) * 16;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += stg[(r0 + q) * kStgStride + c];
+    return s;
+}
+
+template <int HB, int OB, int NS>
+__global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_mlp_bwd_t p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int DPH = HB * 32, OP = OB * 32;
+    constexpr int NSW = NS > 0 ? NS : 1;
+    constexpr int T2 = OP / 8, T1 = DPH / 8;     // fp32 K chunks of dh (K = dout) and dx (K = hid)
+    constexpr int S2 = OP / 16, S1 = DPH / 16;   // split-bf16 K steps
+
+    int kin = 0;
+    for (int s = 0; s < p.nsrc; ++s) kin += p.src[s].width;
+
+    // ---- weights: W2^T (hid x dout) then W1_s^T (w_s x hid) per source with a data gradient ----
+    const size_t w2_floats = NS > 0 ? (size_t)NS * DPH * OP / 2 : (size_t)DPH * OP;
+    float* W2t = smem;
+    float* W1t = W2t + w2_floats;
+    size_t w1_floats = 0;
+    int w1_off[NLAM_MAX_SRC] = {0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+        w1_off[s] = (int)w1_floats;
+        if (s < p.nsrc && p.dmode[s] != 0) w1_floats += NS > 0 ? (size_t)NS * p.src[s].width * DPH / 2 : (size_t)p.src[s].width * DPH;
+    }
+    float* gml = W1t + w1_floats;                         // OP
+    float* stg_all = gml + OP;                            // kWavesPerBlock x 32 x kStgStride
+    if constexpr (NS > 0) {
+        // A[m = hidden][k = out (slot-permuted)] = W2[k][m]
+        stage_split<NSW>(reinterpret_cast<u32x4*>(W2t), S2, 0, p.W2, 1, p.hid, HB, p.dout, true, p.hid);
+        int off = 0;
+        for (int s = 0; s < p.nsrc; ++s) {
+            const int w = p.src[s].width;
+            if (p.dmode[s] != 0)   // A[m = source column][k = hidden (slot-permuted)] = W1[k][off + m]
+                stage_split<NSW>(reinterpret_cast<u32x4*>(W1t + w1_off[s]), S1, 0, p.W1 + off, 1, w, w >> 5, p.hid, true, kin);
+            off += w;
+        }
+    } else {
+        stage_packed(W2t, T2, 0, p.W2, 1, p.hid, p.hid, HB, p.dout);
+        int off = 0;
+        for (int s = 0; s < p.nsrc; ++s) {
+            const int w = p.src[s].width;
+            if (p.dmode[s] != 0) stage_packed(W1t + w1_off[s], T1, 0, p.W1 + off, 1, kin, w, w >> 5, p.hid);
+            off += w;
+        }
+    }
+    stage_vec(gml, p.ln_w, p.dout, OP, 1.f);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    float* stg = stg_all + (size_t)wave * 32 * kStgStride;
+    const bool has_ln = p.ln_w != nullptr;
+    const float inv_dout = 1.f / (float)p.dout;
+    const bool add_gout = (p.flags & NLAM_F_ADD_SRC0) != 0 && p.g_out != nullptr && p.dmode[0] != 0;
+    const bool add_gmsg = (p.flags & NLAM_F_ADD_SRC1) != 0 && p.nsrc > 1 && p.dmode[1] != 0;
+
+    // per-lane column accumulators: lane -> (column lane & 31, row half lane >> 5) of each 32-column block
+    float acc_db1[HB], acc_db2[OB], acc_dg[OB], acc_dbt[OB];
+#pragma unroll
+    for (int k = 0; k < HB; ++k) acc_db1[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < OB; ++k) acc_db2[k] = acc_dg[k] = acc_dbt[k] = 0.f;
+
+    const long total_tiles = (long)p.ntiles * p.batch;
+    for (long gt = (long)blockIdx.x * kWavesPerBlock + wave; gt < total_tiles; gt += (long)gridDim.x * kWavesPerBlock) {
+        const int b = (int)(gt / p.ntiles);
+        const TileInfo tl = get_tile(p.tiles, (int)(gt % p.ntiles), p.rows);
+        const bool valid = j < tl.nrows;
+        const int prow = tl.row0 + j;
+        const int prow_c = min(tl.row0 + max(min(j, tl.nrows - 1), 0), p.rows - 1);   // clamped: loads never fault
+        const size_t srow_c = (size_t)b * p.rows + prow_c;
+        const size_t tile_row0 = (size_t)b * p.rows + tl.row0;
+
+        // ---- indices ----
+        int oidx = prow_c;
+        if (p.g_out != nullptr && p.out_idx != nullptr) oidx = p.out_idx[prow_c];
+        int sg = 0;
+        float gscale = 1.f;
+        if (p.g_aggr != nullptr) {
+            sg = p.seg_of_row[prow_c];
+            if (p.flags & NLAM_F_MEAN) gscale = p.inv_deg[sg];
+        }
+        int sidx[NLAM_MAX_SRC] = {prow_c, prow_c, prow_c};
+#pragma unroll
+        for (int s = 0; s < NLAM_MAX_SRC; ++s)
+            if (s < p.nsrc && p.dmode[s] == 1 && p.src[s].idx != nullptr) sidx[s] = p.src[s].idx[prow_c];
+        int raw_ptr = 0;
+        if (p.rowptr != nullptr && !tl.split && lane <= tl.nseg) raw_ptr = p.rowptr[tl.seg0 + lane];
+        const float rstd = has_ln ? p.rstd[srow_c] : 0.f;
+        const float* grow = p.g_out != nullptr ? p.g_out + (long)b * p.out_bstride + (long)oidx * p.dout : nullptr;
+        const float* garow = p.g_aggr != nullptr ? p.g_aggr + ((size_t)b * p.nseg_total + sg) * p.dout : nullptr;
+        const float* xrow = has_ln ? p.xhat + srow_c * p.dout : nullptr;
+        const float* zrow = p.z1 + srow_c * p.hid;
+
+        // ---- dmsg (C-layout chunks), LayerNorm backward ----
+        f32x16 dz2[OB];
+        f32x4 gsave[OB][4];   // g_out chunks for the edge residual (out = msg + src0)
+        {
+            float m1 = 0.f, m2 = 0.f;
+            f32x4 xh[OB][4];
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
+                    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                    if (grow != nullptr) {
+                        g = *reinterpret_cast<const f32x4*>(grow + c0);
+                        gsave[ob][tt] = g;
+                    }
+                    if (garow != nullptr) g += *reinterpret_cast<const f32x4*>(garow + c0) * gscale;
+                    if (!valid) g = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (has_ln) xh[ob][tt] = *reinterpret_cast<const f32x4*>(xrow + c0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dz2[ob][4 * tt + c] = g[c];
+                }
+                if (has_ln) {
+                    // dbeta = colsum(dmsg), dgamma = colsum(dmsg * xhat), through the staged block
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt);
+                    wave_lds_sync();
+                    acc_dbt[ob] += block_colsum_half(stg, lane);
+                    wave_lds_sync();
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+                        *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt) * xh[ob][tt];
+                    wave_lds_sync();
+                    acc_dg[ob] += block_colsum_half(stg, lane);
+                    wave_lds_sync();
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(&gml[8 * (ob * 4 + tt) + 4 * hi]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float gy = dz2[ob][4 * tt + c] * gm[c];
+                            dz2[ob][4 * tt + c] = gy;
+                            m1 += gy;
+                            m2 += gy * xh[ob][tt][c];
+                        }
+                    }
+                }
+            }
+            if (has_ln) {
+                m1 = row_allreduce(m1) * inv_dout;
+                m2 = row_allreduce(m2) * inv_dout;
+#pragma unroll
+                for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float v = rstd * (dz2[ob][4 * tt + c] - m1 - xh[ob][tt][c] * m2);
+                            dz2[ob][4 * tt + c] = valid ? v : 0.f;
+                        }
+            }
+        }
+        // ---- dz2 rows out (for wgrad) + db2 ----
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt);
+            wave_lds_sync();
+            acc_db2[ob] += block_colsum_half(stg, lane);
+            if (p.dz2 != nullptr) {
+                float* dbase = p.dz2 + tile_row0 * p.dout + 32 * ob;
+                block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return dbase + (size_t)r * p.dout; });
+            }
+            wave_lds_sync();
+        }
+
+        // ---- dh = W2^T dz2 ; dz1 = dh * silu'(z1) ----
+        f32x16 dz1[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz1[hb][r] = 0.f;
+        if constexpr (NS > 0) {
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float xs8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) xs8[q] = dz2[ob][8 * h + q];
+                    const BfFrag<NSW> Bf = split8<NSW>(xs8);
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) {
+                        const BfFrag<NSW> A = load_afrag<NSW>(reinterpret_cast<const u32x4*>(W2t), HB, S2, hb, 2 * ob + h, lane);
+                        mma_split<NSW>(dz1[hb], A, Bf);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) mma_chunk<HB>(dz1, W2t, T2, ob * 4 + tt, acc_chunk(dz2[ob], tt), lane);
+        }
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const f32x4 z = *reinterpret_cast<const f32x4*>(zrow + 8 * (hb * 4 + tt) + 4 * hi);
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[c] = valid ? dz1[hb][4 * tt + c] * silu_grad_f(z[c]) : 0.f;
+                    dz1[hb][4 * tt + c] = v[c];
+                }
+                *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = v;
+            }
+            wave_lds_sync();
+            acc_db1[hb] += block_colsum_half(stg, lane);
+            if (p.dz1 != nullptr) {
+                float* dbase = p.dz1 + tile_row0 * p.hid + 32 * hb;
+                block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return dbase + (size_t)r * p.hid; });
+            }
+            wave_lds_sync();
+        }
+
+        // ---- dx_s = W1_s^T dz1 per source ----
+#pragma unroll
+        for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+            if (s >= p.nsrc || p.dmode[s] == 0) continue;
+            const int mode = p.dmode[s];
+            const int w = p.src[s].width;
+            const int MBs = w >> 5;   // 1 or 2
+            f32x16 dx[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dx[mb][r] = 0.f;
+            if constexpr (NS > 0) {
+                const u32x4* A1 = reinterpret_cast<const u32x4*>(W1t + w1_off[s]);
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float xs8[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) xs8[q] = dz1[hb][8 * h + q];
+                        const BfFrag<NSW> Bf = split8<NSW>(xs8);
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb)
+                            if (mb < MBs) {
+                                const BfFrag<NSW> A = load_afrag<NSW>(A1, MBs, S1, mb, 2 * hb + h, lane);
+                                mma_split<NSW>(dx[mb], A, Bf);
+                            }
+                    }
+            } else {
+                const float* A1 = W1t + w1_off[s];
+                if (MBs == 1) {
+                    f32x16 d1[1];
+                    d1[0] = dx[0];
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) mma_chunk<1>(d1, A1, T1, hb * 4 + tt, acc_chunk(dz1[hb], tt), lane);
+                    dx[0] = d1[0];
+                } else {
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) mma_chunk<2>(dx, A1, T1, hb * 4 + tt, acc_chunk(dz1[hb], tt), lane);
+                }
+            }
+            float* dbase = p.dsrc[s] + (long)b * p.dsrc_bstride[s];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                if (mb >= MBs) continue;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    f32x4 v = acc_chunk(dx[mb], tt);
+                    if (s == 0 && add_gout) v += gsave[mb < OB ? mb : 0][tt];
+                    if (s == 1 && add_gmsg) {   // msg = mlp + src1: d src1 += dmsg (re-read: rare PropagationNet path)
+                        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                        const int c0 = 8 * (mb * 4 + tt) + 4 * hi;
+                        if (grow != nullptr) g += *reinterpret_cast<const f32x4*>(grow + c0);
+                        if (garow != nullptr) g += *reinterpret_cast<const f32x4*>(garow + c0) * gscale;
+                        v += g;
+                    }
+                    if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = v;
+                }
+                wave_lds_sync();
+                if (mode == 1) {
+                    block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return dbase + (long)__shfl(sidx[s], r, 64) * w + 32 * mb; });
+                } else if (mode == 2) {
+                    float* tb = p.dsrc[s] + (tile_row0 * w) + 32 * mb;
+                    block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return tb + (size_t)r * w; });
+                } else {
+                    block_segment_reduce(stg, tl, raw_ptr, 1.f, dbase + 32 * mb, w, 32, lane);
+                }
+                wave_lds_sync();
+            }
+        }
+    }
+
+    // ---- combine the waves' column partials through LDS; one row per workgroup ----
+    if (p.vec_partials != nullptr) {
+        __syncthreads();
+        float* red = stg_all;   // kWavesPerBlock x 4 x 64 floats (fits: 8 x 32 x 36 staging)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float v1 = k < HB ? acc_db1[k < HB ? k : 0] : 0.f;
+            const float v2 = k < OB ? acc_db2[k < OB ? k : 0] : 0.f;
+            const float v3 = k < OB ? acc_dg[k < OB ? k : 0] : 0.f;
+            const float v4 = k < OB ? acc_dbt[k < OB ? k : 0] : 0.f;
+            // lane (c, half): add the two row halves, keep in lanes < 32 -> column 32 * k + c
+            const float s1 = v1 + __shfl_xor(v1, 32, 64), s2 = v2 + __shfl_xor(v2, 32, 64);
+            const float s3 = v3 + __shfl_xor(v3, 32, 64), s4 = v4 + __shfl_xor(v4, 32, 64);
+            if (lane < 32) {
+                red[(wave * 4 + 0) * 64 + 32 * k + lane] = s1;
+                red[(wave * 4 + 1) * 64 + 32 * k + lane] = s2;
+                red[(wave * 4 + 2) * 64 + 32 * k + lane] = s3;
+                red[(wave * 4 + 3) * 64 + 32 * k + lane] = s4;
+            }
+        }
+        __syncthreads();
+        if (wave < 4) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; ++w) s += red[(w * 4 + wave) * 64 + lane];
+            p.vec_partials[((size_t)blockIdx.x * 4 + wave) * p.vec_stride + lane] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // weight gradients:  C[m][n] = sum_rows A[row][m] * B[row][n]
 //   A = dz (contiguous), B = gathered concat of sources (optionally SiLU'd)
 // One workgroup (4 waves) = one partial; each wave owns up to NBW 32x32 blocks.
@@ -1449,6 +1793,15 @@ size_t bwd_lds_bytes(const nlam_mlp_bwd_t* p, int HB, int OB) {
     return f * sizeof(float);
 }
 
+size_t bwd_fast_lds_bytes(const nlam_mlp_bwd_t* p, int HB, int OB, int NS) {
+    const int DPH = HB * 32, OP = OB * 32;
+    size_t wf = (size_t)DPH * OP;
+    for (int s = 0; s < p->nsrc; ++s)
+        if (p->dmode[s] != 0) wf += (size_t)p->src[s].width * DPH;
+    if (NS > 0) wf = wf * NS / 2;
+    return (wf + OP + (size_t)kWavesPerBlock * 32 * kStgStride) * sizeof(float);
+}
+
 constexpr size_t kMaxLds = 160 * 1024;
 
 // Raise a kernel's dynamic-LDS limit once (and only upward): the attribute call is not a
@@ -1786,6 +2139,32 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
     }
     const int blocks = grid_blocks((long)p->ntiles * p->batch);
     const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
+    bool fast = (p->hid % 32 == 0) && (p->dout % 32 == 0);
+    for (int s = 0; s < p->nsrc; ++s)
+        if (p->dmode[s] != 0) fast = fast && (p->src[s].width == 32 || p->src[s].width == 64);
+    if ((p->flags & NLAM_F_ADD_SRC0) && p->dmode[0] != 0 && p->src[0].width != p->dout) fast = false;
+    if (fast) {
+        const int ns = (int)((p->flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
+#define NLAM_LAUNCH_BWDF1(HB_, OB_, NS_)                                                                            \
+    do {                                                                                                            \
+        const size_t lds = bwd_fast_lds_bytes(p, HB_, OB_, NS_);                                                    \
+        int rc = set_lds(mlp_bwd_fast_kernel<HB_, OB_, NS_>, lds);                                                  \
+        if (rc != 0) return rc;                                                                                     \
+        hipLaunchKernelGGL((mlp_bwd_fast_kernel<HB_, OB_, NS_>), dim3(blocks), dim3(kBlockThreads), lds, stream, *p); \
+    } while (0)
+#define NLAM_LAUNCH_BWDF(HB_, OB_)                     \
+    do {                                               \
+        if (ns == 3) NLAM_LAUNCH_BWDF1(HB_, OB_, 3);      \
+        else if (ns == 2) NLAM_LAUNCH_BWDF1(HB_, OB_, 2); \
+        else if (ns == 1) NLAM_LAUNCH_BWDF1(HB_, OB_, 1); \
+        else NLAM_LAUNCH_BWDF1(HB_, OB_, 0);              \
+    } while (0)
+        if (HB == 1 && OB == 1) NLAM_LAUNCH_BWDF(1, 1);
+        else if (HB == 2 && OB == 1) NLAM_LAUNCH_BWDF(2, 1);
+        else if (HB == 1 && OB == 2) NLAM_LAUNCH_BWDF(1, 2);
+        else NLAM_LAUNCH_BWDF(2, 2);
+        return (int32_t)hipGetLastError();
+    }
     if (HB == 1 && OB == 1) NLAM_LAUNCH_BWD(1, 1);
     else if (HB == 2 && OB == 1) NLAM_LAUNCH_BWD(2, 1);
     else if (HB == 1 && OB == 2) NLAM_LAUNCH_BWD(1, 2);

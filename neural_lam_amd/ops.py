@@ -265,7 +265,7 @@ class FusedMLPFunction(torch.autograd.Function):
         p.nsrc, p.batch, p.rows, p.ntiles = nsrc, B, rows, ntiles
         p.tiles = _ptr(geom.tiles)
         p.W1, p.W2, p.ln_w = _ptr(W1), _ptr(W2), _ptr(ln_w) if ctx.has_ln else None
-        p.hid, p.dout, p.flags, p.nseg_total = hid, dout, geom.flags, geom.nseg_total
+        p.hid, p.dout, p.flags, p.nseg_total = hid, dout, geom.flags | _mm_flags(), geom.nseg_total
         if g_out is not None:
             p.g_out, p.out_idx, p.out_bstride = _ptr(g_out), _ptr(geom.out_idx), g_out.shape[1] * dout
         if g_aggr is not None:
