@@ -380,6 +380,39 @@ __device__ __forceinline__ void mma_split(f32x16& acc, const BfFrag<NS>& A, cons
         for (int pa = 0; pa <= ord; ++pa) acc = MFMA_BF16(A.t[pa], B.t[ord - pa], acc);
 }
 
+// acc[blk] += sum_{p+q < NS} A_p(blk) B_q for NB blocks sharing one B fragment.
+//  * block index innermost: consecutive MFMAs go to different accumulators.  A chain of
+//    dependent MFMAs on ONE accumulator is issued ahead of its execution and fetches its A/B
+//    registers late; VALU code that re-uses those registers for the next fragment then
+//    corrupted rows 16..31 of a tile now and again (run-to-run differences of bf16-level size,
+//    found with tools/determinism_check*.py).  With a lone accumulator every MFMA is followed
+//    by 32 wait states instead.
+//  * all A terms of a step are fetched into distinct registers before its first MFMA.
+template <int NS, int NB>
+__device__ __forceinline__ void mma_split_lds(f32x16 (&acc)[NB], const u32x4* Wp, int MB, int S, int st, int lane,
+                                              const BfFrag<NS>& B) {
+    // every A term of the step in its own registers before the first MFMA: nothing an in-flight MFMA reads is
+    // rewritten until the whole group has been issued.  NB is exact (no run-time predicate on the MFMAs: a
+    // conditional accumulator update makes the compiler copy the 16-register accumulators around).
+    u32x4 a[NS][NB];
+#pragma unroll
+    for (int pa = 0; pa < NS; ++pa)
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) a[pa][blk] = Wp[(((size_t)pa * MB + blk) * S + st) * 64 + lane];
+#pragma unroll
+    for (int ord = NS - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int pa = 0; pa <= ord; ++pa)
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                acc[blk] = MFMA_BF16(a[pa][blk], B.t[ord - pa], acc[blk]);
+                if (NB == 1) {
+                    asm volatile("s_nop 15");
+                    asm volatile("s_nop 15");
+                }
+            }
+}
+
 // Stage an (M x K) weight slice as split-bf16 A fragments:
 //   dst[((term * MB + mb) * S + s0 + s) * 64 + lane] (16 B) = slots q = 0..7 of row mb*32 + (lane & 31),
 //   k = perm2 ? 32*(s>>1) + 16*(s&1) + (q&3) + 8*(q>>2) + 4*hi : 16*s + 8*hi + q ;  A[m][k] = W[m*ldm + k]
@@ -572,11 +605,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
                     const float xs8[8] = {x[2 * h][0], x[2 * h][1], x[2 * h][2], x[2 * h][3],
                                           x[2 * h + 1][0], x[2 * h + 1][1], x[2 * h + 1][2], x[2 * h + 1][3]};
                     const BfFrag<NSW> B = split8<NSW>(xs8);
-#pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) {
-                        const BfFrag<NSW> A = load_afrag<NSW>(W1s, HB, S1, hb, 2 * u + h, lane);
-                        mma_split<NSW>(acc1[hb], A, B);
-                    }
+                    mma_split_lds<NSW, HB>(acc1, W1s, HB, S1, 2 * u + h, lane, B);
                 }
             };
             int nunits = 0;
@@ -665,11 +694,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
 #pragma unroll
                     for (int q = 0; q < 8; ++q) xs8[q] = acc1[hb][8 * h + q];
                     const BfFrag<NSW> B = split8<NSW>(xs8);
-#pragma unroll
-                    for (int ob = 0; ob < OB; ++ob) {
-                        const BfFrag<NSW> A = load_afrag<NSW>(W2s, OB, S2, ob, 2 * hb + h, lane);
-                        mma_split<NSW>(acc2[ob], A, B);
-                    }
+                    mma_split_lds<NSW, OB>(acc2, W2s, OB, S2, 2 * hb + h, lane, B);
                 }
         } else {
 #pragma unroll
@@ -1145,6 +1170,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
     }
     float* gml = W1t + w1_floats;                         // OP
     float* stg_all = gml + OP;                            // kWavesPerBlock x 32 x kStgStride
+    float* colacc_all = stg_all + (size_t)kWavesPerBlock * 32 * kStgStride;   // kWavesPerBlock x 8 x 64 column accumulators
     if constexpr (NS > 0) {
         // A[m = hidden][k = out (slot-permuted)] = W2[k][m]
         stage_split<NSW>(reinterpret_cast<u32x4*>(W2t), S2, 0, p.W2, 1, p.hid, HB, p.dout, true, p.hid);
@@ -1176,12 +1202,12 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
     const bool add_gout = (p.flags & NLAM_F_ADD_SRC0) != 0 && p.g_out != nullptr && p.dmode[0] != 0;
     const bool add_gmsg = (p.flags & NLAM_F_ADD_SRC1) != 0 && p.nsrc > 1 && p.dmode[1] != 0;
 
-    // per-lane column accumulators: lane -> (column lane & 31, row half lane >> 5) of each 32-column block
-    float acc_db1[HB], acc_db2[OB], acc_dg[OB], acc_dbt[OB];
+    // per-lane column accumulators, lane -> (column lane & 31, row half lane >> 5) of each 32-column block; they
+    // live in LDS (8 per lane: db1, db2, dgamma, dbeta x 2 blocks) because the kernel sits at the 256-VGPR limit
+    float* colacc = colacc_all + (size_t)wave * 8 * 64 + lane;
+    enum { kDb1 = 0, kDb2 = 2, kDg = 4, kDbt = 6 };
 #pragma unroll
-    for (int k = 0; k < HB; ++k) acc_db1[k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < OB; ++k) acc_db2[k] = acc_dg[k] = acc_dbt[k] = 0.f;
+    for (int k = 0; k < 8; ++k) colacc[k * 64] = 0.f;
 
     const long total_tiles = (long)p.ntiles * p.batch;
     for (long gt = (long)blockIdx.x * kWavesPerBlock + wave; gt < total_tiles; gt += (long)gridDim.x * kWavesPerBlock) {
@@ -1216,23 +1242,19 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
 
         // ---- dmsg (C-layout chunks), LayerNorm backward ----
         f32x16 dz2[OB];
-        f32x4 gsave[OB][4];   // g_out chunks for the edge residual (out = msg + src0)
         {
             float m1 = 0.f, m2 = 0.f;
-            f32x4 xh[OB][4];
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob) {
+                f32x4 xh[4];   // xhat is read twice (here and after the row sums) instead of living in 16*OB VGPRs
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
                     f32x4 g = {0.f, 0.f, 0.f, 0.f};
-                    if (grow != nullptr) {
-                        g = *reinterpret_cast<const f32x4*>(grow + c0);
-                        gsave[ob][tt] = g;
-                    }
+                    if (grow != nullptr) g = *reinterpret_cast<const f32x4*>(grow + c0);
                     if (garow != nullptr) g += *reinterpret_cast<const f32x4*>(garow + c0) * gscale;
                     if (!valid) g = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (has_ln) xh[ob][tt] = *reinterpret_cast<const f32x4*>(xrow + c0);
+                    if (has_ln) xh[tt] = *reinterpret_cast<const f32x4*>(xrow + c0);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) dz2[ob][4 * tt + c] = g[c];
                 }
@@ -1241,13 +1263,13 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt);
                     wave_lds_sync();
-                    acc_dbt[ob] += block_colsum_half(stg, lane);
+                    colacc[(kDbt + ob) * 64] += block_colsum_half(stg, lane);
                     wave_lds_sync();
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt)
-                        *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt) * xh[ob][tt];
+                        *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt) * xh[tt];
                     wave_lds_sync();
-                    acc_dg[ob] += block_colsum_half(stg, lane);
+                    colacc[(kDg + ob) * 64] += block_colsum_half(stg, lane);
                     wave_lds_sync();
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
@@ -1257,7 +1279,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
                             const float gy = dz2[ob][4 * tt + c] * gm[c];
                             dz2[ob][4 * tt + c] = gy;
                             m1 += gy;
-                            m2 += gy * xh[ob][tt][c];
+                            m2 += gy * xh[tt][c];
                         }
                     }
                 }
@@ -1268,12 +1290,14 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
 #pragma unroll
                 for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const f32x4 xh = *reinterpret_cast<const f32x4*>(xrow + 8 * (ob * 4 + tt) + 4 * hi);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const float v = rstd * (dz2[ob][4 * tt + c] - m1 - xh[ob][tt][c] * m2);
+                            const float v = rstd * (dz2[ob][4 * tt + c] - m1 - xh[c] * m2);
                             dz2[ob][4 * tt + c] = valid ? v : 0.f;
                         }
+                    }
             }
         }
         // ---- dz2 rows out (for wgrad) + db2 ----
@@ -1282,7 +1306,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt);
             wave_lds_sync();
-            acc_db2[ob] += block_colsum_half(stg, lane);
+            colacc[(kDb2 + ob) * 64] += block_colsum_half(stg, lane);
             if (p.dz2 != nullptr) {
                 float* dbase = p.dz2 + tile_row0 * p.dout + 32 * ob;
                 block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return dbase + (size_t)r * p.dout; });
@@ -1305,11 +1329,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
 #pragma unroll
                     for (int q = 0; q < 8; ++q) xs8[q] = dz2[ob][8 * h + q];
                     const BfFrag<NSW> Bf = split8<NSW>(xs8);
-#pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) {
-                        const BfFrag<NSW> A = load_afrag<NSW>(reinterpret_cast<const u32x4*>(W2t), HB, S2, hb, 2 * ob + h, lane);
-                        mma_split<NSW>(dz1[hb], A, Bf);
-                    }
+                    mma_split_lds<NSW, HB>(dz1, reinterpret_cast<const u32x4*>(W2t), HB, S2, 2 * ob + h, lane, Bf);
                 }
         } else {
 #pragma unroll
@@ -1331,7 +1351,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
                 *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = v;
             }
             wave_lds_sync();
-            acc_db1[hb] += block_colsum_half(stg, lane);
+            colacc[(kDb1 + hb) * 64] += block_colsum_half(stg, lane);
             if (p.dz1 != nullptr) {
                 float* dbase = p.dz1 + tile_row0 * p.hid + 32 * hb;
                 block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return dbase + (size_t)r * p.hid; });
@@ -1340,6 +1360,20 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
         }
 
         // ---- dx_s = W1_s^T dz1 per source ----
+        // split-bf16: the B fragments of dz1 are the same for every source -- convert once
+        BfFrag<NSW> bz[NS > 0 ? HB * 2 : 1];
+        if constexpr (NS > 0) {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float xs8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) xs8[q] = dz1[hb][8 * h + q];
+                    bz[2 * hb + h] = split8<NSW>(xs8);
+                    __builtin_amdgcn_sched_barrier(0);   // one fragment at a time (the scheduler otherwise interleaves all conversions: VGPRs)
+                }
+        }
 #pragma unroll
         for (int s = 0; s < NLAM_MAX_SRC; ++s) {
             if (s >= p.nsrc || p.dmode[s] == 0) continue;
@@ -1353,21 +1387,16 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
                 for (int r = 0; r < 16; ++r) dx[mb][r] = 0.f;
             if constexpr (NS > 0) {
                 const u32x4* A1 = reinterpret_cast<const u32x4*>(W1t + w1_off[s]);
+                if (MBs == 2) {
 #pragma unroll
-                for (int hb = 0; hb < HB; ++hb)
+                    for (int st = 0; st < HB * 2; ++st) mma_split_lds<NSW, 2>(dx, A1, 2, S1, st, lane, bz[st]);
+                } else {
+                    f32x16 d1[1];
+                    d1[0] = dx[0];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        float xs8[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) xs8[q] = dz1[hb][8 * h + q];
-                        const BfFrag<NSW> Bf = split8<NSW>(xs8);
-#pragma unroll
-                        for (int mb = 0; mb < 2; ++mb)
-                            if (mb < MBs) {
-                                const BfFrag<NSW> A = load_afrag<NSW>(A1, MBs, S1, mb, 2 * hb + h, lane);
-                                mma_split<NSW>(dx[mb], A, Bf);
-                            }
-                    }
+                    for (int st = 0; st < HB * 2; ++st) mma_split_lds<NSW, 1>(d1, A1, 1, S1, st, lane, bz[st]);
+                    dx[0] = d1[0];
+                }
             } else {
                 const float* A1 = W1t + w1_off[s];
                 if (MBs == 1) {
@@ -1392,7 +1421,8 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     f32x4 v = acc_chunk(dx[mb], tt);
-                    if (s == 0 && add_gout) v += gsave[mb < OB ? mb : 0][tt];
+                    if (s == 0 && add_gout)   // out = msg + src0: d src0 += g_out (L2-resident re-read; keeping it live costs 32 VGPRs)
+                        v += *reinterpret_cast<const f32x4*>(grow + 8 * (mb * 4 + tt) + 4 * hi);
                     if (s == 1 && add_gmsg) {   // msg = mlp + src1: d src1 += dmsg (re-read: rare PropagationNet path)
                         f32x4 g = {0.f, 0.f, 0.f, 0.f};
                         const int c0 = 8 * (mb * 4 + tt) + 4 * hi;
@@ -1423,10 +1453,10 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
         float* red = stg_all;   // kWavesPerBlock x 4 x 64 floats (fits: 8 x 32 x 36 staging)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const float v1 = k < HB ? acc_db1[k < HB ? k : 0] : 0.f;
-            const float v2 = k < OB ? acc_db2[k < OB ? k : 0] : 0.f;
-            const float v3 = k < OB ? acc_dg[k < OB ? k : 0] : 0.f;
-            const float v4 = k < OB ? acc_dbt[k < OB ? k : 0] : 0.f;
+            const float v1 = k < HB ? colacc[(kDb1 + k) * 64] : 0.f;
+            const float v2 = k < OB ? colacc[(kDb2 + k) * 64] : 0.f;
+            const float v3 = k < OB ? colacc[(kDg + k) * 64] : 0.f;
+            const float v4 = k < OB ? colacc[(kDbt + k) * 64] : 0.f;
             // lane (c, half): add the two row halves, keep in lanes < 32 -> column 32 * k + c
             const float s1 = v1 + __shfl_xor(v1, 32, 64), s2 = v2 + __shfl_xor(v2, 32, 64);
             const float s3 = v3 + __shfl_xor(v3, 32, 64), s4 = v4 + __shfl_xor(v4, 32, 64);
@@ -1466,7 +1496,7 @@ __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f}
 // per chunk.  MFMA operands are k-major b32 reads of the row-major tiles
 // (consecutive lanes = consecutive columns: conflict-free, the two half-waves read
 // adjacent rows).
-template <int NBW>
+template <int NBW, bool SILU>
 __global__ __launch_bounds__(kWgradThreads) void wgrad_dma_kernel(const nlam_wgrad_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ntile = 1 + p.nsrc;
@@ -1559,13 +1589,20 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_dma_kernel(const nlam_wgr
             if (blk_mb[q] >= 0) {
                 const float* Bt = smem + (size_t)(buf * ntile + blk_tile[q]) * kWgTile;
                 const int ac = blk_mb[q] * 32 + i, bc = blk_nb[q] * 32 + i;
+                // all operands of the chunk first (one lgkmcnt wait), then 16 back-to-back MFMAs;
+                // SiLU is a compile-time variant: as a run-time flag it was evaluated (and discarded) for every MFMA
+                float a[kWgradRows / 2], bv[kWgradRows / 2];
 #pragma unroll
                 for (int ks = 0; ks < kWgradRows / 2; ++ks) {
-                    const float a = At[(2 * ks + hi) * 64 + ac];
-                    float bv = Bt[(2 * ks + hi) * 64 + bc];
-                    if (p.flags & NLAM_F_SILU_B) bv = silu_f(bv);
-                    acc[q] = MFMA32(a, bv, acc[q]);
+                    a[ks] = At[(2 * ks + hi) * 64 + ac];
+                    bv[ks] = Bt[(2 * ks + hi) * 64 + bc];
                 }
+                if constexpr (SILU) {
+#pragma unroll
+                    for (int ks = 0; ks < kWgradRows / 2; ++ks) bv[ks] = silu_f(bv[ks]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < kWgradRows / 2; ++ks) acc[q] = MFMA32(a[ks], bv[ks], acc[q]);
             }
         }
         buf ^= 1;
@@ -1799,7 +1836,7 @@ size_t bwd_fast_lds_bytes(const nlam_mlp_bwd_t* p, int HB, int OB, int NS) {
     for (int s = 0; s < p->nsrc; ++s)
         if (p->dmode[s] != 0) wf += (size_t)p->src[s].width * DPH;
     if (NS > 0) wf = wf * NS / 2;
-    return (wf + OP + (size_t)kWavesPerBlock * 32 * kStgStride) * sizeof(float);
+    return (wf + OP + (size_t)kWavesPerBlock * 32 * kStgStride + (size_t)kWavesPerBlock * 8 * 64) * sizeof(float);
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
@@ -2184,20 +2221,31 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     for (int s = 0; s < p->nsrc; ++s) nb_total += (p->src[s].width + 31) / 32;
     if (wgrad_is_wide(p)) {
         const size_t lds = (size_t)4 * kWWTile * sizeof(float);
-        int rc = set_lds(wgrad_wide_kernel, lds);
-        if (rc != 0) return rc;
-        hipLaunchKernelGGL(wgrad_wide_kernel, dim3(p->nparts, wgrad_windows(p)), dim3(kWgradThreads), lds, stream, *p);
+        if (p->flags & NLAM_F_SILU_B) {
+            int rc = set_lds(wgrad_wide_kernel<true>, lds);
+            if (rc != 0) return rc;
+            hipLaunchKernelGGL(wgrad_wide_kernel<true>, dim3(p->nparts, wgrad_windows(p)), dim3(kWgradThreads), lds, stream, *p);
+        } else {
+            int rc = set_lds(wgrad_wide_kernel<false>, lds);
+            if (rc != 0) return rc;
+            hipLaunchKernelGGL(wgrad_wide_kernel<false>, dim3(p->nparts, wgrad_windows(p)), dim3(kWgradThreads), lds, stream, *p);
+        }
         return (int32_t)hipGetLastError();
     }
     if (dma) {
         const int nblocks = ((p->m + 31) / 32) * nb_total;
         const int nbw = (nblocks + 3) / 4;
         const size_t lds = (size_t)2 * (1 + p->nsrc) * kWgTile * sizeof(float);
-#define NLAM_LAUNCH_WGD(N_)                                                                               \
-    do {                                                                                                  \
-        int rc = set_lds(wgrad_dma_kernel<N_>, lds);                                                      \
-        if (rc != 0) return rc;                                                                           \
-        hipLaunchKernelGGL((wgrad_dma_kernel<N_>), dim3(p->nparts), dim3(kWgradThreads), lds, stream, *p); \
+#define NLAM_LAUNCH_WGD1(N_, S_)                                                                              \
+    do {                                                                                                      \
+        int rc = set_lds(wgrad_dma_kernel<N_, S_>, lds);                                                      \
+        if (rc != 0) return rc;                                                                               \
+        hipLaunchKernelGGL((wgrad_dma_kernel<N_, S_>), dim3(p->nparts), dim3(kWgradThreads), lds, stream, *p); \
+    } while (0)
+#define NLAM_LAUNCH_WGD(N_)                                        \
+    do {                                                           \
+        if (p->flags & NLAM_F_SILU_B) NLAM_LAUNCH_WGD1(N_, true);  \
+        else NLAM_LAUNCH_WGD1(N_, false);                          \
     } while (0)
         if (nbw <= 1) NLAM_LAUNCH_WGD(1);
         else if (nbw <= 2) NLAM_LAUNCH_WGD(2);

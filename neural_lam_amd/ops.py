@@ -25,7 +25,7 @@ def _vec_stride(hid: int, dout: int) -> int:
 # chains), "bf16x3" / "bf16x2" = operands split into 3 / 2 bf16 terms on the bf16 matrix cores with fp32
 # accumulation (fp32-class / ~2^-16 product error), "bf16" = plain bf16 operands.
 _MM_FLAGS = {"f32": 0, "bf16": 1 << 8, "bf16x2": 2 << 8, "bf16x3": 3 << 8}
-MATMUL_MODE = os.environ.get("NLAM_MATMUL", "f32")
+MATMUL_MODE = os.environ.get("NLAM_MATMUL", "bf16x3")
 
 
 def set_matmul_mode(mode: str):
