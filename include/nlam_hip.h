@@ -219,6 +219,18 @@ typedef struct {
 } nlam_reduce_jobs_t;
 int32_t nlam_reduce_jobs(const nlam_reduce_jobs_t* jobs, void* hip_stream);
 
+/* Training loss of ForecasterModule.training_step (models/module.py:463-510) with metrics.wmse /
+ * mask_and_reduce_metric (metrics.py:37-137) for a per-variable std:
+ *   loss = scale * sum_{row, v} row_weight[row % nodes] * inv_var[v] * (pred - target)^2,
+ * row_weight = interior mask / #interior nodes, scale = 1 / (batch * ar_steps).  The forward writes one
+ * partial per block (nparts blocks; finish with nlam_reduce_partials, fixed order); the backward takes the
+ * upstream scalar gradient from device memory. */
+int32_t nlam_wmse_fwd(const float* pred, const float* target, const float* inv_var, const float* row_weight, int64_t rows,
+                      int32_t nodes, int32_t nvars, float scale, float* partials, int32_t nparts, void* hip_stream);
+int32_t nlam_wmse_bwd(const float* pred, const float* target, const float* inv_var, const float* row_weight,
+                      const float* gscalar, int64_t rows, int32_t nodes, int32_t nvars, float scale, float* dpred,
+                      void* hip_stream);
+
 /* decoupled-weight-decay Adam on flat buffers; step_count is the 1-based step */
 int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step_count,

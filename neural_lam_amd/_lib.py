@@ -33,6 +33,8 @@ EXPORTS = [
     "nlam_segment_sum",
     "nlam_reduce_partials",
     "nlam_reduce_jobs",
+    "nlam_wmse_fwd",
+    "nlam_wmse_bwd",
     "nlam_adamw_step",
 ]
 
@@ -202,6 +204,10 @@ def load():
     lib.nlam_reduce_partials.restype = i32
     lib.nlam_reduce_jobs.argtypes = [C.POINTER(ReduceJobs), vp]
     lib.nlam_reduce_jobs.restype = i32
+    lib.nlam_wmse_fwd.argtypes = [vp, vp, vp, vp, i64, i32, i32, f32, vp, i32, vp]
+    lib.nlam_wmse_fwd.restype = i32
+    lib.nlam_wmse_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, f32, vp, vp]
+    lib.nlam_wmse_bwd.restype = i32
     lib.nlam_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
     lib.nlam_adamw_step.restype = i32
     if lib.nlam_abi_version() != 2:

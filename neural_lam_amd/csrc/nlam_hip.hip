@@ -1547,7 +1547,23 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_dma_kernel(const nlam_wgr
     const long total_chunks = (long)chunks_per_batch * p.batch;
     const int lrow = lane >> 4, lcol = (lane & 15) << 2;  // lane -> (row within the 4-row group, first column)
 
-    auto issue = [&](long ch, int buf) {
+    // gather indices of a chunk (one per fetched row and source); loaded one chunk ahead of the DMA that uses
+    // them, so the index -> row dependent-load chain never sits in front of the MFMAs
+    auto load_idx = [&](long ch, int(&ix)[2][NLAM_MAX_SRC]) {
+        const int r0 = (int)(ch % chunks_per_batch) * kWgradRows;
+        const int nr = min(kWgradRows, p.rows - r0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int r = wave * 8 + g * 4 + lrow;
+            const int prow = r0 + (r < nr ? r : 0);
+#pragma unroll
+            for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+                ix[g][s] = prow;
+                if (s < p.nsrc && r < nr && p.src[s].idx != nullptr) ix[g][s] = p.src[s].idx[prow];
+            }
+        }
+    };
+    auto issue = [&](long ch, int buf, const int(&ix)[2][NLAM_MAX_SRC]) {
         const int b = (int)(ch / chunks_per_batch);
         const int r0 = (int)(ch % chunks_per_batch) * kWgradRows;
         const int nr = min(kWgradRows, p.rows - r0);
@@ -1563,13 +1579,12 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_dma_kernel(const nlam_wgr
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             }
-            for (int s = 0; s < p.nsrc; ++s) {
+#pragma unroll
+            for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+                if (s >= p.nsrc) continue;
                 const nlam_src_t S = p.src[s];
                 const float* src = g_zero16;
-                if (rv && lcol < S.width) {
-                    const long ridx = S.idx != nullptr ? S.idx[prow] : prow;
-                    src = S.ptr + (long)b * S.bstride + ridx * S.width + lcol;
-                }
+                if (rv && lcol < S.width) src = S.ptr + (long)b * S.bstride + (long)ix[g][s] * S.width + lcol;
                 float* dst = smem + ((size_t)(buf * ntile + 1 + s) * kWgTile) + (wave * 8 + g * 4) * 64;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -1579,10 +1594,16 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_dma_kernel(const nlam_wgr
 
     long ch = blockIdx.x;
     int buf = 0;
-    if (ch < total_chunks) issue(ch, 0);
+    int ix[2][NLAM_MAX_SRC];
+    if (ch < total_chunks) {
+        load_idx(ch, ix);
+        issue(ch, 0, ix);
+    }
+    if (ch + gridDim.x < total_chunks) load_idx(ch + gridDim.x, ix);
     for (; ch < total_chunks; ch += gridDim.x) {
         __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)); everyone is done reading buf ^ 1
-        if (ch + gridDim.x < total_chunks) issue(ch + gridDim.x, buf ^ 1);
+        if (ch + gridDim.x < total_chunks) issue(ch + gridDim.x, buf ^ 1, ix);
+        if (ch + 2 * (long)gridDim.x < total_chunks) load_idx(ch + 2 * (long)gridDim.x, ix);
         const float* At = smem + (size_t)(buf * ntile) * kWgTile;
 #pragma unroll
         for (int q = 0; q < NBW; ++q) {
@@ -1787,6 +1808,40 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(const nlam_reduce_jobs
             jb.out[idx] = jb.accumulate ? jb.out[idx] + t : t;
         }
         __syncthreads();
+    }
+}
+
+// masked, weighted MSE (metrics.wmse + mask_and_reduce_metric + the batch / time means of
+// training_step) as one HBM-bound pass: partial[block] = sum rw[row % nodes] * inv_var[v] * (pred - target)^2
+__global__ __launch_bounds__(256) void wmse_fwd_kernel(const float* pred, const float* target, const float* inv_var,
+                                                       const float* row_weight, long total, int nodes, int nvars, float scale,
+                                                       float* partials) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / nvars;
+        const int v = (int)(e - row * nvars);
+        const float w = row_weight[row % nodes];
+        if (w != 0.f) {
+            const float d = pred[e] - target[e];
+            s += w * inv_var[v] * d * d;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+}
+
+__global__ void wmse_bwd_kernel(const float* pred, const float* target, const float* inv_var, const float* row_weight,
+                                const float* gscalar, long total, int nodes, int nvars, float scale, float* dpred) {
+    const float g = 2.f * scale * gscalar[0];
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / nvars;
+        const int v = (int)(e - row * nvars);
+        const float w = row_weight[row % nodes];
+        dpred[e] = w != 0.f ? g * w * inv_var[v] * (pred[e] - target[e]) : 0.f;
     }
 }
 
@@ -2304,6 +2359,28 @@ int32_t nlam_reduce_jobs(const nlam_reduce_jobs_t* jobs, void* hip_stream) {
     int blocks = (nmax + 63) / 64;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(reduce_jobs_kernel, dim3(blocks, jobs->njobs), dim3(256), 0, (hipStream_t)hip_stream, *jobs);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_wmse_fwd(const float* pred, const float* target, const float* inv_var, const float* row_weight, int64_t rows,
+                      int32_t nodes, int32_t nvars, float scale, float* partials, int32_t nparts, void* hip_stream) {
+    if (pred == nullptr || target == nullptr || inv_var == nullptr || row_weight == nullptr || partials == nullptr) return NLAM_EINVAL;
+    if (rows < 1 || nodes < 1 || nvars < 1 || nparts < 1) return NLAM_EINVAL;
+    hipLaunchKernelGGL(wmse_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)hip_stream, pred, target, inv_var, row_weight,
+                       (long)rows * nvars, nodes, nvars, scale, partials);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_wmse_bwd(const float* pred, const float* target, const float* inv_var, const float* row_weight, const float* gscalar,
+                      int64_t rows, int32_t nodes, int32_t nvars, float scale, float* dpred, void* hip_stream) {
+    if (pred == nullptr || target == nullptr || inv_var == nullptr || row_weight == nullptr || gscalar == nullptr || dpred == nullptr)
+        return NLAM_EINVAL;
+    if (rows < 1 || nodes < 1 || nvars < 1) return NLAM_EINVAL;
+    const long total = (long)rows * nvars;
+    long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wmse_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, pred, target, inv_var, row_weight,
+                       gscalar, total, nodes, nvars, scale, dpred);
     return (int32_t)hipGetLastError();
 }
 

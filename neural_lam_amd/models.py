@@ -508,6 +508,8 @@ class ForecasterStep(nn.Module):
         bm = torch.tensor(datastore.boundary_mask.values, dtype=torch.float32)
         self.register_buffer("interior_mask_bool", (1.0 - bm).to(torch.bool), persistent=False)
         self.register_buffer("interior_index", torch.nonzero(1.0 - bm > 0.5).reshape(-1), persistent=False)
+        interior = (1.0 - bm > 0.5).to(torch.float32)
+        self.register_buffer("interior_weight", interior / interior.sum().clamp(min=1.0), persistent=False)
         st = datastore.get_standardization_dataarray("state")
         eps = torch.finfo(torch.float32).eps
         if not forecaster.predicts_std:
@@ -543,6 +545,12 @@ class ForecasterStep(nn.Module):
         if standardize:
             init_states, target_states, forcing = self.standardize(init_states, target_states, forcing)
         prediction, pred_std = self.forecaster(init_states, forcing, target_states)
+        if pred_std is None and prediction.is_cuda:
+            # fixed per-variable std: wmse + interior mask + the grid / batch / step means in one HBM-bound kernel pair
+            from .ops import WmseLossFunction
+
+            inv_var = 1.0 / (self.per_var_std * self.per_var_std)
+            return prediction, WmseLossFunction.apply(prediction, target_states, inv_var, self.interior_weight)
         if pred_std is None:
             pred_std = self.per_var_std
         time_step_loss = torch.mean(wmse(prediction, target_states, pred_std, mask=self.interior_index), dim=0)

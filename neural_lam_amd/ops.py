@@ -390,6 +390,41 @@ class FusedMLPFunction(torch.autograd.Function):
         return (None, dW1, db1, dW2, db2, dg, dbt, *grads_src)
 
 
+class WmseLossFunction(torch.autograd.Function):
+    """``mean_t mean_b wmse(pred, target, per_var_std, interior mask)`` as one pass (nlam_wmse_fwd / _bwd).
+
+    forward(pred (B, T, N, V), target, inv_var (V), row_weight (N) = interior / #interior) -> scalar
+    """
+
+    @staticmethod
+    def forward(ctx, pred, target, inv_var, row_weight):
+        lib = L.load()
+        _require_gpu(pred, target, inv_var, row_weight)
+        B, T, N, V = pred.shape
+        predc, targc = pred.contiguous(), target.contiguous()
+        nparts = 512
+        partials = torch.empty((nparts,), device=pred.device, dtype=torch.float32)
+        scale = 1.0 / (B * T)
+        L.check(lib.nlam_wmse_fwd(_ptr(predc), _ptr(targc), _ptr(inv_var), _ptr(row_weight), B * T * N, N, V, scale,
+                                  _ptr(partials), nparts, _stream()), "nlam_wmse_fwd")
+        out = torch.empty((), device=pred.device, dtype=torch.float32)
+        L.check(lib.nlam_reduce_partials(_ptr(partials), nparts, 1, 1, _ptr(out), 0, _stream()), "nlam_reduce_partials")
+        ctx.save_for_backward(predc, targc, inv_var, row_weight)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        pred, target, inv_var, row_weight = ctx.saved_tensors
+        B, T, N, V = pred.shape
+        dpred = torch.empty_like(pred)
+        gc = g.contiguous().to(torch.float32)
+        L.check(lib.nlam_wmse_bwd(_ptr(pred), _ptr(target), _ptr(inv_var), _ptr(row_weight), _ptr(gc), B * T * N, N, V,
+                                  ctx.scale, _ptr(dpred), _stream()), "nlam_wmse_bwd")
+        return dpred, None, None, None
+
+
 class AdamWFlat:
     """torch.optim.AdamW(lr, betas=(0.9, 0.95)) semantics (models/module.py:293-304)
     on one flat fp32 buffer: a single HBM-bound kernel per step."""
