@@ -13,11 +13,19 @@ synthetic batch per GPU: standardised inputs -> AR rollout
 multiscale mesh on the synthetic MEPS-shaped 238x268 grid, 17 state variables,
 hidden_dim 64, 4 processor layers, batch 1 per GPU, ar_steps 1, fp32.
 
+Launch mode: zero-grad + forward + loss + backward are captured once into a HIP
+graph and replayed per step (the gradient all-reduce for N > 1 and the fused AdamW
+run after each replay); ``--eager`` issues every launch from Python instead.
+
 Extra objects on the JSON line:
-  roofline      the dominant kernel = mlp_fwd_kernel<2,2> on the m2g edge set
-                (255 136 edges): algorithmic FLOPs 8*E*d^2 / measured launch time
-                (HIP events on the launch stream, averaged over the K timed steps
-                of a second, instrumented pass) vs. the fp32-MFMA peak.
+  roofline      the dominant kernel = the fused edge kernel (gather + edge MLP +
+                LayerNorm + aggregation) on the m2g edge set (255 136 edges):
+                algorithmic FLOPs 8*E*d^2 / measured launch time (HIP events on the
+                launch stream, averaged over the K timed steps of a second,
+                instrumented eager pass) vs. the fp32-MFMA peak of the dtype; the
+                algorithmic HBM bytes/launch and the PMC-measured HBM traffic of the
+                same kernel (profiles/round1/pmc_traffic.json, written by
+                tools/pmc_collect.py) are reported next to it.
   cpu_baseline  the oracle (pure-torch restatement of the reference) timed on this
                 box's host cores on the same workload, bounded to a few steps.
 """
@@ -211,22 +219,40 @@ def main():
         recs = ops.PROFILE.collect()
         ops.PROFILE.reset(enabled=False)
         E = int(raw["m2g_edge_index"].shape[1])
+        Nr = int(raw["m2g_edge_index"][1].max()) + 1
         d = cfg["d"]
         key = ("mlp_fwd", E * cfg["B"], 3 * d, d, d)
         if key in recs and recs[key]:
             avg_ms = sum(recs[key]) / len(recs[key])
             flops = 8.0 * E * cfg["B"] * d * d  # edge MLP: 2*E*(3d*d + d*d)
             achieved = flops / (avg_ms * 1e-3) / 1e12
+            # algorithmic HBM bytes of one training-mode launch: edge rows in, z1 + xhat (+rstd) out per edge,
+            # aggregate out per receiver; sender / receiver rows and the weights are L2 / MALL resident
+            alg_bytes = cfg["B"] * (E * (4 * d + 2 * 4 * d + 4) + Nr * 4 * d)
+            traffic = None
+            tfile = ROOT / "profiles" / "round1" / "pmc_traffic.json"
+            if tfile.exists():
+                try:
+                    traffic = json.loads(tfile.read_text()).get("m2g_edge_fwd_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            mode = ops.MATMUL_MODE
             roofline = {
                 "bound": "mfma",
-                "kernel": "mlp_fwd_kernel<2,2> (m2g edge set: gather+edge MLP+LN+aggregate)",
+                "kernel": ("mlp_fwd_bf_kernel<2,2,%s>" % mode[-1] if mode.startswith("bf16") else "mlp_fwd_kernel<2,2,FAST>")
+                          + " (m2g edge set: gather + edge MLP + LayerNorm + aggregate, training mode)",
+                "matmul_mode": mode,
                 "achieved": achieved,
                 "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                 "avg_launch_ms": avg_ms,
                 "launches": len(recs[key]),
-                "traffic": None,
+                "algorithmic_flops_per_launch": flops,
+                "algorithmic_hbm_bytes_per_launch": alg_bytes,
+                "hbm_GBps_algorithmic": alg_bytes / (avg_ms * 1e-3) / 1e9,
+                "hbm_frac_of_8TBps": alg_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "traffic": traffic,
             }
 
     if rank == 0:
@@ -242,6 +268,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "matmul_mode": ops.MATMUL_MODE,
             "data": "synthetic",
             "launch_mode": "eager" if args.eager else "hip_graph (zero-grad + fwd + loss + bwd captured once; all-reduce + AdamW after each replay)",
             "forecast_steps_per_s": forecast_steps_per_s,

@@ -822,6 +822,343 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
 }
 
 // ---------------------------------------------------------------------------
+// forward, split-bf16 matrix path, FAST shapes, software-pipelined across tiles.
+// One wave = one tile at a time (two waves per SIMD).  With the GEMMs on the bf16 cores a
+// tile holds only ~6k cycles of MFMA and ~8k of VALU, so memory latency decides: every load
+// of tile n+1 is issued while tile n still computes, and -- because gfx950 retires loads and
+// stores through ONE in-order counter -- always AHEAD of tile n's stores:
+//   top of tile n   : rows of tile n are already in registers (96 VGPRs: 3 sources x 64 columns);
+//                     request desc(n+2)?  no: desc(n+1) arrived during tile n-1; request idx(n+1),
+//                     the epilogue indices of tile n (rowptr, out rows) and desc(n+2)
+//   GEMM1(n)        : consumes the row registers
+//   right after     : rows of tile n+1 -> the same registers (idx(n+1) has landed)
+//   SiLU, GEMM2, LayerNorm, then ALL stores of tile n (z1, xhat, aggr / out)
+// ---------------------------------------------------------------------------
+template <int HB, int OB, int NS>
+__global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_fwd_t p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int DPH = HB * 32, OP = OB * 32;
+    constexpr int S2 = DPH / 16;
+    constexpr int MAXU = 2 * NLAM_MAX_SRC;            // 32-column units per tile row (widths <= 64)
+
+    int kin = 0, nunits = 0;
+    for (int s = 0; s < p.nsrc; ++s) {
+        kin += p.src[s].width;
+        nunits += p.src[s].width >> 5;
+    }
+    const int S1 = kin >> 4;
+
+    u32x4* W1s = reinterpret_cast<u32x4*>(smem);                       // [NS][HB][S1][64] x 16 B
+    u32x4* W2s = W1s + (size_t)NS * HB * S1 * 64;                      // [NS][OB][S2][64] x 16 B
+    float* b1l = reinterpret_cast<float*>(W2s + (size_t)NS * OB * S2 * 64);   // DPH
+    float* b2l = b1l + DPH;                                            // OP
+    float* gml = b2l + OP;                                             // OP
+    float* btl = gml + OP;                                             // OP
+    float* stg_all = btl + OP;                                         // kFwdWaves x 32 x kStgStride
+    {
+        int s0 = 0, off = 0;
+        for (int s = 0; s < p.nsrc; ++s) {
+            const int w = p.src[s].width;
+            stage_split<NS>(W1s, S1, s0, p.W1 + off, kin, p.hid, HB, w, false);
+            off += w;
+            s0 += w >> 4;
+        }
+        stage_split<NS>(W2s, S2, 0, p.W2, p.hid, p.dout, OB, p.hid, true);
+    }
+    stage_vec(b1l, p.b1, p.hid, DPH, 0.f);
+    stage_vec(b2l, p.b2, p.dout, OP, 0.f);
+    stage_vec(gml, p.ln_w, p.dout, OP, 1.f);
+    stage_vec(btl, p.ln_b, p.dout, OP, 0.f);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    float* stg = stg_all + (size_t)wave * 32 * kStgStride;
+    const bool has_ln = p.ln_w != nullptr;
+    const float inv_dout = 1.f / (float)p.dout;
+
+    // unit u -> (source, first column) ; fixed per launch
+    int usrc[MAXU], ucol[MAXU];
+    {
+        int u = 0;
+#pragma unroll
+        for (int s = 0; s < NLAM_MAX_SRC; ++s)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                usrc[2 * s + c] = 0;
+                ucol[2 * s + c] = 0;
+            }
+        for (int s = 0; s < p.nsrc; ++s)
+            for (int c = 0; c < (p.src[s].width >> 5); ++c) {
+#pragma unroll
+                for (int k = 0; k < MAXU; ++k)
+                    if (k == u) {
+                        usrc[k] = s;
+                        ucol[k] = 32 * c;
+                    }
+                ++u;
+            }
+    }
+
+    const int nwaves = blockDim.x >> 6;
+    const long total_tiles = (long)p.ntiles * p.batch;
+    const long stride = (long)gridDim.x * nwaves;
+    long gt = (long)blockIdx.x * nwaves + wave;
+
+    auto tile_of = [&](long g, int& b_out) -> TileInfo {
+        b_out = (int)(g / p.ntiles);
+        return get_tile(p.tiles, (int)(g % p.ntiles), p.rows);
+    };
+    auto clamp_row = [&](const TileInfo& t) { return min(t.row0 + max(min(j, t.nrows - 1), 0), p.rows - 1); };
+    // gathered rows of a tile -> per-source row pointers
+    auto row_ptrs = [&](const TileInfo& t, int b, const int (&ridx)[NLAM_MAX_SRC], const float* (&rp)[NLAM_MAX_SRC]) {
+#pragma unroll
+        for (int s = 0; s < NLAM_MAX_SRC; ++s)
+            rp[s] = s < p.nsrc ? p.src[s].ptr + (long)b * p.src[s].bstride + (long)ridx[s] * p.src[s].width : nullptr;
+    };
+    auto load_idx = [&](const TileInfo& t, int (&ridx)[NLAM_MAX_SRC]) {
+        const int pr = clamp_row(t);
+#pragma unroll
+        for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+            ridx[s] = pr;
+            if (s < p.nsrc && p.src[s].idx != nullptr) ridx[s] = p.src[s].idx[pr];
+        }
+    };
+    constexpr int kPre = 4;   // units prefetched a tile ahead (the rest stream in at the top of their own tile)
+    f32x4 xp[kPre][4];        // loop-carried: rows of the next tile
+    auto load_unit = [&](const float* const (&rp)[NLAM_MAX_SRC], int u, f32x4(&xu)[4]) {
+        const float* base = (usrc[u] == 0 ? rp[0] : (usrc[u] == 1 ? rp[1] : rp[2])) + ucol[u] + 8 * hi;
+        xu[0] = *reinterpret_cast<const f32x4*>(base);
+        xu[1] = *reinterpret_cast<const f32x4*>(base + 4);
+        xu[2] = *reinterpret_cast<const f32x4*>(base + 16);
+        xu[3] = *reinterpret_cast<const f32x4*>(base + 20);
+    };
+    auto load_pre = [&](const float* const (&rp)[NLAM_MAX_SRC]) {
+#pragma unroll
+        for (int u = 0; u < kPre; ++u)
+            if (u < nunits) load_unit(rp, u, xp[u]);
+    };
+    // ---- pipeline prologue: tile 0 fully resolved and loaded, tile 1's descriptor requested ----
+    TileInfo tl = {0, 0, 0, 0, false}, tln = {0, 0, 0, 0, false};
+    int b = 0, bn = 0;
+    int ridx[NLAM_MAX_SRC] = {0, 0, 0}, ridx_n[NLAM_MAX_SRC] = {0, 0, 0};
+    const float* srow[NLAM_MAX_SRC] = {nullptr, nullptr, nullptr};
+    if (gt < total_tiles) {
+        tl = tile_of(gt, b);
+        load_idx(tl, ridx);
+        row_ptrs(tl, b, ridx, srow);
+        load_pre(srow);
+        if (gt + stride < total_tiles) tln = tile_of(gt + stride, bn);
+    }
+
+    for (; gt < total_tiles; gt += stride) {
+        const bool valid = j < tl.nrows;
+        const int prow = tl.row0 + j;
+        const bool has_next = gt + stride < total_tiles;
+
+        // ---- the last units of this tile (behind the previous tile's stores, but needed last in GEMM1) ----
+        f32x4 xt[MAXU - kPre][4];
+#pragma unroll
+        for (int u = kPre; u < MAXU; ++u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xt[u - kPre][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (u < nunits) load_unit(srow, u, xt[u - kPre]);
+        }
+        // ---- requests that must be ahead of this tile's stores: idx(n+1), epilogue indices of tile n, desc(n+2) ----
+        if (has_next) load_idx(tln, ridx_n);
+        int oidx = ridx[0];
+        if (p.out != nullptr && p.out_idx != p.src[0].idx) oidx = p.out_idx != nullptr ? p.out_idx[clamp_row(tl)] : clamp_row(tl);
+        int raw_ptr = 0;
+        float my_scale = 1.f;
+        if (p.aggr != nullptr) {
+            if (!tl.split && lane <= tl.nseg) raw_ptr = p.rowptr[tl.seg0 + lane];
+            if ((p.flags & NLAM_F_MEAN) && lane < tl.nseg) my_scale = p.inv_deg[tl.seg0 + lane];
+        }
+        TileInfo tlnn = {0, 0, 0, 0, false};
+        int bnn = 0;
+        if (gt + 2 * stride < total_tiles) tlnn = tile_of(gt + 2 * stride, bnn);
+
+        // ---- GEMM1 over the resident rows ----
+        f32x16 acc1[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[hb][r] = 0.f;
+        f32x4 resid[2][4];   // the 64 columns of source 0 (edge / node residual) or source 1 (PropagationNet)
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u) {
+            if (u < nunits) {
+                const f32x4(&x)[4] = u < kPre ? xp[u < kPre ? u : 0] : xt[u >= kPre ? u - kPre : 0];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float xs8[8] = {x[2 * h][0], x[2 * h][1], x[2 * h][2], x[2 * h][3],
+                                          x[2 * h + 1][0], x[2 * h + 1][1], x[2 * h + 1][2], x[2 * h + 1][3]};
+                    const BfFrag<NS> B = split8<NS>(xs8);
+                    mma_split_lds<NS, HB>(acc1, W1s, HB, S1, 2 * u + h, lane, B);
+                }
+            }
+        }
+        // residual rows (C-layout chunks 8t + 4hi differ from the unit layout 8hi + ..: re-read below, ahead of the stores)
+        const bool add0 = (p.flags & NLAM_F_ADD_SRC0) != 0 && p.out != nullptr;
+        const bool add1 = (p.flags & NLAM_F_ADD_SRC1) != 0;
+        if (add0 || add1) {
+            const float* rr = add1 ? srow[1] : srow[0];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+                    if (ob < OB) resid[ob][tt] = *reinterpret_cast<const f32x4*>(rr + 8 * (ob * 4 + tt) + 4 * hi);
+        }
+        // ---- rows of tile n+1 into the same registers (still ahead of every store of tile n) ----
+        const float* srow_n[NLAM_MAX_SRC] = {nullptr, nullptr, nullptr};
+        if (has_next) {
+            row_ptrs(tln, bn, ridx_n, srow_n);
+            load_pre(srow_n);
+        }
+
+        // ---- bias, save pre-activation, SiLU -> B operand of GEMM2 ----
+        {
+            float* zbase = p.z1 != nullptr ? p.z1 + ((size_t)b * p.rows + tl.row0) * p.hid : nullptr;
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(&b1l[8 * (hb * 4 + tt) + 4 * hi]);
+                    const f32x4 z = acc_chunk(acc1[hb], tt) + bias;
+                    if (p.z1 != nullptr) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = z;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc1[hb][4 * tt + c] = silu_f(z[c]);
+                }
+                if (p.z1 != nullptr) {
+                    wave_lds_sync();
+                    block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return zbase + (size_t)r * p.hid + 32 * hb; });
+                    wave_lds_sync();
+                }
+            }
+        }
+
+        // ---- GEMM2 straight from the accumulators ----
+        f32x16 acc2[OB];
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[ob][r] = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float xs8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xs8[q] = acc1[hb][8 * h + q];
+                const BfFrag<NS> B = split8<NS>(xs8);
+                mma_split_lds<NS, OB>(acc2, W2s, OB, S2, 2 * hb + h, lane, B);
+            }
+
+        // ---- bias 2 + LayerNorm ----
+        float sum = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(&b2l[8 * (ob * 4 + tt) + 4 * hi]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = acc2[ob][4 * tt + c] + bias[c];
+                    acc2[ob][4 * tt + c] = v;
+                    sum += v;
+                }
+            }
+        if (has_ln) {
+            const float mean = row_allreduce(sum) * inv_dout;
+            float sq = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dlt = acc2[ob][r] - mean;
+                    acc2[ob][r] = dlt;
+                    sq += dlt * dlt;
+                }
+            const float rstd = rsqrtf(row_allreduce(sq) * inv_dout + p.eps);
+            if (p.rstd != nullptr && valid && hi == 0) p.rstd[(size_t)b * p.rows + prow] = rstd;
+            float* xbase = p.xhat != nullptr ? p.xhat + ((size_t)b * p.rows + tl.row0) * p.dout : nullptr;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
+                    f32x4 xh;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xh[c] = acc2[ob][4 * tt + c] * rstd;
+                    if (p.xhat != nullptr) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = xh;
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(&gml[c0]);
+                    const f32x4 be = *reinterpret_cast<const f32x4*>(&btl[c0]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc2[ob][4 * tt + c] = xh[c] * g[c] + be[c];
+                }
+                if (p.xhat != nullptr) {
+                    wave_lds_sync();
+                    block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return xbase + (size_t)r * p.dout + 32 * ob; });
+                    wave_lds_sync();
+                }
+            }
+        }
+
+        // ---- msg = mlp [+ src1]; aggregate; out = msg [+ src0] ----
+        {
+            float* obase = p.out != nullptr ? p.out + (long)b * p.out_bstride : nullptr;
+            float* abase = p.aggr != nullptr ? p.aggr + (size_t)b * p.nseg_total * p.dout : nullptr;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob) {
+                f32x4 m[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    m[tt] = acc_chunk(acc2[ob], tt);
+                    if (add1) m[tt] += resid[ob][tt];
+                    if (!valid) m[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (p.aggr != nullptr) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = m[tt];
+                    wave_lds_sync();
+                    block_segment_reduce(stg, tl, raw_ptr, my_scale, abase + 32 * ob, p.dout, 32, lane);
+                    wave_lds_sync();
+                }
+                if (p.out != nullptr) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        if (add0) {
+                            // both residuals at once (PropagationNet with edge update) re-reads source 0 behind the stores
+                            if (add1)
+                                m[tt] += *reinterpret_cast<const f32x4*>(srow[0] + 8 * (ob * 4 + tt) + 4 * hi);
+                            else
+                                m[tt] += resid[ob][tt];
+                        }
+                        *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = m[tt];
+                    }
+                    wave_lds_sync();
+                    block_rows_out(stg, tl.nrows, 32, lane,
+                                   [&](int r) { return obase + (long)__shfl(oidx, r, 64) * p.dout + 32 * ob; });
+                    wave_lds_sync();
+                }
+            }
+        }
+
+        // ---- rotate ----
+        tl = tln;
+        b = bn;
+        tln = tlnn;
+        bn = bnn;
+#pragma unroll
+        for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+            ridx[s] = ridx_n[s];
+            srow[s] = srow_n[s];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // backward (data gradients + bias / LayerNorm-affine partial sums)
 // ---------------------------------------------------------------------------
 // column sums of a staged 32 x w tile, accumulated into one register per lane
@@ -2072,7 +2409,7 @@ int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p) {
 int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     if (p == nullptr) return 0;
     const long total_chunks = (long)p->batch * ((p->rows + kWgradRows - 1) / kWgradRows);
-    long np = total_chunks / 4;
+    long np = total_chunks;   // small problems: one 32-row chunk per workgroup (latency-bound otherwise)
     long cap = 512;
     if (wgrad_is_wide(p)) {
         cap = 1024 / wgrad_windows(p);
@@ -2089,13 +2426,20 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
         if (rc != 0) return rc;                                                                                        \
         hipLaunchKernelGGL((mlp_fwd_kernel<HB_, OB_, FAST_, NS_>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p);  \
     } while (0)
-#define NLAM_LAUNCH_FWD(HB_, OB_)                              \
-    do {                                                       \
-        if (ns == 3) NLAM_LAUNCH_FWD1(HB_, OB_, true, 3);      \
-        else if (ns == 2) NLAM_LAUNCH_FWD1(HB_, OB_, true, 2); \
-        else if (ns == 1) NLAM_LAUNCH_FWD1(HB_, OB_, true, 1); \
-        else if (fast) NLAM_LAUNCH_FWD1(HB_, OB_, true, 0);    \
-        else NLAM_LAUNCH_FWD1(HB_, OB_, false, 0);             \
+#define NLAM_LAUNCH_FWDBF(HB_, OB_, NS_)                                                                          \
+    do {                                                                                                          \
+        const size_t lds = fwd_lds_bytes(p, HB_, OB_, NS_);                                                       \
+        int rc = set_lds(mlp_fwd_bf_kernel<HB_, OB_, NS_>, lds);                                                  \
+        if (rc != 0) return rc;                                                                                   \
+        hipLaunchKernelGGL((mlp_fwd_bf_kernel<HB_, OB_, NS_>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p); \
+    } while (0)
+#define NLAM_LAUNCH_FWD(HB_, OB_)                            \
+    do {                                                     \
+        if (ns == 3) NLAM_LAUNCH_FWDBF(HB_, OB_, 3);         \
+        else if (ns == 2) NLAM_LAUNCH_FWDBF(HB_, OB_, 2);    \
+        else if (ns == 1) NLAM_LAUNCH_FWDBF(HB_, OB_, 1);    \
+        else if (fast) NLAM_LAUNCH_FWD1(HB_, OB_, true, 0);  \
+        else NLAM_LAUNCH_FWD1(HB_, OB_, false, 0);           \
     } while (0)
 
 int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
@@ -2152,7 +2496,7 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
     bool w32 = true;
     for (int s = 0; s < p->nsrc; ++s) {
         fast = fast && (p->src[s].width % 8 == 0);
-        w32 = w32 && (p->src[s].width % 32 == 0);
+        w32 = w32 && (p->src[s].width % 32 == 0) && p->src[s].width <= 64;
     }
     // matrix path: NLAM_F_MM_* asks for the split-bf16 cores; shapes they do not cover run the fp32 MFMA
     int ns = 0;

@@ -169,7 +169,8 @@ class Trainer:
         # the warm-up's autograd graph (and its AccumulateGrad nodes, bound to the side stream) is gone here, so the
         # capture creates its own on the capture stream and accumulates in place into the flat gradient views
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # thread_local: the RCCL watchdog thread may query events while this thread captures
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
             self.fp.grad.zero_()
             self._static_loss = self._fwd_bwd()
 

@@ -370,3 +370,121 @@ def test_fused_adamw_matches_torch(dev):
         opt.step()
         mine.step()
     assert rel_err(p.cpu(), ref_p.detach().cpu()) < 1e-5
+
+
+# ---------------------------------------------------------------------------
+# matrix-path modes, determinism, fused loss, HIP-graph step
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("bf16x2", 1e-4), ("bf16", 3e-2)])
+def test_matmul_modes_match_oracle(dev, mode, tol):
+    """f32 = fp32 MFMA; bf16xN = operands split into N bf16 terms on the bf16 matrix cores (fp32 accumulate).
+    bf16x3 is the default and fp32-class; plain bf16 is the autocast-like mode with its own (stated) tolerance."""
+    from neural_lam_amd import ops
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    ns, nr, e, B, d = 61, 47, 1501, 2, 64
+    ei = _rand_ei(ns, nr, e, seed=7)
+    torch.manual_seed(7)
+    ref = og.InteractionNet(ei, d)
+    net = hl.InteractionNet(ei, d)
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    send, rec, edge = torch.randn(B, ns, d), torch.randn(B, nr, d), torch.randn(B, e, d)
+    s1, r1, e1 = (t.clone().requires_grad_() for t in (send, rec, edge))
+    s2, r2, e2 = (t.to(dev).requires_grad_() for t in (send, rec, edge))
+    old = ops.MATMUL_MODE
+    try:
+        ops.set_matmul_mode(mode)
+        o2 = net(s2, r2, e2)
+        sum(o.square().sum() for o in o2).backward()
+    finally:
+        ops.set_matmul_mode(old)
+    o1 = ref(s1, r1, e1)
+    sum(o.square().sum() for o in o1).backward()
+    for a, b in zip(o2, o1):
+        assert rel_err(a.cpu(), b) < tol
+    for a, b in ((s2, s1), (r2, r1), (e2, e1)):
+        assert rel_err(a.grad.cpu(), b.grad) < tol
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < tol, k
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_layer_is_bit_reproducible_at_meps_size(dev, mode):
+    """Same inputs -> identical bits, 8 runs (no atomics on the MEPS graphs; the split-bf16 MFMA groups keep
+    their operands in distinct registers -- see mma_split_lds in csrc/nlam_hip.hip)."""
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import ops
+
+    hl = _hl()
+    raw = G.create_regular_grid_graph(G.regular_grid_xy(238, 268))
+    ei = raw["g2m_edge_index"]
+    ns, nr, E = int(ei[0].max()) + 1, int(ei[1].max()) + 1, ei.shape[1]
+    torch.manual_seed(0)
+    net = hl.InteractionNet(ei, 64, update_edges=False).to(dev)
+    send, rec, edge = (torch.randn(1, n, 64, device=dev, requires_grad=True) for n in (ns, nr, E))
+    old = ops.MATMUL_MODE
+    try:
+        ops.set_matmul_mode(mode)
+        runs = []
+        for _ in range(8):
+            for t in (send, rec, edge):
+                t.grad = None
+            net.zero_grad(set_to_none=True)
+            out = net(send, rec, edge)
+            out.square().sum().backward()
+            runs.append([out.detach().clone(), send.grad.clone(), rec.grad.clone(), edge.grad.clone()]
+                        + [p.grad.clone() for p in net.parameters()])
+    finally:
+        ops.set_matmul_mode(old)
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+
+
+def test_fused_wmse_loss_matches_reference_formula(dev):
+    """nlam_wmse_fwd/bwd == metrics.wmse + mask_and_reduce_metric + batch/step means (metrics.py:37-137, module.py:463-510)."""
+    from neural_lam_amd import models as hm
+    from neural_lam_amd.ops import WmseLossFunction
+
+    torch.manual_seed(3)
+    B, T, N, V = 2, 3, 1000, 17
+    pred = torch.randn(B, T, N, V, device=dev, requires_grad=True)
+    target = torch.randn(B, T, N, V, device=dev)
+    std = torch.rand(V, device=dev) + 0.5
+    mask = torch.rand(N, device=dev) > 0.3
+    w = mask.float() / mask.sum()
+    loss = WmseLossFunction.apply(pred, target, 1.0 / (std * std), w)
+    loss.backward()
+    p2 = pred.detach().clone().requires_grad_()
+    ref = torch.mean(torch.mean(hm.wmse(p2, target, std, mask=mask), dim=0))
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    assert rel_err(pred.grad.cpu(), p2.grad.cpu()) < 1e-5
+
+
+def test_hip_graph_step_equals_eager_step(dev, tmp_path):
+    """Trainer(use_graph=True) replays zero-grad + fwd + loss + bwd from one HIP graph: same bits as eager."""
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import models as hm
+    from neural_lam_amd.datastore import SyntheticDatastore
+    from neural_lam_amd.trainer import Trainer
+
+    def make(use_graph):
+        ds = SyntheticDatastore(30, 27, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+        ext = ds.get_xy_extent("state")
+        graph = G.normalise_graph(G.create_regular_grid_graph(ds.get_xy("state")), max(ext[1] - ext[0], ext[3] - ext[2]))
+        torch.manual_seed(1)
+        fc = hm.ARForecaster(hm.GraphLAM(ds, graph=graph, hidden_dim=16, processor_layers=2), ds)
+        return ds, Trainer(hm.ForecasterStep(fc, ds).to(dev), lr=1e-3, use_graph=use_graph)
+
+    ds, t_eager = make(False)
+    _, t_graph = make(True)
+    N = ds.num_grid_points
+    g = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        batch = [torch.randn(1, 2, N, 5, generator=g).to(dev), torch.randn(1, 2, N, 5, generator=g).to(dev),
+                 torch.randn(1, 2, N, 6, generator=g).to(dev)]
+        le, lg = float(t_eager.step(*batch)), float(t_graph.step(*batch))
+        assert le == lg
+        assert torch.equal(t_eager.fp.flat, t_graph.fp.flat) and torch.equal(t_eager.fp.grad, t_graph.fp.grad)
