@@ -417,8 +417,9 @@ __device__ __forceinline__ void mma_split_lds(f32x16 (&acc)[NB], const u32x4* Wp
 //   dst[((term * MB + mb) * S + s0 + s) * 64 + lane] (16 B) = slots q = 0..7 of row mb*32 + (lane & 31),
 //   k = perm2 ? 32*(s>>1) + 16*(s&1) + (q&3) + 8*(q>>2) + 4*hi : 16*s + 8*hi + q ;  A[m][k] = W[m*ldm + k]
 template <int NS>
-__device__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2, long ldk = 1) {
-    const int nst = K >> 4;
+__device__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2, long ldk = 1,
+                            int Kpad = 0) {
+    const int nst = (Kpad > 0 ? Kpad : K) >> 4;   // steps written (columns k >= K are zero)
     const int total = MB * nst * 64;
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
         const int lane = idx & 63;
@@ -834,19 +835,22 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
 //   right after     : rows of tile n+1 -> the same registers (idx(n+1) has landed)
 //   SiLU, GEMM2, LayerNorm, then ALL stores of tile n (z1, xhat, aggr / out)
 // ---------------------------------------------------------------------------
-template <int HB, int OB, int NS>
+// RAG = some source is narrower than / not a multiple of a 32-column unit (element-wise, zero-filled loads)
+template <int HB, int OB, int NS, bool RAG>
 __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_fwd_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int DPH = HB * 32, OP = OB * 32;
     constexpr int S2 = DPH / 16;
-    constexpr int MAXU = 2 * NLAM_MAX_SRC;            // 32-column units per tile row (widths <= 64)
+    constexpr int MAXU = RAG ? 2 : 2 * NLAM_MAX_SRC;  // 32-column units per tile row (widths <= 64; RAG: a single source)
 
+    // every source is padded to whole 32-column units (zero weights / zero-filled loads past its width), so
+    // narrow or odd inputs (the 2- / 3-feature embedder inputs, kin = 56) run on the same path
     int kin = 0, nunits = 0;
     for (int s = 0; s < p.nsrc; ++s) {
         kin += p.src[s].width;
-        nunits += p.src[s].width >> 5;
+        nunits += (p.src[s].width + 31) >> 5;
     }
-    const int S1 = kin >> 4;
+    const int S1 = 2 * nunits;
 
     u32x4* W1s = reinterpret_cast<u32x4*>(smem);                       // [NS][HB][S1][64] x 16 B
     u32x4* W2s = W1s + (size_t)NS * HB * S1 * 64;                      // [NS][OB][S2][64] x 16 B
@@ -859,9 +863,9 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
         int s0 = 0, off = 0;
         for (int s = 0; s < p.nsrc; ++s) {
             const int w = p.src[s].width;
-            stage_split<NS>(W1s, S1, s0, p.W1 + off, kin, p.hid, HB, w, false);
+            stage_split<NS>(W1s, S1, s0, p.W1 + off, kin, p.hid, HB, w, false, 1, ((w + 31) >> 5) * 32);
             off += w;
-            s0 += w >> 4;
+            s0 += 2 * ((w + 31) >> 5);
         }
         stage_split<NS>(W2s, S2, 0, p.W2, p.hid, p.dout, OB, p.hid, true);
     }
@@ -883,14 +887,12 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
     {
         int u = 0;
 #pragma unroll
-        for (int s = 0; s < NLAM_MAX_SRC; ++s)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                usrc[2 * s + c] = 0;
-                ucol[2 * s + c] = 0;
-            }
+        for (int k2 = 0; k2 < MAXU; ++k2) {
+            usrc[k2] = 0;
+            ucol[k2] = 0;
+        }
         for (int s = 0; s < p.nsrc; ++s)
-            for (int c = 0; c < (p.src[s].width >> 5); ++c) {
+            for (int c = 0; c < ((p.src[s].width + 31) >> 5); ++c) {
 #pragma unroll
                 for (int k = 0; k < MAXU; ++k)
                     if (k == u) {
@@ -925,14 +927,26 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
             if (s < p.nsrc && p.src[s].idx != nullptr) ridx[s] = p.src[s].idx[pr];
         }
     };
-    constexpr int kPre = 4;   // units prefetched a tile ahead (the rest stream in at the top of their own tile)
+    constexpr int kPre = RAG ? 2 : 4;   // units prefetched a tile ahead (the rest stream in at the top of their own tile)
+    constexpr int kTop = MAXU - kPre > 0 ? MAXU - kPre : 1;
     f32x4 xp[kPre][4];        // loop-carried: rows of the next tile
     auto load_unit = [&](const float* const (&rp)[NLAM_MAX_SRC], int u, f32x4(&xu)[4]) {
-        const float* base = (usrc[u] == 0 ? rp[0] : (usrc[u] == 1 ? rp[1] : rp[2])) + ucol[u] + 8 * hi;
-        xu[0] = *reinterpret_cast<const f32x4*>(base);
-        xu[1] = *reinterpret_cast<const f32x4*>(base + 4);
-        xu[2] = *reinterpret_cast<const f32x4*>(base + 16);
-        xu[3] = *reinterpret_cast<const f32x4*>(base + 20);
+        const float* row = usrc[u] == 0 ? rp[0] : (usrc[u] == 1 ? rp[1] : rp[2]);
+        const int w = usrc[u] == 0 ? p.src[0].width : (usrc[u] == 1 ? p.src[1].width : p.src[2].width);
+        const int c0 = ucol[u] + 8 * hi;
+        if (!RAG || (w & 31) == 0) {   // whole units, 16-B aligned rows
+            xu[0] = *reinterpret_cast<const f32x4*>(row + c0);
+            xu[1] = *reinterpret_cast<const f32x4*>(row + c0 + 4);
+            xu[2] = *reinterpret_cast<const f32x4*>(row + c0 + 16);
+            xu[3] = *reinterpret_cast<const f32x4*>(row + c0 + 20);
+        } else {               // ragged source: element-wise, zero past its width
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cq = c0 + (q & 1) * 4 + (q >> 1) * 16;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xu[q][c] = cq + c < w ? row[cq + c] : 0.f;
+            }
+        }
     };
     auto load_pre = [&](const float* const (&rp)[NLAM_MAX_SRC]) {
 #pragma unroll
@@ -958,7 +972,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
         const bool has_next = gt + stride < total_tiles;
 
         // ---- the last units of this tile (behind the previous tile's stores, but needed last in GEMM1) ----
-        f32x4 xt[MAXU - kPre][4];
+        f32x4 xt[kTop][4];
 #pragma unroll
         for (int u = kPre; u < MAXU; ++u) {
 #pragma unroll
@@ -989,7 +1003,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
 #pragma unroll
         for (int u = 0; u < MAXU; ++u) {
             if (u < nunits) {
-                const f32x4(&x)[4] = u < kPre ? xp[u < kPre ? u : 0] : xt[u >= kPre ? u - kPre : 0];
+                const f32x4(&x)[4] = u < kPre ? xp[u < kPre ? u : 0] : xt[u >= kPre ? (u - kPre < kTop ? u - kPre : 0) : 0];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float xs8[8] = {x[2 * h][0], x[2 * h][1], x[2 * h][2], x[2 * h][3],
@@ -2061,6 +2075,83 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_kernel(const nlam_wgrad_t
     }
 }
 
+// Weight gradient against a very narrow B (n <= 8 columns, one source: the 2- / 3-feature inputs of
+// the mesh / edge embedders): no MFMA tile would be more than 1/4 full, so this is a streaming
+// reduction: lane = column m of A, every wave walks rows, B's few values are broadcast loads.
+// HBM-bound (reads A once).  partials layout as the MFMA kernels: (nparts, m, n).
+constexpr int kSmallN = 8;
+// m % 4 == 0: lane -> (row of the pass, 4 columns of A): one coalesced 16-B load per lane covers 64 / (m/4) rows
+__global__ __launch_bounds__(256) void wgrad_smalln_kernel(const nlam_wgrad_t p) {
+    __shared__ float red[256 * 4 * kSmallN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const nlam_src_t S = p.src[0];
+    const int n = S.width;
+    const long total_rows = (long)p.batch * p.rows;
+    const long per = (total_rows + gridDim.x - 1) / gridDim.x;
+    const long r_begin = (long)blockIdx.x * per, r_end = min(total_rows, r_begin + per);
+    const bool flat_b = p.batch == 1 || (S.idx == nullptr && S.bstride == (long)p.rows * n);
+    for (int m0 = 0; m0 < p.m; m0 += 256) {
+        const int cols = min(256, p.m - m0);
+        const int vpr = cols >> 2;                 // float4 per row in this column pass (<= 64)
+        const int rpp = 64 / vpr;                  // rows per wave-instruction
+        const int rsub = lane / vpr, c4 = lane - rsub * vpr;
+        const bool lane_ok = rsub < rpp;
+        float acc[4][kSmallN];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < kSmallN; ++k) acc[c][k] = 0.f;
+        constexpr int kRB = 4;                     // passes in flight per wave
+        for (long g0 = r_begin + (long)wave * rpp * kRB; g0 < r_end; g0 += 4L * rpp * kRB) {
+            f32x4 a[kRB];
+            float xv[kRB][kSmallN];
+#pragma unroll
+            for (int u = 0; u < kRB; ++u) {
+                const long gr = g0 + (long)u * rpp + rsub;
+                const bool ok = lane_ok && gr < r_end;
+                const long grc = ok ? gr : r_begin;
+                a[u] = ok ? *reinterpret_cast<const f32x4*>(p.A + grc * p.m + m0 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* xr;
+                if (flat_b && S.idx == nullptr) {
+                    xr = S.ptr + grc * n;
+                } else {
+                    const int b = (int)(grc / p.rows);
+                    const int row = (int)(grc - (long)b * p.rows);
+                    const long ridx = S.idx != nullptr ? S.idx[row] : row;
+                    xr = S.ptr + (long)b * S.bstride + ridx * n;
+                }
+#pragma unroll
+                for (int k = 0; k < kSmallN; ++k) xv[u][k] = k < n ? xr[k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < kRB; ++u)
+#pragma unroll
+                for (int k = 0; k < kSmallN; ++k)
+                    if (k < n) {
+                        float x = xv[u][k];
+                        if (p.flags & NLAM_F_SILU_B) x = silu_f(x);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c][k] += a[u][c] * x;
+                    }
+        }
+        // combine the 4 waves x rpp row groups: thread -> (column, k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < kSmallN; ++k) red[(tid * 4 + c) * kSmallN + k] = lane_ok ? acc[c][k] : 0.f;
+        __syncthreads();
+        for (int o = tid; o < cols * n; o += 256) {
+            const int col = o / n, k = o - col * n;
+            const int cc4 = col >> 2, c = col & 3;
+            float sum = 0.f;
+            for (int w = 0; w < 4; ++w)
+                for (int rs = 0; rs < rpp; ++rs) sum += red[((w * 64 + rs * vpr + cc4) * 4 + c) * kSmallN + k];
+            p.partials[(size_t)blockIdx.x * p.m * p.n + (size_t)(m0 + col) * p.n + k] = sum;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // small HBM-bound kernels
 // ---------------------------------------------------------------------------
@@ -2207,7 +2298,11 @@ size_t fwd_lds_bytes(const nlam_mlp_fwd_t* p, int HB, int OB, int NS = 0) {
     size_t T1 = 0;
     for (int s = 0; s < p->nsrc; ++s) T1 += (p->src[s].width + 7) / 8;
     size_t wf = (size_t)DPH * 8 * T1 + (size_t)OP * DPH;   // weights, in floats
-    if (NS > 0) wf = wf * NS / 2;                            // NS bf16 copies
+    if (NS > 0) {                                            // NS bf16 copies, sources padded to 32-column units
+        size_t k1 = 0;
+        for (int s = 0; s < p->nsrc; ++s) k1 += (size_t)((p->src[s].width + 31) / 32) * 32;
+        wf = ((size_t)DPH * k1 + (size_t)OP * DPH) * NS / 2;
+    }
     size_t f = wf + DPH + 3 * OP;
     f += (size_t)kFwdWaves * 32 * kStgStride;
     return f * sizeof(float);
@@ -2411,6 +2506,7 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     const long total_chunks = (long)p->batch * ((p->rows + kWgradRows - 1) / kWgradRows);
     long np = total_chunks;   // small problems: one 32-row chunk per workgroup (latency-bound otherwise)
     long cap = 512;
+    if (p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) np = (total_chunks + 3) / 4;   // streaming kernel: >= 128 rows per workgroup
     if (wgrad_is_wide(p)) {
         cap = 1024 / wgrad_windows(p);
         if (cap < 4) cap = 4;
@@ -2426,12 +2522,17 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
         if (rc != 0) return rc;                                                                                        \
         hipLaunchKernelGGL((mlp_fwd_kernel<HB_, OB_, FAST_, NS_>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p);  \
     } while (0)
-#define NLAM_LAUNCH_FWDBF(HB_, OB_, NS_)                                                                          \
-    do {                                                                                                          \
-        const size_t lds = fwd_lds_bytes(p, HB_, OB_, NS_);                                                       \
-        int rc = set_lds(mlp_fwd_bf_kernel<HB_, OB_, NS_>, lds);                                                  \
-        if (rc != 0) return rc;                                                                                   \
-        hipLaunchKernelGGL((mlp_fwd_bf_kernel<HB_, OB_, NS_>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p); \
+#define NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, RAG_)                                                                          \
+    do {                                                                                                                \
+        const size_t lds = fwd_lds_bytes(p, HB_, OB_, NS_);                                                             \
+        int rc = set_lds(mlp_fwd_bf_kernel<HB_, OB_, NS_, RAG_>, lds);                                                  \
+        if (rc != 0) return rc;                                                                                         \
+        hipLaunchKernelGGL((mlp_fwd_bf_kernel<HB_, OB_, NS_, RAG_>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p); \
+    } while (0)
+#define NLAM_LAUNCH_FWDBF(HB_, OB_, NS_)                \
+    do {                                                \
+        if (ragged) NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, true); \
+        else NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, false);  \
     } while (0)
 #define NLAM_LAUNCH_FWD(HB_, OB_)                            \
     do {                                                     \
@@ -2492,15 +2593,21 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
     long need = (ttiles + nwaves - 1) / nwaves;
     const int blocks = (int)(need < 1 ? 1 : (need < kMaxGridBlocks ? need : kMaxGridBlocks));
     const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
-    bool fast = (p->hid % 32 == 0) && (p->dout % 32 == 0);
-    bool w32 = true;
+    const bool fast_out = (p->hid % 32 == 0) && (p->dout % 32 == 0);
+    bool fast = fast_out, w64 = true, ragged = false;
     for (int s = 0; s < p->nsrc; ++s) {
         fast = fast && (p->src[s].width % 8 == 0);
-        w32 = w32 && (p->src[s].width % 32 == 0) && p->src[s].width <= 64;
+        w64 = w64 && p->src[s].width <= 64;
+        ragged = ragged || (p->src[s].width % 32 != 0);
+    }
+    if (ragged && p->nsrc != 1) w64 = false;   // ragged inputs are covered for single-source MLPs (embedders, grid MLPs)
+    if ((p->flags & (NLAM_F_ADD_SRC0 | NLAM_F_ADD_SRC1)) != 0) {   // residual rows are read as whole 16-B chunks
+        const int rs = (p->flags & NLAM_F_ADD_SRC1) ? 1 : 0;
+        w64 = w64 && (p->src[rs].width % 32 == 0) && ((p->flags & NLAM_F_ADD_SRC0) == 0 || p->src[0].width % 32 == 0);
     }
     // matrix path: NLAM_F_MM_* asks for the split-bf16 cores; shapes they do not cover run the fp32 MFMA
     int ns = 0;
-    if (fast && w32) ns = (int)((p->flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
+    if (fast_out && w64) ns = (int)((p->flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
     if (ns > 3) return NLAM_EINVAL;
     if (HB == 1 && OB == 1) NLAM_LAUNCH_FWD(1, 1);
     else if (HB == 2 && OB == 1) NLAM_LAUNCH_FWD(2, 1);
@@ -2615,6 +2722,10 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     for (int s = 0; s < p->nsrc; ++s) n += p->src[s].width;
     if (n != p->n || p->m < 1 || p->nparts < 1) return NLAM_EINVAL;
     hipStream_t stream = (hipStream_t)hip_stream;
+    if (p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) {
+        hipLaunchKernelGGL(wgrad_smalln_kernel, dim3(p->nparts), dim3(256), 0, stream, *p);
+        return (int32_t)hipGetLastError();
+    }
     const bool dma = wgrad_is_narrow_dma(p);
     int nb_total = 0;
     for (int s = 0; s < p->nsrc; ++s) nb_total += (p->src[s].width + 31) / 32;
