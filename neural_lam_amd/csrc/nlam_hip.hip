@@ -529,7 +529,9 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
 
     const long total_tiles = (long)p.ntiles * p.batch;
     const int nwaves = blockDim.x >> 6;   // 1..kFwdWaves, chosen per launch so that small problems still cover the chip
-    for (long gt = (long)blockIdx.x * nwaves + wave; gt < total_tiles; gt += (long)gridDim.x * nwaves) {
+    // tile -> (workgroup, wave) with the workgroup index fastest: small launches put one tile on each CU while all
+    // 8 waves of every workgroup still share the weight staging
+    for (long gt = (long)wave * gridDim.x + blockIdx.x; gt < total_tiles; gt += (long)gridDim.x * nwaves) {
 #ifdef NLAM_TIMING
         ++t_ntiles_;
 #endif
@@ -859,22 +861,6 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
     float* gml = b2l + OP;                                             // OP
     float* btl = gml + OP;                                             // OP
     float* stg_all = btl + OP;                                         // kFwdWaves x 32 x kStgStride
-    {
-        int s0 = 0, off = 0;
-        for (int s = 0; s < p.nsrc; ++s) {
-            const int w = p.src[s].width;
-            stage_split<NS>(W1s, S1, s0, p.W1 + off, kin, p.hid, HB, w, false, 1, ((w + 31) >> 5) * 32);
-            off += w;
-            s0 += 2 * ((w + 31) >> 5);
-        }
-        stage_split<NS>(W2s, S2, 0, p.W2, p.hid, p.dout, OB, p.hid, true);
-    }
-    stage_vec(b1l, p.b1, p.hid, DPH, 0.f);
-    stage_vec(b2l, p.b2, p.dout, OP, 0.f);
-    stage_vec(gml, p.ln_w, p.dout, OP, 1.f);
-    stage_vec(btl, p.ln_b, p.dout, OP, 0.f);
-    __syncthreads();
-
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int j = lane & 31, hi = lane >> 5;
@@ -906,7 +892,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
     const int nwaves = blockDim.x >> 6;
     const long total_tiles = (long)p.ntiles * p.batch;
     const long stride = (long)gridDim.x * nwaves;
-    long gt = (long)blockIdx.x * nwaves + wave;
+    long gt = (long)wave * gridDim.x + blockIdx.x;   // workgroup index fastest (see mlp_fwd_kernel)
 
     auto tile_of = [&](long g, int& b_out) -> TileInfo {
         b_out = (int)(g / p.ntiles);
@@ -965,6 +951,23 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
         load_pre(srow);
         if (gt + stride < total_tiles) tln = tile_of(gt + stride, bn);
     }
+
+    // ---- weights -> LDS while the first tile's descriptor / index / row loads are in flight ----
+    {
+        int s0 = 0, off = 0;
+        for (int s = 0; s < p.nsrc; ++s) {
+            const int w = p.src[s].width;
+            stage_split<NS>(W1s, S1, s0, p.W1 + off, kin, p.hid, HB, w, false, 1, ((w + 31) >> 5) * 32);
+            off += w;
+            s0 += 2 * ((w + 31) >> 5);
+        }
+        stage_split<NS>(W2s, S2, 0, p.W2, p.hid, p.dout, OB, p.hid, true);
+    }
+    stage_vec(b1l, p.b1, p.hid, DPH, 0.f);
+    stage_vec(b2l, p.b2, p.dout, OP, 0.f);
+    stage_vec(gml, p.ln_w, p.dout, OP, 1.f);
+    stage_vec(btl, p.ln_b, p.dout, OP, 0.f);
+    __syncthreads();
 
     for (; gt < total_tiles; gt += stride) {
         const bool valid = j < tl.nrows;
@@ -1259,7 +1262,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_kernel(const nlam_mlp_b
     float acc_db1 = 0.f, acc_db2 = 0.f, acc_dg = 0.f, acc_dbt = 0.f;
 
     const long total_tiles = (long)p.ntiles * p.batch;
-    for (long gt = (long)blockIdx.x * kWavesPerBlock + wave; gt < total_tiles; gt += (long)gridDim.x * kWavesPerBlock) {
+    for (long gt = (long)wave * gridDim.x + blockIdx.x; gt < total_tiles; gt += (long)gridDim.x * kWavesPerBlock) {
         const int b = (int)(gt / p.ntiles);
         const int ti = (int)(gt % p.ntiles);
         const TileInfo tl = get_tile(p.tiles, ti, p.rows);
@@ -1561,7 +1564,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
     for (int k = 0; k < 8; ++k) colacc[k * 64] = 0.f;
 
     const long total_tiles = (long)p.ntiles * p.batch;
-    for (long gt = (long)blockIdx.x * kWavesPerBlock + wave; gt < total_tiles; gt += (long)gridDim.x * kWavesPerBlock) {
+    for (long gt = (long)wave * gridDim.x + blockIdx.x; gt < total_tiles; gt += (long)gridDim.x * kWavesPerBlock) {
         const int b = (int)(gt / p.ntiles);
         const TileInfo tl = get_tile(p.tiles, (int)(gt % p.ntiles), p.rows);
         const bool valid = j < tl.nrows;
@@ -2353,9 +2356,9 @@ int set_lds(K kernel, size_t bytes) {
     return 0;
 }
 
+// backward kernels: one persistent 8-wave workgroup per CU; tiles are dealt to workgroups first, then to waves
 int grid_blocks(long total_tiles) {
-    long need = (total_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (need < 1) need = 1;
+    long need = total_tiles < 1 ? 1 : total_tiles;
     return (int)(need < kMaxGridBlocks ? need : kMaxGridBlocks);
 }
 
@@ -2585,13 +2588,11 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
         else NLAM_LAUNCH_FWD_WIDE(8, 2);
         return (int32_t)hipGetLastError();
     }
-    // launch shape: one persistent workgroup per CU with up to kFwdWaves waves; launches with fewer
-    // tiles than kNumCUs * kFwdWaves use fewer waves per workgroup so the tiles still spread over all CUs
+    // launch shape: one persistent workgroup of kFwdWaves waves per CU (fewer workgroups than CUs only when there
+    // are fewer tiles than CUs); tiles are dealt to workgroups first, then to waves
     const long ttiles = (long)p->ntiles * p->batch;
-    long nw_l = (ttiles + kNumCUs - 1) / kNumCUs;
-    const int nwaves = (int)(nw_l < 1 ? 1 : (nw_l > kFwdWaves ? kFwdWaves : nw_l));
-    long need = (ttiles + nwaves - 1) / nwaves;
-    const int blocks = (int)(need < 1 ? 1 : (need < kMaxGridBlocks ? need : kMaxGridBlocks));
+    const int nwaves = kFwdWaves;
+    const int blocks = (int)(ttiles < 1 ? 1 : (ttiles < kMaxGridBlocks ? ttiles : kMaxGridBlocks));
     const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
     const bool fast_out = (p->hid % 32 == 0) && (p->dout % 32 == 0);
     bool fast = fast_out, w64 = true, ragged = false;
