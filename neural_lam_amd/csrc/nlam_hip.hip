@@ -843,6 +843,10 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int DPH = HB * 32, OP = OB * 32;
     constexpr int S2 = DPH / 16;
+    NLAM_T_DECL
+#ifdef NLAM_TIMING
+    int t_ntiles_ = 0;
+#endif
     constexpr int MAXU = RAG ? 2 : 2 * NLAM_MAX_SRC;  // 32-column units per tile row (widths <= 64; RAG: a single source)
 
     // every source is padded to whole 32-column units (zero weights / zero-filled loads past its width), so
@@ -968,8 +972,12 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
     stage_vec(gml, p.ln_w, p.dout, OP, 1.f);
     stage_vec(btl, p.ln_b, p.dout, OP, 0.f);
     __syncthreads();
+    NLAM_T_MARK(0)
 
     for (; gt < total_tiles; gt += stride) {
+#ifdef NLAM_TIMING
+        ++t_ntiles_;
+#endif
         const bool valid = j < tl.nrows;
         const int prow = tl.row0 + j;
         const bool has_next = gt + stride < total_tiles;
@@ -996,6 +1004,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
         int bnn = 0;
         if (gt + 2 * stride < total_tiles) tlnn = tile_of(gt + 2 * stride, bnn);
 
+        NLAM_T_MARK(1)
         // ---- GEMM1 over the resident rows ----
         f32x16 acc1[HB];
 #pragma unroll
@@ -1016,6 +1025,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
                 }
             }
         }
+        NLAM_T_MARK(2)
         // residual rows (C-layout chunks 8t + 4hi differ from the unit layout 8hi + ..: re-read below, ahead of the stores)
         const bool add0 = (p.flags & NLAM_F_ADD_SRC0) != 0 && p.out != nullptr;
         const bool add1 = (p.flags & NLAM_F_ADD_SRC1) != 0;
@@ -1055,6 +1065,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
             }
         }
 
+        NLAM_T_MARK(3)
         // ---- GEMM2 straight from the accumulators ----
         f32x16 acc2[OB];
 #pragma unroll
@@ -1072,6 +1083,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
                 mma_split_lds<NS, OB>(acc2, W2s, OB, S2, 2 * hb + h, lane, B);
             }
 
+        NLAM_T_MARK(4)
         // ---- bias 2 + LayerNorm ----
         float sum = 0.f;
 #pragma unroll
@@ -1122,6 +1134,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
             }
         }
 
+        NLAM_T_MARK(5)
         // ---- msg = mlp [+ src1]; aggregate; out = msg [+ src0] ----
         {
             float* obase = p.out != nullptr ? p.out + (long)b * p.out_bstride : nullptr;
@@ -1162,6 +1175,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
             }
         }
 
+        NLAM_T_MARK(6)
         // ---- rotate ----
         tl = tln;
         b = bn;
@@ -1173,6 +1187,9 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
             srow[s] = srow_n[s];
         }
     }
+    NLAM_T_DRAIN
+    NLAM_T_MARK(7)
+    NLAM_T_FLUSH(t_ntiles_)
 }
 
 // ---------------------------------------------------------------------------

@@ -176,7 +176,16 @@ class Trainer:
 
     def _graph_step(self, *batch):
         if self._graph is None:
-            self._capture(*batch)
+            try:
+                self._capture(*batch)
+            except Exception as exc:  # capture is an optimisation: never let it take the job down
+                import warnings
+
+                warnings.warn(f"HIP-graph capture of the training step failed ({exc!r}); continuing with eager launches")
+                self._graph = None
+                self.use_graph = False
+                torch.cuda.synchronize()
+                return self.step(*batch)
         for s, b in zip(self._static_in, batch):
             s.copy_(b)
         self._graph.replay()

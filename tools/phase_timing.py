@@ -66,8 +66,8 @@ def read(label, names):
     print(f"   total wave-cycles per tile {tot / tiles:.0f}")
 
 
-FWD = ["*prologue (weights -> LDS)", "desc -> idx -> src0 rows (drained)", "GEMM1 (+ src1/src2 row waits)", "bias, z1 store, SiLU",
-       "GEMM2", "LN, xhat/out stores, staging", "segment reduce", "*tail drain"]
+FWD = ["*prologue (first loads + weights -> LDS)", "tile top: late units, idx(n+1), epilogue idx", "GEMM1 (+ row waits)",
+       "resid, rows(n+1) issue, z1 store, SiLU", "GEMM2", "LN, xhat store", "msg, segment reduce, out store", "*tail drain"]
 for rep in range(3):
     out = net(send, rec, edge)  # edge kernel then node kernel
     torch.cuda.synchronize()

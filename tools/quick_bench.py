@@ -13,19 +13,25 @@ from neural_lam_amd.datastore import meps_like_datastore  # noqa: E402
 
 dev = torch.device("cuda:0")
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+model = sys.argv[2] if len(sys.argv) > 2 else "graph_lam"   # graph_lam | hi_lam | hi_lam_parallel
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 ds = meps_like_datastore("/tmp/nlam_qb")
 ext = ds.get_xy_extent("state")
 t0 = time.time()
-graph = G.normalise_graph(G.create_regular_grid_graph(ds.get_xy("state")), max(ext[1] - ext[0], ext[3] - ext[2]))
+hier = model != "graph_lam"
+graph = G.normalise_graph(G.create_regular_grid_graph(ds.get_xy("state"), n_max_levels=3 if hier else None, hierarchical=hier),
+                          max(ext[1] - ext[0], ext[3] - ext[2]))
 print(f"graph built in {time.time() - t0:.2f}s")
 torch.manual_seed(42)
-fc = hm.ARForecaster(hm.GraphLAM(ds, graph=graph, hidden_dim=d, processor_layers=4), ds)
+fc = hm.ARForecaster(hm.MODELS[model](ds, graph=graph, hidden_dim=d, processor_layers=L), ds)
+print(f"model {model} d={d} L={L} T={T} params={sum(p.numel() for p in fc.parameters())}")
 step = hm.ForecasterStep(fc, ds).to(dev)
 N = ds.num_grid_points
 torch.manual_seed(123)
 init = torch.randn(1, 2, N, 17, device=dev)
-target = torch.randn(1, 1, N, 17, device=dev)
-forcing = torch.randn(1, 1, N, 18, device=dev)
+target = torch.randn(1, T, N, 17, device=dev)
+forcing = torch.randn(1, T, N, 18, device=dev)
 params = [p for p in step.parameters()]
 opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.95))
 
