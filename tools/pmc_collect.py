@@ -45,7 +45,7 @@ def main():
             with open(f) as fh:
                 for row in csv.DictReader(fh):
                     k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-                    key = (k, row.get("Grid_Size", ""))
+                    key = (k, f'{row.get("Grid_Size", "")} lds={row.get("LDS_Block_Size", "")}')
                     stats[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for f in d.rglob("*kernel_trace.csv"):
             with open(f) as fh:
