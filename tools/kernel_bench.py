@@ -18,6 +18,7 @@ raw = G.create_regular_grid_graph(G.regular_grid_xy(238, 268))
 ei = raw[f"{which}_edge_index"] if which != "m2m" else raw["m2m_edge_index"][0]
 ns, nr, E = int(ei[0].max()) + 1, int(ei[1].max()) + 1, ei.shape[1]
 d = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+stage = sys.argv[4] if len(sys.argv) > 4 else "layer"   # layer | edge (edge kernel + its backward only: unambiguous PMC rows)
 torch.manual_seed(0)
 net = hl.InteractionNet(ei, d, update_edges=(which == "m2m")).to(dev)
 send = torch.randn(1, ns, d, device=dev, requires_grad=True)
@@ -25,6 +26,10 @@ rec = torch.randn(1, nr, d, device=dev, requires_grad=True)
 edge = torch.randn(1, E, d, device=dev, requires_grad=True)
 ops.PROFILE.reset(enabled=True)
 for _ in range(reps):
+    if stage == "edge":
+        aggr, eo = net._messages_and_aggregate(send, rec, edge, net.update_edges, True)
+        (aggr.sum() + (eo.sum() if eo is not None else 0.0)).backward()
+        continue
     out = net(send, rec, edge)
     outs = out if isinstance(out, tuple) else (out,)
     sum(o.sum() for o in outs).backward()
