@@ -838,7 +838,10 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
 //   SiLU, GEMM2, LayerNorm, then ALL stores of tile n (z1, xhat, aggr / out)
 // ---------------------------------------------------------------------------
 // RAG = some source is narrower than / not a multiple of a 32-column unit (element-wise, zero-filled loads)
-template <int HB, int OB, int NS, bool RAG>
+// RES = the launch adds a residual row (NLAM_F_ADD_SRC0 with an output, or NLAM_F_ADD_SRC1): only then are the 32
+// VGPRs of the stashed residual chunks allocated (the kernel sits at the 256-VGPR limit; spills are VMEM ops and
+// would queue behind the tile's stores)
+template <int HB, int OB, int NS, bool RAG, bool RES>
 __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_fwd_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int DPH = HB * 32, OP = OB * 32;
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[hb][r] = 0.f;
-        f32x4 resid[2][4];   // the 64 columns of source 0 (edge / node residual) or source 1 (PropagationNet)
+        f32x4 resid[RES ? 2 : 1][4];   // the 64 columns of source 0 (edge / node residual) or source 1 (PropagationNet)
 #pragma unroll
         for (int u = 0; u < MAXU; ++u) {
             if (u < nunits) {
@@ -1027,15 +1030,15 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
         }
         NLAM_T_MARK(2)
         // residual rows (C-layout chunks 8t + 4hi differ from the unit layout 8hi + ..: re-read below, ahead of the stores)
-        const bool add0 = (p.flags & NLAM_F_ADD_SRC0) != 0 && p.out != nullptr;
-        const bool add1 = (p.flags & NLAM_F_ADD_SRC1) != 0;
-        if (add0 || add1) {
+        const bool add0 = RES && (p.flags & NLAM_F_ADD_SRC0) != 0 && p.out != nullptr;
+        const bool add1 = RES && (p.flags & NLAM_F_ADD_SRC1) != 0;
+        if (RES && (add0 || add1)) {
             const float* rr = add1 ? srow[1] : srow[0];
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
-                    if (ob < OB) resid[ob][tt] = *reinterpret_cast<const f32x4*>(rr + 8 * (ob * 4 + tt) + 4 * hi);
+                    if (ob < OB) resid[RES ? ob : 0][tt] = *reinterpret_cast<const f32x4*>(rr + 8 * (ob * 4 + tt) + 4 * hi);
         }
         // ---- rows of tile n+1 into the same registers (still ahead of every store of tile n) ----
         const float* srow_n[NLAM_MAX_SRC] = {nullptr, nullptr, nullptr};
@@ -1145,7 +1148,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     m[tt] = acc_chunk(acc2[ob], tt);
-                    if (add1) m[tt] += resid[ob][tt];
+                    if (add1) m[tt] += resid[RES ? ob : 0][tt];
                     if (!valid) m[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 if (p.aggr != nullptr) {
@@ -1163,7 +1166,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
                             if (add1)
                                 m[tt] += *reinterpret_cast<const f32x4*>(srow[0] + 8 * (ob * 4 + tt) + 4 * hi);
                             else
-                                m[tt] += resid[ob][tt];
+                                m[tt] += resid[RES ? ob : 0][tt];
                         }
                         *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = m[tt];
                     }
@@ -2542,17 +2545,18 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
         if (rc != 0) return rc;                                                                                        \
         hipLaunchKernelGGL((mlp_fwd_kernel<HB_, OB_, FAST_, NS_>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p);  \
     } while (0)
-#define NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, RAG_)                                                                          \
-    do {                                                                                                                \
-        const size_t lds = fwd_lds_bytes(p, HB_, OB_, NS_);                                                             \
-        int rc = set_lds(mlp_fwd_bf_kernel<HB_, OB_, NS_, RAG_>, lds);                                                  \
-        if (rc != 0) return rc;                                                                                         \
-        hipLaunchKernelGGL((mlp_fwd_bf_kernel<HB_, OB_, NS_, RAG_>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p); \
+#define NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, RAG_, RES_)                                                                          \
+    do {                                                                                                                      \
+        const size_t lds = fwd_lds_bytes(p, HB_, OB_, NS_);                                                                   \
+        int rc = set_lds(mlp_fwd_bf_kernel<HB_, OB_, NS_, RAG_, RES_>, lds);                                                  \
+        if (rc != 0) return rc;                                                                                               \
+        hipLaunchKernelGGL((mlp_fwd_bf_kernel<HB_, OB_, NS_, RAG_, RES_>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p); \
     } while (0)
-#define NLAM_LAUNCH_FWDBF(HB_, OB_, NS_)                \
-    do {                                                \
-        if (ragged) NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, true); \
-        else NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, false);  \
+#define NLAM_LAUNCH_FWDBF(HB_, OB_, NS_)                               \
+    do {                                                               \
+        if (ragged) NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, true, false);    \
+        else if (resid) NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, false, true); \
+        else NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, false, false);          \
     } while (0)
 #define NLAM_LAUNCH_FWD(HB_, OB_)                            \
     do {                                                     \
@@ -2619,6 +2623,8 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
         ragged = ragged || (p->src[s].width % 32 != 0);
     }
     if (ragged && p->nsrc != 1) w64 = false;   // ragged inputs are covered for single-source MLPs (embedders, grid MLPs)
+    const bool resid = ((p->flags & NLAM_F_ADD_SRC0) != 0 && p->out != nullptr) || (p->flags & NLAM_F_ADD_SRC1) != 0;
+    if (ragged && resid) w64 = false;
     if ((p->flags & (NLAM_F_ADD_SRC0 | NLAM_F_ADD_SRC1)) != 0) {   // residual rows are read as whole 16-B chunks
         const int rs = (p->flags & NLAM_F_ADD_SRC1) ? 1 : 0;
         w64 = w64 && (p->src[rs].width % 32 == 0) && ((p->flags & NLAM_F_ADD_SRC0) == 0 || p->src[0].width % 32 == 0);
