@@ -6,6 +6,7 @@ There is deliberately no eager / CPU fallback: CPU tensors raise.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from dataclasses import dataclass, field
@@ -44,6 +45,36 @@ def _mm_flags() -> int:
 # into those views inside the partial-sum reduction and returns None for them: ~6 AccumulateGrad add
 # launches per MLP (~130 per step at cfg2) disappear.
 DIRECT_PARAM_GRADS = False
+
+
+class _WgradOverlap:
+    """Weight-gradient kernels on a second HIP stream.
+
+    The weight / bias / LayerNorm gradients of a fused MLP are needed only by the optimizer, not by the rest of
+    backward, and at cfg2 sizes they are ~40 latency-bound launches per step.  While a trainer has this switched on
+    (and owns the parameter gradients, DIRECT_PARAM_GRADS), FusedMLPFunction.backward forks them onto a side stream
+    right after the data-gradient kernel; ``end()`` joins before the optimizer.  Inside a HIP-graph capture the fork /
+    join become parallel branches of the graph.  Tensors the side stream reads are kept alive until the join."""
+
+    def __init__(self):
+        self.stream = None
+        self.active = False
+        self.keep = []
+
+    def begin(self):
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.active = True
+        self.keep = []
+
+    def end(self):
+        if self.active:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep = []
+        self.active = False
+
+
+OVERLAP = _WgradOverlap()
 
 
 def _stream():
@@ -314,6 +345,30 @@ class FusedMLPFunction(torch.autograd.Function):
                 )
 
         # ---- weight gradients: two TN GEMMs with deterministic two-stage reduction ----
+        # ---- weight gradients: TN GEMMs with a deterministic two-stage reduction; on the side stream when the
+        # trainer owns the parameter gradients (see _WgradOverlap) ----
+        prm = ctx.param_refs
+
+        def is_direct(param, shape):
+            return (
+                DIRECT_PARAM_GRADS and param is not None and param.grad is not None and param.grad.is_contiguous()
+                and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32
+            )
+
+        wanted = [  # (slot, needs_grad, param, shape)
+            (0, ctx.needs_input_grad[1], prm[0], (hid, kin)), (1, ctx.needs_input_grad[2], prm[1], (hid,)),
+            (2, ctx.needs_input_grad[3], prm[2], (dout, hid)), (3, ctx.needs_input_grad[4], prm[3], (dout,)),
+            (4, ctx.has_ln and ctx.needs_input_grad[5], prm[4], (dout,)),
+            (5, ctx.has_ln and ctx.needs_input_grad[6], prm[5], (dout,)),
+        ]
+        on_side = OVERLAP.active and all(is_direct(pp, sh) for _, need, pp, sh in wanted if need)
+        if on_side:
+            OVERLAP.stream.wait_stream(torch.cuda.current_stream())
+            OVERLAP.keep.extend([dz1, dz2, vecp, z1, *bases])
+            side_ctx = torch.cuda.stream(OVERLAP.stream)
+        else:
+            side_ctx = contextlib.nullcontext()
+
         def wgrad(A, m, src_list, n, flags):
             q = L.Wgrad()
             q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(src_list), flags, n
@@ -330,48 +385,47 @@ class FusedMLPFunction(torch.autograd.Function):
         for k in range(nsrc):
             b_, bstride = ctx.binfo[k]
             src_list.append((bases[k], bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k]))
-        part1 = wgrad(dz1, hid, src_list, kin, 0) if ctx.needs_input_grad[1] else None
-        part2 = wgrad(dz2, dout, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if ctx.needs_input_grad[3] else None
-
-        # ---- one launch reduces every partial sum; with DIRECT_PARAM_GRADS it accumulates into .grad ----
-        prm = ctx.param_refs
-        jobs = L.ReduceJobs()
         results = [None] * 6   # dW1, db1, dW2, db2, dgamma, dbeta
-        keep = []
+        with side_ctx:
+            part1 = wgrad(dz1, hid, src_list, kin, 0) if ctx.needs_input_grad[1] else None
+            part2 = wgrad(dz2, dout, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if ctx.needs_input_grad[3] else None
 
-        def add_job(slot, partials_ptr, nparts, stride, shape, param):
-            n = 1
-            for d_ in shape:
-                n *= d_
-            direct = (
-                DIRECT_PARAM_GRADS and param is not None and param.grad is not None and param.grad.is_contiguous()
-                and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32
-            )
-            if direct:
-                out = param.grad
-            else:
-                out = torch.empty(shape, device=dev, dtype=torch.float32)
-                results[slot] = out
-            keep.append(out)
-            j = jobs.job[jobs.njobs]
-            j.partials, j.out, j.stride, j.nparts, j.n, j.accumulate = partials_ptr, _ptr(out), stride, nparts, n, 1 if direct else 0
-            jobs.njobs += 1
+            # ---- one launch reduces every partial sum; with DIRECT_PARAM_GRADS it accumulates into .grad ----
+            jobs = L.ReduceJobs()
+            keep = []
 
-        vbase = vecp.data_ptr()
-        if part1 is not None:
-            add_job(0, _ptr(part1), part1.shape[0], hid * kin, (hid, kin), prm[0])
-        if ctx.needs_input_grad[2]:
-            add_job(1, vbase + 0 * vs * 4, nblk, 4 * vs, (hid,), prm[1])
-        if part2 is not None:
-            add_job(2, _ptr(part2), part2.shape[0], dout * hid, (dout, hid), prm[2])
-        if ctx.needs_input_grad[4]:
-            add_job(3, vbase + 1 * vs * 4, nblk, 4 * vs, (dout,), prm[3])
-        if ctx.has_ln and ctx.needs_input_grad[5]:
-            add_job(4, vbase + 2 * vs * 4, nblk, 4 * vs, (dout,), prm[4])
-        if ctx.has_ln and ctx.needs_input_grad[6]:
-            add_job(5, vbase + 3 * vs * 4, nblk, 4 * vs, (dout,), prm[5])
-        if jobs.njobs > 0:
-            L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
+            def add_job(slot, partials_ptr, nparts, stride, shape, param):
+                n = 1
+                for d_ in shape:
+                    n *= d_
+                direct = is_direct(param, shape)
+                if direct:
+                    out = param.grad
+                else:
+                    out = torch.empty(shape, device=dev, dtype=torch.float32)
+                    results[slot] = out
+                keep.append(out)
+                j = jobs.job[jobs.njobs]
+                j.partials, j.out, j.stride, j.nparts, j.n, j.accumulate = partials_ptr, _ptr(out), stride, nparts, n, 1 if direct else 0
+                jobs.njobs += 1
+
+            vbase = vecp.data_ptr()
+            if part1 is not None:
+                add_job(0, _ptr(part1), part1.shape[0], hid * kin, (hid, kin), prm[0])
+            if ctx.needs_input_grad[2]:
+                add_job(1, vbase + 0 * vs * 4, nblk, 4 * vs, (hid,), prm[1])
+            if part2 is not None:
+                add_job(2, _ptr(part2), part2.shape[0], dout * hid, (dout, hid), prm[2])
+            if ctx.needs_input_grad[4]:
+                add_job(3, vbase + 1 * vs * 4, nblk, 4 * vs, (dout,), prm[3])
+            if ctx.has_ln and ctx.needs_input_grad[5]:
+                add_job(4, vbase + 2 * vs * 4, nblk, 4 * vs, (dout,), prm[4])
+            if ctx.has_ln and ctx.needs_input_grad[6]:
+                add_job(5, vbase + 3 * vs * 4, nblk, 4 * vs, (dout,), prm[5])
+            if jobs.njobs > 0:
+                L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
+            if on_side:
+                OVERLAP.keep.extend([part1, part2])
         dW1, db1, dW2, db2, dg, dbt = results
 
         grads_src = []

@@ -125,9 +125,11 @@ class Trainer:
     """
 
     def __init__(self, module: nn.Module, lr=1e-3, betas=(0.9, 0.95), weight_decay=1e-2, eps=1e-8,
-                 bucket_bytes: int = 32 << 20, optimizer_factory=None, group=None, use_graph: bool = False):
+                 bucket_bytes: int = 32 << 20, optimizer_factory=None, group=None, use_graph: bool = False,
+                 overlap_wgrad: bool = True):
         self.module = module
         self.use_graph = use_graph
+        self.overlap_wgrad = overlap_wgrad
         try:   # the fused-MLP backward may now add parameter gradients straight into the flat views
             from . import ops
 
@@ -149,10 +151,27 @@ class Trainer:
 
     # ---- HIP-graph step: zero-grad + forward + loss + backward are ~330 launches of 3-150 us at cfg2,
     # which eager Python cannot issue as fast as the GPU retires them; captured once, replayed per step ----
+    def _backward(self, loss):
+        """backward with the weight-gradient kernels forked onto a second stream (ops._WgradOverlap)."""
+        ov = None
+        try:
+            from . import ops
+
+            ov = ops.OVERLAP if loss.is_cuda and self.overlap_wgrad else None
+        except Exception:
+            ov = None
+        if ov is not None:
+            ov.begin()
+        try:
+            loss.backward()
+        finally:
+            if ov is not None:
+                ov.end()
+
     def _fwd_bwd(self):
         out = self.module(*self._static_in)
         loss = out[-1] if isinstance(out, tuple) else out
-        loss.backward()
+        self._backward(loss)
         return loss.detach()   # nothing that references the autograd graph survives this frame
 
     def _capture(self, *batch):
@@ -202,7 +221,7 @@ class Trainer:
         self.buckets.begin_step()
         out = self.module(*batch)
         loss = out[-1] if isinstance(out, tuple) else out
-        loss.backward()
+        self._backward(loss)
         self.buckets.finish_step()
         self.opt.step(1.0 / self.world)
         return loss.detach()
