@@ -26,37 +26,75 @@ from .ops import FusedMLPFunction, MlpGeometry, as_batched, segment_sum
 
 
 class FusedMLP(nn.Sequential):
-    """``Linear -> SiLU -> Linear [-> LayerNorm]`` with the reference's child
-    names (``0``, ``2``, ``3``), executed as one HIP kernel."""
+    """``[Linear -> SiLU] * hidden_layers -> Linear [-> LayerNorm]`` with the reference's child names
+    (``0``, ``2``, ..: Linear; last: LayerNorm; utils/networks.py:8-40).
+
+    ``hidden_layers == 1`` (every BASELINE config, the reference's default) is ONE fused HIP kernel and can take
+    the gather / concat / residual / aggregation geometry of the GNN layers.  Other depths are composed: the
+    trailing ``Linear -> SiLU -> Linear [-> LayerNorm]`` pairs run on the fused kernel, a leftover leading
+    ``Linear -> SiLU`` (odd number of Linears) and the ``hidden_layers == 0`` case go through the ROCm library GEMM
+    (``F.linear``); the GNN layers then use their explicit-gather path.  GPU only either way."""
 
     def __init__(self, blueprint, layer_norm: bool = True):
         hidden_layers = len(blueprint) - 2
         assert hidden_layers >= 0, "Invalid MLP blueprint"
-        if hidden_layers != 1:
-            raise NotImplementedError(
-                "the fused gfx950 kernels cover hidden_layers == 1 (every BASELINE config); "
-                f"got a blueprint with {hidden_layers} hidden layers"
-            )
-        layers = [nn.Linear(blueprint[0], blueprint[1]), nn.SiLU(), nn.Linear(blueprint[1], blueprint[2])]
+        layers = []
+        for i, (d1, d2) in enumerate(zip(blueprint[:-1], blueprint[1:])):
+            layers.append(nn.Linear(d1, d2))
+            if i != hidden_layers:
+                layers.append(nn.SiLU())
         if layer_norm:
-            layers.append(nn.LayerNorm(blueprint[2]))
+            layers.append(nn.LayerNorm(blueprint[-1]))
         super().__init__(*layers)
         self.has_layer_norm = layer_norm
+        self.hidden_layers = hidden_layers
         self._geom = MlpGeometry(nsrc=1)
 
+    @property
+    def fully_fused(self) -> bool:
+        return self.hidden_layers == 1
+
+    def _linears(self):
+        return [m for m in self if isinstance(m, nn.Linear)]
+
     def params(self):
-        ln = self[3] if self.has_layer_norm else None
+        """(W1, b1, W2, b2, ln_w, ln_b) of the last ``Linear -> SiLU -> Linear [-> LN]`` block."""
+        lin = self._linears()
+        ln = self[len(self) - 1] if self.has_layer_norm else None
         return (
-            self[0].weight, self[0].bias, self[2].weight, self[2].bias,
+            lin[-2].weight, lin[-2].bias, lin[-1].weight, lin[-1].bias,
             ln.weight if ln is not None else None, ln.bias if ln is not None else None,
         )
 
     def forward(self, x):
-        out, _ = FusedMLPFunction.apply(self._geom, *self.params(), x)
-        return out
+        if not x.is_cuda:
+            raise RuntimeError("neural_lam_amd layers run on MI355X only (no CPU / eager fallback; see oracle/ for a CPU reference)")
+        lin = self._linears()
+        n = len(lin)
+        if n == 1:   # hidden_layers == 0: Linear [-> LayerNorm]
+            y = torch.nn.functional.linear(x, lin[0].weight, lin[0].bias)
+            if self.has_layer_norm:
+                ln = self[len(self) - 1]
+                y = torch.nn.functional.layer_norm(y, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+            return y
+        k = 0
+        if n % 2 == 1:   # leftover leading Linear -> SiLU
+            x = torch.nn.functional.silu(torch.nn.functional.linear(x, lin[0].weight, lin[0].bias))
+            k = 1
+        while k < n:
+            last = k + 2 == n
+            ln = self[len(self) - 1] if (last and self.has_layer_norm) else None
+            out, _ = FusedMLPFunction.apply(
+                self._geom, lin[k].weight, lin[k].bias, lin[k + 1].weight, lin[k + 1].bias,
+                ln.weight if ln is not None else None, ln.bias if ln is not None else None, x,
+            )
+            x = out if last else torch.nn.functional.silu(out)
+            k += 2
+        return x
 
     def forward_fused(self, geom: MlpGeometry, *srcs):
-        """Run with a caller-supplied geometry (concatenated sources, residuals, ...)."""
+        """Run with a caller-supplied geometry (concatenated sources, residuals, ...); hidden_layers == 1 only."""
+        assert self.fully_fused
         return FusedMLPFunction.apply(geom, *self.params(), *srcs)
 
 
@@ -128,6 +166,7 @@ class InteractionNet(nn.Module):
         )
         edge_recipe = [3 * input_dim] + [hidden_dim] * (hidden_layers + 1)
         aggr_recipe = [2 * input_dim] + [hidden_dim] * (hidden_layers + 1)
+        self.hidden_layers = hidden_layers
         if edge_chunk_sizes is None:
             self.edge_mlp = make_mlp(edge_recipe)
         else:
@@ -211,7 +250,7 @@ class InteractionNet(nn.Module):
         """-> (aggr, edge_out | None); edge_out = msg (+ edge_rep if add_edge), original edge order."""
         self._check_inputs(send_rep, rec_rep, edge_rep)
         csr = self._csr(send_rep.device, send_rep.shape[-2])
-        if isinstance(self.edge_mlp, SplitMLPs):
+        if isinstance(self.edge_mlp, SplitMLPs) or not self.edge_mlp.fully_fused:
             return self._messages_generic(csr, send_rep, rec_rep, edge_rep, want_out, add_edge)
         geom = self._edge_geom(csr, want_out, add_edge, (str(send_rep.device), send_rep.shape[-2]))
         edge_out, aggr = self.edge_mlp.forward_fused(geom, edge_rep, send_rep, rec_rep)
@@ -233,7 +272,7 @@ class InteractionNet(nn.Module):
         return aggr, edge_out
 
     def _node_update(self, rec_rep, aggr):
-        if isinstance(self.aggr_mlp, SplitMLPs):
+        if isinstance(self.aggr_mlp, SplitMLPs) or not self.aggr_mlp.fully_fused:
             rec_diff = self.aggr_mlp(torch.cat((rec_rep, aggr), dim=-1))
             return self.node_residual_target(rec_rep, aggr) + rec_diff
         out, _ = self.aggr_mlp.forward_fused(self._node_geom(), rec_rep, aggr)

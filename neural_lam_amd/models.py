@@ -247,7 +247,10 @@ class BaseGraphModel(StepPredictor):
         mesh_rep = self.g2m_gnn(
             grid_emb, self.expand_to_batch(st["mesh"], B), self.expand_to_batch(st["g2m"], B)
         )
-        grid_rep, _ = self.encoding_grid_mlp.forward_fused(self._enc_geom, grid_emb)  # graph/base.py:308
+        if self.encoding_grid_mlp.fully_fused:
+            grid_rep, _ = self.encoding_grid_mlp.forward_fused(self._enc_geom, grid_emb)  # graph/base.py:308
+        else:
+            grid_rep = grid_emb + self.encoding_grid_mlp(grid_emb)
         mesh_rep = self.process_step(mesh_rep, st)
         grid_rep = self.m2g_gnn(mesh_rep, grid_rep, self.expand_to_batch(st["m2g"], B))
         net_output = self.output_map(grid_rep)

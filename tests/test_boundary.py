@@ -106,9 +106,18 @@ def test_sequential_child_names_follow_pyg():
         hl.make_gnn_seq(_edge_index(5, 5), 0, 1, 8)
 
 
-def test_unsupported_depth_raises():
-    with pytest.raises(NotImplementedError):
-        hl.make_mlp([8, 8, 8, 8])
+def test_other_depths_keep_reference_structure():
+    """hidden_layers != 1 (utils/networks.py:8-40): same children / parameter names as the reference's Sequential."""
+    from oracle import gnn_layers as og
+
+    for h in (0, 2, 3):
+        bp = [6] + [8] * (h + 1)
+        mine, ref = hl.make_mlp(bp), og.make_mlp(bp)
+        assert list(mine.state_dict().keys()) == list(ref.state_dict().keys())
+        assert [type(m).__name__ for m in mine] == [type(m).__name__ for m in ref]
+        with pytest.raises(RuntimeError):   # no CPU / eager fallback at any depth
+            mine(torch.zeros(3, 6))
+
 
 
 def test_tile_schedule_covers_every_edge_and_receiver_once():

@@ -488,3 +488,50 @@ def test_hip_graph_step_equals_eager_step(dev, tmp_path):
         le, lg = float(t_eager.step(*batch)), float(t_graph.step(*batch))
         assert le == lg
         assert torch.equal(t_eager.fp.flat, t_graph.fp.flat) and torch.equal(t_eager.fp.grad, t_graph.fp.grad)
+
+
+@pytest.mark.parametrize("hidden_layers", [0, 2, 3])
+def test_other_mlp_depths_match_oracle(dev, hidden_layers):
+    """utils.make_mlp with hidden_layers != 1 (utils/networks.py:8-40): composed from the fused kernel + library GEMMs."""
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    torch.manual_seed(hidden_layers)
+    bp = [24] + [64] * (hidden_layers + 1)
+    ref, net = og.make_mlp(bp), hl.make_mlp(bp)
+    assert list(ref.state_dict().keys()) == list(net.state_dict().keys())
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    x = torch.randn(2, 700, 24)
+    x1, x2 = x.clone().requires_grad_(), x.to(dev).requires_grad_()
+    y1, y2 = ref(x1), net(x2)
+    assert rel_err(y2.cpu(), y1) < TOL
+    y1.sin().sum().backward()
+    y2.sin().sum().backward()
+    assert rel_err(x2.grad.cpu(), x1.grad) < TOL
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < TOL, k
+
+
+def test_interaction_net_with_two_hidden_layers(dev):
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    ei = _rand_ei(23, 19, 211, seed=5)
+    torch.manual_seed(5)
+    ref = og.InteractionNet(ei, 32, hidden_layers=2)
+    net = hl.InteractionNet(ei, 32, hidden_layers=2)
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    send, rec, edge = torch.randn(2, 23, 32), torch.randn(2, 19, 32), torch.randn(2, 211, 32)
+    s1, r1, e1 = (t.clone().requires_grad_() for t in (send, rec, edge))
+    s2, r2, e2 = (t.to(dev).requires_grad_() for t in (send, rec, edge))
+    o1, o2 = ref(s1, r1, e1), net(s2, r2, e2)
+    for a, b in zip(o2, o1):
+        assert rel_err(a.cpu(), b) < TOL
+    sum(o.square().sum() for o in o1).backward()
+    sum(o.square().sum() for o in o2).backward()
+    for a, b in ((s2, s1), (r2, r1), (e2, e1)):
+        assert rel_err(a.grad.cpu(), b.grad) < TOL
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < TOL, k
