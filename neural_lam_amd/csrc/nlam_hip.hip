@@ -2192,8 +2192,20 @@ __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32
         float* o = out + ((size_t)b * nseg + sgm) * width + 4 * c4;
         const float sc = scale != nullptr ? scale[sgm] : 1.f;
         if ((width & 3) == 0) {
+            // 8 gathered rows in flight per thread (segments of the sender view are ~40 edges long: a plain
+            // dependent loop is latency-bound); fixed summation order
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int q = lo; q < hi_; ++q) {
+            int q = lo;
+            for (; q + 8 <= hi_; q += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const long row = order != nullptr ? order[q + u] : q + u;
+                    v[u] = *reinterpret_cast<const f32x4*>(base + row * width + 4 * c4);
+                }
+                acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            for (; q < hi_; ++q) {
                 const long row = order != nullptr ? order[q] : q;
                 acc += *reinterpret_cast<const f32x4*>(base + row * width + 4 * c4);
             }
