@@ -1527,6 +1527,10 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
     constexpr int NSW = NS > 0 ? NS : 1;
     constexpr int T2 = OP / 8, T1 = DPH / 8;     // fp32 K chunks of dh (K = dout) and dx (K = hid)
     constexpr int S2 = OP / 16, S1 = DPH / 16;   // split-bf16 K steps
+    NLAM_T_DECL
+#ifdef NLAM_TIMING
+    int t_ntiles_ = 0;
+#endif
 
     int kin = 0;
     for (int s = 0; s < p.nsrc; ++s) kin += p.src[s].width;
@@ -1566,6 +1570,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
     }
     stage_vec(gml, p.ln_w, p.dout, OP, 1.f);
     __syncthreads();
+    NLAM_T_MARK(0)
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1593,6 +1598,9 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
         const size_t srow_c = (size_t)b * p.rows + prow_c;
         const size_t tile_row0 = (size_t)b * p.rows + tl.row0;
 
+#ifdef NLAM_TIMING
+        ++t_ntiles_;
+#endif
         // ---- indices ----
         int oidx = prow_c;
         if (p.g_out != nullptr && p.out_idx != nullptr) oidx = p.out_idx[prow_c];
@@ -1614,6 +1622,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
         const float* xrow = has_ln ? p.xhat + srow_c * p.dout : nullptr;
         const float* zrow = p.z1 + srow_c * p.hid;
 
+        NLAM_T_MARK(1)
         // ---- dmsg (C-layout chunks), LayerNorm backward ----
         f32x16 dz2[OB];
         {
@@ -1674,6 +1683,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
                     }
             }
         }
+        NLAM_T_MARK(2)
         // ---- dz2 rows out (for wgrad) + db2 ----
 #pragma unroll
         for (int ob = 0; ob < OB; ++ob) {
@@ -1688,6 +1698,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
             wave_lds_sync();
         }
 
+        NLAM_T_MARK(3)
         // ---- dh = W2^T dz2 ; dz1 = dh * silu'(z1) ----
         f32x16 dz1[HB];
 #pragma unroll
@@ -1733,6 +1744,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
             wave_lds_sync();
         }
 
+        NLAM_T_MARK(4)
         // ---- dx_s = W1_s^T dz1 per source ----
         // split-bf16: the B fragments of dz1 are the same for every source -- convert once
         BfFrag<NSW> bz[NS > 0 ? HB * 2 : 1];
@@ -1819,8 +1831,12 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
                 wave_lds_sync();
             }
         }
+        NLAM_T_MARK(5)
     }
 
+    NLAM_T_DRAIN
+    NLAM_T_MARK(6)
+    NLAM_T_FLUSH(t_ntiles_)
     // ---- combine the waves' column partials through LDS; one row per workgroup ----
     if (p.vec_partials != nullptr) {
         __syncthreads();

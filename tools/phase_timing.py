@@ -80,3 +80,10 @@ with torch.no_grad():
 read(f"edge fwd (inference mode) {which} d={d}", FWD)
 out = timed(lambda: net._node_update(rec, aggr.detach()))
 read(f"node fwd {which} d={d} N={nr}", FWD)
+
+BWD = ["*prologue (weights -> LDS)", "indices", "dmsg loads, LN backward, dbeta/dgamma", "dz2 rows out + db2",
+       "dh GEMM, silu', dz1 rows out + db1", "dx GEMMs + data-gradient outputs", "*tail drain", "-"]
+aggr, eo = net._messages_and_aggregate(send, rec, edge, net.update_edges, True)
+lib.nlam_debug_phase_cycles(buf)
+(aggr.sum() + (eo.sum() if eo is not None else 0.0)).backward()
+read(f"edge bwd {which} d={d} E={E} (counters also include the 2 wgrad kernels: none instrumented)", BWD)
