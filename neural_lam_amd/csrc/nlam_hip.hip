@@ -1627,9 +1627,10 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
         f32x16 dz2[OB];
         {
             float m1 = 0.f, m2 = 0.f;
+            f32x4 xhs[OB][4];   // xhat stays in registers between its two uses (the big edge sets are HBM-bound: one read)
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob) {
-                f32x4 xh[4];   // xhat is read twice (here and after the row sums) instead of living in 16*OB VGPRs
+                f32x4(&xh)[4] = xhs[ob];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
@@ -1674,7 +1675,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
                 for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
-                        const f32x4 xh = *reinterpret_cast<const f32x4*>(xrow + 8 * (ob * 4 + tt) + 4 * hi);
+                        const f32x4 xh = xhs[ob][tt];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const float v = rstd * (dz2[ob][4 * tt + c] - m1 - xh[c] * m2);
