@@ -1,22 +1,28 @@
 // nlam_hip.hip -- gfx950 (MI355X, CDNA4) kernels behind include/nlam_hip.h.
 //
-// Design (see DESIGN.md for the full derivation):
-//  * One *wave* owns a tile of <= 32 rows (edges in receiver-sorted CSR order, or
-//    nodes).  The tile is the N (column) side of v_mfma_f32_32x32x2_f32; the
-//    weight matrix is the A operand (rows = output features).  In this
-//    "transposed" form the accumulator layout of GEMM1 *is* the B-operand layout
-//    of GEMM2 (K order is a free permutation, applied to the weights once when
-//    they are staged into LDS), so Linear -> SiLU -> Linear -> LayerNorm runs
-//    register to register with no LDS round trip and no shuffles.
-//  * Weights are staged once per persistent workgroup into LDS in a "packed"
-//    order so every lane fetches the A operands of four MFMAs with one
-//    conflict-free ds_read_b128.
-//  * Tiles consist of whole receivers (host-built schedule), so the segment
-//    reduction (sum / mean aggregation) happens inside the wave through an LDS
-//    staging buffer with plain stores: no atomics, deterministic.  Receivers with
-//    in-degree > 32 are split over several tiles and only those use atomics.
-//  * fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf
-//    chain, so parity with the fp32 oracle is at rounding-order level.
+// Design (DESIGN.md has the derivation and the measurements behind each choice):
+//  * d <= 64: one *wave* owns a tile of <= 32 rows (edges in receiver-sorted CSR order, or
+//    nodes).  The tile is the N (column) side of the MFMA; the weight matrix is the A
+//    operand (rows = output features), staged once per persistent workgroup into LDS.  In
+//    this transposed form the accumulator layout of GEMM1 *is* the B-operand layout of
+//    GEMM2 (the K order is a permutation applied to the weights when they are staged), so
+//    Linear -> SiLU -> Linear -> LayerNorm runs register to register.
+//  * Matrix path: fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fmaf chains; it shares the fp32
+//    vector lanes with VALU work) or, by default, the bf16 matrix cores with every fp32
+//    operand split into 3 bf16 terms (6 MFMAs per product block, fp32 accumulate: fp32-class
+//    accuracy, co-issues with VALU).  Kernel families:
+//      mlp_fwd_bf_kernel      forward, split-bf16, software-pipelined across tiles
+//      mlp_fwd_kernel         forward, fp32 MFMA: FAST shapes and the fully generic path
+//      mlp_bwd_fast_kernel    backward, FAST shapes, fp32 or split-bf16
+//      mlp_bwd_kernel         backward, generic shapes
+//      wgrad_dma_kernel / wgrad_kernel / wgrad_smalln_kernel   weight gradients (LDS-DMA row streaming /
+//                             odd widths / 2-3 column inputs), reduce_jobs_kernel their deterministic 2nd stage
+//      nlam_wide.inc          64 < d <= 512: workgroup-cooperative forward / backward / weight gradients
+//  * Tiles consist of whole receivers (host-built schedule), so the segment reduction (sum /
+//    mean aggregation) happens inside the wave through an LDS block with plain stores: no
+//    atomics, deterministic.  Receivers with in-degree > 32 are split over several tiles and
+//    only those use atomics.
+//  * Every row store goes through a per-wave [32][36] LDS block and leaves as whole 128-B lines.
 //
 // "chunk" below always means: 4 consecutive features [8t + 4hi, 8t + 4hi + 4) of
 // one row, held by lane (j = lane & 31, hi = lane >> 5) as one float4.
@@ -371,15 +377,6 @@ __device__ __forceinline__ BfFrag<NS> split8(const float (&x)[8]) {
     return f;
 }
 
-// acc += sum_{p+q < NS} A_p B_q ; smallest terms first
-template <int NS>
-__device__ __forceinline__ void mma_split(f32x16& acc, const BfFrag<NS>& A, const BfFrag<NS>& B) {
-#pragma unroll
-    for (int ord = NS - 1; ord >= 0; --ord)
-#pragma unroll
-        for (int pa = 0; pa <= ord; ++pa) acc = MFMA_BF16(A.t[pa], B.t[ord - pa], acc);
-}
-
 // acc[blk] += sum_{p+q < NS} A_p(blk) B_q for NB blocks sharing one B fragment.
 //  * block index innermost: consecutive MFMAs go to different accumulators.  A chain of
 //    dependent MFMAs on ONE accumulator is issued ahead of its execution and fetches its A/B
@@ -437,14 +434,6 @@ __device__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm,
 #pragma unroll
         for (int p = 0; p < NS; ++p) dst[(((size_t)p * MB + mb) * S + s0 + st) * 64 + lane] = f.t[p];
     }
-}
-
-template <int NS>
-__device__ __forceinline__ BfFrag<NS> load_afrag(const u32x4* Wp, int MB, int S, int mb, int st, int lane) {
-    BfFrag<NS> f;
-#pragma unroll
-    for (int p = 0; p < NS; ++p) f.t[p] = Wp[(((size_t)p * MB + mb) * S + st) * 64 + lane];
-    return f;
 }
 
 // FAST = every source width is a multiple of 8, hid == 32*HB and dout == 32*OB: no
