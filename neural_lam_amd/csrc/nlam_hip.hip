@@ -425,10 +425,24 @@ __device__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm,
         const int i = lane & 31, hi = lane >> 5;
         const int m = mb * 32 + i;
         float x[8];
+        // slots 0..3 and 4..7 are each 4 consecutive k: with unit k stride and 16-B aligned rows that is two dwordx4 loads
+        const int kA = perm2 ? 32 * (st >> 1) + 16 * (st & 1) + 4 * hi : 16 * st + 8 * hi;
+        const int kB = perm2 ? kA + 8 : kA + 4;
+        const float* rowp = W + (long)m * ldm;
+        if (ldk == 1 && m < M && kB + 4 <= K && ((ldm & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0)) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(rowp + kA);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(rowp + kB);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = perm2 ? 32 * (st >> 1) + 16 * (st & 1) + (q & 3) + 8 * (q >> 2) + 4 * hi : 16 * st + 8 * hi + q;
-            x[q] = (m < M && k < K) ? W[(long)m * ldm + (long)k * ldk] : 0.f;
+            for (int c = 0; c < 4; ++c) {
+                x[c] = va[c];
+                x[4 + c] = vb[c];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = (q < 4 ? kA : kB) + (q & 3);
+                x[q] = (m < M && k < K) ? W[(long)m * ldm + (long)k * ldk] : 0.f;
+            }
         }
         const BfFrag<NS> f = split8<NS>(x);
 #pragma unroll
