@@ -29,6 +29,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/nlam_hip.h"
 
@@ -2344,6 +2345,7 @@ __global__ void adamw_kernel(float* param, const float* grad, float* m, float* v
 }
 
 #include "nlam_wide.inc"
+#include "nlam_wbf.inc"
 
 // ---------------------------------------------------------------------------
 // host side helpers
@@ -2389,7 +2391,7 @@ struct LdsGrant {
     const void* fn;
     size_t bytes;
 };
-LdsGrant g_lds_grants[64];
+LdsGrant g_lds_grants[128];
 int g_lds_ngrants = 0;
 
 template <typename K>
@@ -2403,7 +2405,7 @@ int set_lds(K kernel, size_t bytes) {
     if (slot >= 0 && g_lds_grants[slot].bytes >= bytes) return 0;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
-    if (slot < 0 && g_lds_ngrants < 64) slot = g_lds_ngrants++;
+    if (slot < 0 && g_lds_ngrants < 128) slot = g_lds_ngrants++;
     if (slot >= 0) g_lds_grants[slot] = {fn, bytes};
     return 0;
 }
@@ -2534,6 +2536,8 @@ int32_t nlam_max_width(void) { return kMaxWide; }
 
 int64_t nlam_mlp_fwd_wpack_floats(const nlam_mlp_fwd_t* p) {
     if (p == nullptr || !fwd_is_wide(p)) return 0;
+    const int ns = fwd_wbf_ns(p);
+    if (ns > 0) return fwd_wbf_wpack_floats(p, ns);
     const int64_t HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
     return (HBT * fwd_nq1(p) + OBT * HBT) * 1024;
 }
@@ -2613,6 +2617,59 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
         if (cfg.nwv == 0) return NLAM_EUNSUP;
         const int64_t need = nlam_mlp_fwd_wpack_floats(p);
         if (p->wpack == nullptr || p->wpack_floats < need) return NLAM_EINVAL;
+        const int wns = fwd_wbf_ns(p);
+        if (wns > 0) {   // split-bf16 matrix path (nlam_wbf.inc)
+            const WbfPlan pl = wbf_plan(p->hid > p->dout ? p->hid : p->dout);
+            const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
+            const int TK1 = fwd_wbf_tk1(p, pl.kg);
+            int kin = 0;
+            for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
+            u32x4* A1 = reinterpret_cast<u32x4*>(p->wpack);
+            packbf_jobs_t jobs;
+            jobs.njobs = 0;
+            int off = 0, g0 = 0;
+            long most = 0;
+            for (int s = 0; s < p->nsrc; ++s) {
+                const int w = p->src[s].width;
+                const int ng = ((w + 16 * pl.kg - 1) / (16 * pl.kg)) * pl.kg;
+                jobs.job[jobs.njobs++] = {p->W1 + off, (long)kin, 1L, p->hid, HBT, w, TK1, g0, ng, 0, A1};
+                off += w;
+                g0 += ng;
+                if ((long)HBT * ng * 64 > most) most = (long)HBT * ng * 64;
+            }
+            jobs.job[jobs.njobs++] = {p->W2, (long)p->hid, 1L, p->dout, OBT, p->hid, 2 * HBT, 0, 2 * HBT, 1,
+                                      A1 + (size_t)HBT * TK1 * wns * 64};
+            if ((long)OBT * 2 * HBT * 64 > most) most = (long)OBT * 2 * HBT * 64;
+            long pblocks = (most + 255) / 256;
+            if (pblocks > 1024) pblocks = 1024;
+            if (wns == 1) hipLaunchKernelGGL(pack_bf_kernel<1>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
+            else hipLaunchKernelGGL(pack_bf_kernel<3>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
+            const size_t lds = fwd_wbf_lds(p, wns, pl);
+            const long nsuper = (long)((p->ntiles + pl.nrt - 1) / pl.nrt) * p->batch;
+            long wcap = (long)kNumCUs * (long)(kMaxLds / lds < 1 ? 1 : kMaxLds / lds);
+            wcap = kNumCUs;   // one 8-wave workgroup per CU
+            {
+                static const char* e = getenv("NLAM_WBF_WGS_PER_CU");   // debug: occupancy experiments
+                if (e != nullptr && atoi(e) > 0) wcap = (long)kNumCUs * atoi(e);
+            }
+            const int wblocks = (int)(nsuper < wcap ? (nsuper < 1 ? 1 : nsuper) : wcap);
+#define NLAM_LAUNCH_FWD_WBF(NS_, NW_, FG_, FB_, RT_, RTP_)                                                                    \
+    do {                                                                                                                      \
+        int rc = set_lds(mlp_fwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_, RTP_>, lds);                                             \
+        if (rc != 0) return rc;                                                                                               \
+        hipLaunchKernelGGL((mlp_fwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_, RTP_>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p); \
+    } while (0)
+            if (wns == 1) {
+                if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(1, 8, 4, 1, 2, 2);
+                else if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF(1, 8, 8, 1, 4, 2);
+                else NLAM_LAUNCH_FWD_WBF(1, 8, 8, 2, 2, 1);
+            } else {
+                if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(3, 8, 4, 1, 2, 2);
+                else if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF(3, 8, 8, 1, 4, 2);
+                else NLAM_LAUNCH_FWD_WBF(3, 8, 8, 2, 2, 1);
+            }
+            return (int32_t)hipGetLastError();
+        }
         const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32, NQ1 = fwd_nq1(p);
         int kin = 0;
         for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;

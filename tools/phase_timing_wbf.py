@@ -1,0 +1,63 @@
+"""Per-phase wave cycles of the wide split-bf16 forward (instrumented build, see tools/phase_timing.py).
+
+  python tools/phase_timing.py build
+  NLAM_LIB=neural_lam_amd/libnlam_hip_timing.so python tools/phase_timing_wbf.py m2g 256
+"""
+import ctypes as C
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+assert os.environ.get("NLAM_LIB"), "run with NLAM_LIB=neural_lam_amd/libnlam_hip_timing.so"
+import torch  # noqa: E402
+
+from neural_lam_amd import _lib as L  # noqa: E402
+from neural_lam_amd import gnn_layers as hl  # noqa: E402
+from neural_lam_amd import graph as G  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "m2g"
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+dev = torch.device("cuda:0")
+lib = L.load()
+lib.nlam_debug_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
+raw = G.create_regular_grid_graph(G.regular_grid_xy(238, 268))
+ei = raw[f"{which}_edge_index"] if which != "m2m" else raw["m2m_edge_index"][0]
+ns, nr, E = int(ei[0].max()) + 1, int(ei[1].max()) + 1, ei.shape[1]
+torch.manual_seed(0)
+net = hl.InteractionNet(ei, d, update_edges=(which == "m2m")).to(dev)
+send = torch.randn(1, ns, d, device=dev)
+rec = torch.randn(1, nr, d, device=dev)
+edge = torch.randn(1, E, d, device=dev)
+buf = (C.c_ulonglong * 16)()
+NAMES = ["row ids + sync", "first chunk load/split/sync", "GEMM1 chunks", "publish hidden (z1 store, SiLU, split) + sync",
+         "GEMM2", "bias2 + LayerNorm (2 syncs)", "msg/out stores, segment reduce, syncs", "*tail drain"]
+
+
+def read(label):
+    lib.nlam_debug_phase_cycles(buf)
+    v = list(buf)
+    tiles, waves = max(v[12], 1), max(v[13], 1)
+    tot = sum(v[:12])
+    print(f"{label}: {tiles} super tiles over {waves} waves")
+    for k, nm in enumerate(NAMES):
+        per = v[k] / (waves if nm.startswith("*") else tiles)
+        print(f"   phase {k} {nm:48s} {per:10.0f} cyc   {100.0 * v[k] / tot:5.1f} %")
+    print(f"   total wave-cycles per super tile {tot / tiles:.0f}")
+
+
+for mode in ("inference", "training"):
+    for rep in range(2):
+        with torch.set_grad_enabled(mode == "training"):
+            if mode == "training":
+                edge.requires_grad_(True)
+            aggr, eo = net._messages_and_aggregate(send, rec, edge, net.update_edges, True)
+        torch.cuda.synchronize()
+        lib.nlam_debug_phase_cycles(buf) if rep == 0 else read(f"edge fwd ({mode}) {which} d={d} E={E}")
+with torch.no_grad():
+    out = net._node_update(rec, aggr.detach())
+    lib.nlam_debug_phase_cycles(buf)
+    out = net._node_update(rec, aggr.detach())
+    torch.cuda.synchronize()
+read(f"node fwd {which} d={d} N={nr}")
