@@ -37,6 +37,12 @@ def set_matmul_mode(mode: str):
 
 
 def _mm_flags() -> int:
+    """Matrix-path bits for a launch.  Under ``torch.autocast`` (Lightning ``--precision bf16-mixed``,
+    SURVEY.md section 8b "precision contract") the fused MLPs do what autocast does to the reference's
+    ``nn.Linear``s: plain bf16 operands, fp32 accumulation, LayerNorm / SiLU / aggregation in fp32
+    (fp16 autocast keeps two bf16 terms: at least fp16's 11 significant bits)."""
+    if torch.is_autocast_enabled("cuda"):
+        return _MM_FLAGS["bf16" if torch.get_autocast_dtype("cuda") == torch.bfloat16 else "bf16x2"]
     return _MM_FLAGS[MATMUL_MODE]
 
 
@@ -204,8 +210,11 @@ class FusedMLPFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, geom: MlpGeometry, W1, b1, W2, b2, ln_w, ln_b, *srcs):
         lib = L.load()
-        _require_gpu(W1, b1, W2, b2, ln_w, ln_b, *srcs)
         assert len(srcs) == geom.nsrc
+        mm_flags = _mm_flags()   # read before anything can change the autocast state; backward re-uses it
+        # storage is fp32 throughout: low-precision activations handed in by an autocast region are widened here
+        srcs = tuple(s if s.dtype == torch.float32 or not s.is_floating_point() else s.float() for s in srcs)
+        _require_gpu(W1, b1, W2, b2, ln_w, ln_b, *srcs)
         hid, kin = W1.shape
         dout = W2.shape[0]
         binfo = [as_batched(s) for s in srcs]
@@ -231,7 +240,8 @@ class FusedMLPFunction(torch.autograd.Function):
         W1c, b1c, W2c, b2c = W1.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous()
         p.W1, p.b1, p.W2, p.b2 = _ptr(W1c), _ptr(b1c), _ptr(W2c), _ptr(b2c)
         p.ln_w, p.ln_b = _ptr(ln_w), _ptr(ln_b)
-        p.eps, p.hid, p.dout, p.flags = 1e-5, hid, dout, geom.flags | _mm_flags()
+        p.eps, p.hid, p.dout, p.flags = 1e-5, hid, dout, geom.flags | mm_flags
+        ctx.mm_flags = mm_flags
         out = aggr = None
         if geom.want_out:
             out_rows = geom.out_rows if geom.out_rows is not None else rows
@@ -296,7 +306,7 @@ class FusedMLPFunction(torch.autograd.Function):
         p.nsrc, p.batch, p.rows, p.ntiles = nsrc, B, rows, ntiles
         p.tiles = _ptr(geom.tiles)
         p.W1, p.W2, p.ln_w = _ptr(W1), _ptr(W2), _ptr(ln_w) if ctx.has_ln else None
-        p.hid, p.dout, p.flags, p.nseg_total = hid, dout, geom.flags | _mm_flags(), geom.nseg_total
+        p.hid, p.dout, p.flags, p.nseg_total = hid, dout, geom.flags | ctx.mm_flags, geom.nseg_total
         if g_out is not None:
             p.g_out, p.out_idx, p.out_bstride = _ptr(g_out), _ptr(geom.out_idx), g_out.shape[1] * dout
         if g_aggr is not None:

@@ -93,6 +93,31 @@ def test_model_training_step_matches_reference_golden(dev, name, tmp_path):
         assert float((p.grad.cpu() - ref_g).abs().max()) < 1e-4 * max(float(ref_g.abs().max()), 1e-3), k
 
 
+@pytest.mark.parametrize("name", ["graphlam_30x27", "graphlam_30x27_d128", "hilam_81x30"])
+def test_model_step_under_bf16_autocast(dev, name, tmp_path):
+    """The whole training step inside torch.autocast(bfloat16) (= Lightning --precision bf16-mixed): runs, every
+    parameter gets a finite gradient, and prediction / loss stay within bf16-operand distance (5e-2) of the fp32
+    reference run stored in the golden file."""
+    from neural_lam_amd import models as hm
+    from neural_lam_amd.datastore import SyntheticDatastore
+
+    case = load_golden(name)
+    ds = SyntheticDatastore(root_path=tmp_path, **case["ds_kwargs"])
+    graph = (case["ref_hierarchical"], graph_from_case(case))
+    cls = {"GraphLAM": hm.GraphLAM, "HiLAM": hm.HiLAM, "HiLAMParallel": hm.HiLAMParallel}[case["model"]]
+    forecaster = hm.ARForecaster(cls(ds, graph=graph, **case["model_kwargs"]), ds)
+    forecaster.load_state_dict(case["state_dict"], strict=True)
+    step = hm.ForecasterStep(forecaster, ds).to(dev)
+    init, target, forcing = (case[k].to(dev) for k in ("init", "target", "forcing"))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        pred, loss = step(init, target, forcing)
+    loss.float().backward()
+    assert rel_err(pred.float().cpu(), case["ref_prediction"]) < 5e-2
+    assert abs(float(loss) - float(case["ref_loss"])) < 5e-2 * abs(float(case["ref_loss"]))
+    for k, p in forecaster.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+
+
 # ---------------------------------------------------------------------------
 # HIP vs oracle on seeded inputs (sizes the oracle finishes in seconds)
 # ---------------------------------------------------------------------------
@@ -408,6 +433,52 @@ def test_matmul_modes_match_oracle(dev, mode, tol):
         assert rel_err(a.grad.cpu(), b.grad) < tol
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         assert rel_err(p.grad.cpu(), q.grad) < tol, k
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_autocast_region_uses_bf16_operands(dev, d):
+    """Lightning ``--precision bf16-mixed`` wraps the step in torch.autocast: the fused MLPs then take plain bf16
+    operands (what autocast does to the reference's nn.Linear), accept bf16 activations, keep fp32 outputs, and give
+    bit-for-bit what set_matmul_mode("bf16") gives outside autocast.  Tolerance against the fp32 oracle: 3e-2."""
+    from neural_lam_amd import ops
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    ns, nr, e, B = 61, 47, 1501, 2
+    ei = _rand_ei(ns, nr, e, seed=11)
+    torch.manual_seed(11)
+    ref = og.InteractionNet(ei, d)
+    net = hl.InteractionNet(ei, d)
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    send, rec, edge = torch.randn(B, ns, d), torch.randn(B, nr, d), torch.randn(B, e, d)
+    s1, r1, e1 = (t.clone().requires_grad_() for t in (send, rec, edge))
+    s2, r2, e2 = (t.to(dev).requires_grad_() for t in (send, rec, edge))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        o2 = net(s2, r2, e2)
+        loss = sum(o.float().square().sum() for o in o2)
+    loss.backward()   # outside the region, as Lightning does: the launch re-uses the forward's matrix mode
+    assert all(o.dtype == torch.float32 for o in o2)
+    o1 = ref(s1, r1, e1)
+    sum(o.square().sum() for o in o1).backward()
+    for a, b in zip(o2, o1):
+        assert rel_err(a.detach().cpu(), b) < 3e-2
+    for a, b in ((s2, s1), (r2, r1), (e2, e1)):
+        assert rel_err(a.grad.cpu(), b.grad) < 3e-2
+    old = ops.MATMUL_MODE
+    try:
+        ops.set_matmul_mode("bf16")
+        with torch.no_grad():
+            o3 = net(s2, r2, e2)
+            # bf16 activations coming out of an autocast Linear upstream are widened, not rejected
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                o4 = net(s2.bfloat16(), r2.bfloat16(), e2.bfloat16())
+    finally:
+        ops.set_matmul_mode(old)
+    for a, b in zip(o2, o3):
+        assert torch.equal(a.detach(), b)
+    for a, b in zip(o4, o1):
+        assert a.dtype == torch.float32 and rel_err(a.cpu(), b) < 5e-2
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
