@@ -2660,11 +2660,11 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
         hipLaunchKernelGGL((mlp_fwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_, RTP_>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p); \
     } while (0)
             if (wns == 1) {
-                if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(1, 8, 4, 1, 2, 2);
+                if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(1, 8, 4, 1, 4, 2);
                 else if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF(1, 8, 8, 1, 4, 2);
                 else NLAM_LAUNCH_FWD_WBF(1, 8, 8, 2, 2, 1);
             } else {
-                if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(3, 8, 4, 1, 2, 2);
+                if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(3, 8, 4, 1, 4, 2);
                 else if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF(3, 8, 8, 1, 4, 2);
                 else NLAM_LAUNCH_FWD_WBF(3, 8, 8, 2, 2, 1);
             }
