@@ -177,6 +177,14 @@ int32_t nlam_abi_version(void);
 int32_t nlam_num_blocks(int64_t total_tiles);
 /* widest hidden/output width the fused kernels of this build instantiate */
 int32_t nlam_max_width(void);
+
+/* Launch-shape tuning (process-wide; tests use it to force a kernel family at small sizes).
+ *   NLAM_TUNE_WBF_MIN_SUPERTILES: wide (> 64) fused-MLP launches with fewer super tiles than `value`
+ *   run on the fp32 MFMA kernels even when a split-bf16 matrix mode is requested (default 192:
+ *   a 128-row super tile per workgroup needs that many to occupy 256 CUs).
+ * Returns 0, or NLAM_EINVAL for an unknown key / negative value. */
+#define NLAM_TUNE_WBF_MIN_SUPERTILES 1
+int32_t nlam_set_tuning(int32_t key, int32_t value);
 /* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this
  * call; 0 when the call runs on the narrow (weights-in-LDS) kernels. */
 int64_t nlam_mlp_fwd_wpack_floats(const nlam_mlp_fwd_t* p);

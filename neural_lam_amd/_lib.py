@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ["NLAM_LIB"]) if os.environ.get("NLAM_LIB") else HERE 
 
 NLAM_MAX_SRC = 3
 F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B = 1, 2, 4, 8
+TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning key (include/nlam_hip.h)
 TILE_SPLIT = 1 << 30
 
 EXPORTS = [
@@ -23,6 +24,7 @@ EXPORTS = [
     "nlam_grid_waves",
     "nlam_num_blocks",
     "nlam_max_width",
+    "nlam_set_tuning",
     "nlam_mlp_fwd_wpack_floats",
     "nlam_mlp_bwd_wpack_floats",
     "nlam_mlp_bwd_blocks",
@@ -182,6 +184,8 @@ def load():
     lib.nlam_abi_version.restype = i32
     lib.nlam_grid_waves.restype = i32
     lib.nlam_max_width.restype = i32
+    lib.nlam_set_tuning.restype = i32
+    lib.nlam_set_tuning.argtypes = [i32, i32]
     lib.nlam_num_blocks.argtypes = [i64]
     lib.nlam_num_blocks.restype = i32
     lib.nlam_mlp_fwd_wpack_floats.argtypes = [C.POINTER(MlpFwd)]

@@ -2534,6 +2534,15 @@ int32_t nlam_grid_waves(void) { return kMaxGridBlocks * kWavesPerBlock; }
 int32_t nlam_num_blocks(int64_t total_tiles) { return grid_blocks((long)total_tiles); }
 int32_t nlam_max_width(void) { return kMaxWide; }
 
+int32_t nlam_set_tuning(int32_t key, int32_t value) {
+    if (key == NLAM_TUNE_WBF_MIN_SUPERTILES) {
+        if (value < 0) return NLAM_EINVAL;
+        g_wbf_min_supertiles = value;
+        return 0;
+    }
+    return NLAM_EINVAL;
+}
+
 int64_t nlam_mlp_fwd_wpack_floats(const nlam_mlp_fwd_t* p) {
     if (p == nullptr || !fwd_is_wide(p)) return 0;
     const int ns = fwd_wbf_ns(p);
@@ -2544,6 +2553,7 @@ int64_t nlam_mlp_fwd_wpack_floats(const nlam_mlp_fwd_t* p) {
 
 int64_t nlam_mlp_bwd_wpack_floats(const nlam_mlp_bwd_t* p) {
     if (p == nullptr || !bwd_is_wide(p)) return 0;
+    if (bwd_wbf_ns(p) > 0) return bwd_wbf_wpack_floats(p, bwd_wbf_ns(p));
     const int64_t HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
     int64_t f = HBT * OBT * 1024;
     for (int s = 0; s < p->nsrc; ++s)
@@ -2555,6 +2565,11 @@ int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p) {
     if (p == nullptr) return 0;
     const long total = (long)p->ntiles * p->batch;
     if (!bwd_is_wide(p)) return grid_blocks(total);
+    if (bwd_wbf_ns(p) > 0) {   // partial-sum rows: one per (workgroup, row group)
+        const WbfBwdPlan pl = wbf_bwd_plan(bwd_wide_maxw(p));
+        const long nsuper = (long)((p->ntiles + pl.nrt - 1) / pl.nrt) * p->batch;
+        return (int32_t)((nsuper < kNumCUs ? (nsuper < 1 ? 1 : nsuper) : kNumCUs) * pl.rg);
+    }
     const WideCfg cfg = wide_cfg(bwd_wide_maxw(p));
     if (cfg.nwv == 0) return 0;
     return wide_grid(total, bwd_wide_lds(p, cfg.nwv), cfg.nwv);
@@ -2646,12 +2661,7 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
             else hipLaunchKernelGGL(pack_bf_kernel<3>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
             const size_t lds = fwd_wbf_lds(p, wns, pl);
             const long nsuper = (long)((p->ntiles + pl.nrt - 1) / pl.nrt) * p->batch;
-            long wcap = (long)kNumCUs * (long)(kMaxLds / lds < 1 ? 1 : kMaxLds / lds);
-            wcap = kNumCUs;   // one 8-wave workgroup per CU
-            {
-                static const char* e = getenv("NLAM_WBF_WGS_PER_CU");   // debug: occupancy experiments
-                if (e != nullptr && atoi(e) > 0) wcap = (long)kNumCUs * atoi(e);
-            }
+            const long wcap = kNumCUs;   // one 8-wave workgroup per CU
             const int wblocks = (int)(nsuper < wcap ? (nsuper < 1 ? 1 : nsuper) : wcap);
 #define NLAM_LAUNCH_FWD_WBF(NS_, NW_, FG_, FB_, RT_, RTP_)                                                                    \
     do {                                                                                                                      \
@@ -2763,6 +2773,52 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
         const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
         int kin = 0;
         for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
+        const int wns = bwd_wbf_ns(p);
+        if (wns > 0) {   // split-bf16 matrix path (nlam_wbf.inc)
+            const WbfBwdPlan pl = wbf_bwd_plan(bwd_wide_maxw(p));
+            const int TKA = 2 * OBT, TKB = 2 * HBT;
+            u32x4* base = reinterpret_cast<u32x4*>(p->wpack);
+            packbf_jobs_t jobs;
+            jobs.njobs = 0;
+            long most = (long)HBT * TKA * 64;
+            // A[m = hidden][k = out] = W2[k][m]; K in slot order (the B fragments come straight from accumulator layout)
+            jobs.job[jobs.njobs++] = {p->W2, 1L, (long)p->hid, p->hid, HBT, p->dout, TKA, 0, TKA, 1, base};
+            size_t woff = (size_t)HBT * TKA * wns * 64;
+            int off = 0;
+            for (int s = 0; s < p->nsrc; ++s) {
+                const int w = p->src[s].width;
+                if (p->dmode[s] != 0) {
+                    const int SB = (w + 31) / 32;
+                    // A[m = source column][k = hidden] = W1[k][off + m]
+                    jobs.job[jobs.njobs++] = {p->W1 + off, 1L, (long)kin, w, SB, p->hid, TKB, 0, TKB, 1, base + woff};
+                    woff += (size_t)SB * TKB * wns * 64;
+                    if ((long)SB * TKB * 64 > most) most = (long)SB * TKB * 64;
+                }
+                off += w;
+            }
+            long pblocks = (most + 255) / 256;
+            if (pblocks > 1024) pblocks = 1024;
+            if (wns == 1) hipLaunchKernelGGL(pack_bf_kernel<1>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
+            else hipLaunchKernelGGL(pack_bf_kernel<3>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
+            const size_t lds = bwd_wbf_lds(p, wns, pl);
+            const int wblocks = nlam_mlp_bwd_blocks(p) / pl.rg;
+#define NLAM_LAUNCH_BWD_WBF(NS_, FG_, FB_, RT_)                                                                   \
+    do {                                                                                                          \
+        int rc = set_lds(mlp_bwd_wbf_kernel<NS_, FG_, FB_, RT_>, lds);                                            \
+        if (rc != 0) return rc;                                                                                   \
+        hipLaunchKernelGGL((mlp_bwd_wbf_kernel<NS_, FG_, FB_, RT_>), dim3(wblocks), dim3(512), lds, stream, *p);  \
+    } while (0)
+            if (wns == 1) {
+                if (pl.cfg == 1) NLAM_LAUNCH_BWD_WBF(1, 4, 1, 2);
+                else if (pl.cfg == 2) NLAM_LAUNCH_BWD_WBF(1, 8, 1, 2);
+                else NLAM_LAUNCH_BWD_WBF(1, 8, 2, 1);
+            } else {
+                if (pl.cfg == 1) NLAM_LAUNCH_BWD_WBF(3, 4, 1, 2);
+                else if (pl.cfg == 2) NLAM_LAUNCH_BWD_WBF(3, 8, 1, 2);
+                else NLAM_LAUNCH_BWD_WBF(3, 8, 2, 1);
+            }
+            return (int32_t)hipGetLastError();
+        }
         pack_jobs_t jobs;
         jobs.njobs = 0;
         // A[m = hidden][k = out] = W2[k][m]
@@ -2842,6 +2898,23 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     const bool dma = wgrad_is_narrow_dma(p);
     int nb_total = 0;
     for (int s = 0; s < p->nsrc; ++s) nb_total += (p->src[s].width + 31) / 32;
+    if (wgrad_is_wide(p) && wgrad_wbf_ns(p) > 0) {   // split-bf16 matrix path (nlam_wbf.inc)
+        const int wns = wgrad_wbf_ns(p);
+        const size_t lds = (size_t)2 * 8 * wns * 1024;
+        const dim3 grid(p->nparts, wgrad_windows(p));
+#define NLAM_LAUNCH_WG_WBF(NS_, S_)                                                              \
+    do {                                                                                         \
+        int rc = set_lds(wgrad_wbf_kernel<NS_, S_>, lds);                                        \
+        if (rc != 0) return rc;                                                                  \
+        hipLaunchKernelGGL((wgrad_wbf_kernel<NS_, S_>), grid, dim3(256), lds, stream, *p);       \
+    } while (0)
+        const bool silu = (p->flags & NLAM_F_SILU_B) != 0;
+        if (wns == 1 && silu) NLAM_LAUNCH_WG_WBF(1, true);
+        else if (wns == 1) NLAM_LAUNCH_WG_WBF(1, false);
+        else if (silu) NLAM_LAUNCH_WG_WBF(3, true);
+        else NLAM_LAUNCH_WG_WBF(3, false);
+        return (int32_t)hipGetLastError();
+    }
     if (wgrad_is_wide(p)) {
         const size_t lds = (size_t)4 * kWWTile * sizeof(float);
         if (p->flags & NLAM_F_SILU_B) {

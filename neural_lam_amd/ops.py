@@ -381,7 +381,7 @@ class FusedMLPFunction(torch.autograd.Function):
 
         def wgrad(A, m, src_list, n, flags):
             q = L.Wgrad()
-            q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(src_list), flags, n
+            q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(src_list), flags | ctx.mm_flags, n
             for k, (t, bstride, w, idx) in enumerate(src_list):
                 _fill_src(q.src[k], t, bstride, w, idx)
             nparts = lib.nlam_wgrad_nparts(C.byref(q))

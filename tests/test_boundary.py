@@ -35,6 +35,9 @@ def test_library_exports_every_declared_symbol():
     assert lib.nlam_abi_version() == 2
     assert lib.nlam_max_width() >= 64
     assert lib.nlam_num_blocks(1) == 1 and lib.nlam_num_blocks(10**6) == 256
+    # tuning knob: known key accepted (and restored), unknown key / negative value rejected
+    assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
+    assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, -1) == -1 and lib.nlam_set_tuning(99, 1) == -1
 
 
 def test_ctypes_structs_match_c_layout(tmp_path):

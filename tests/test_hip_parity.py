@@ -33,6 +33,19 @@ def _hl():
     return gnn_layers
 
 
+@pytest.fixture(params=["auto", "wbf"])
+def wide_family(request):
+    """Widths above 64 have two kernel families: the fp32 MFMA one (one 32-row tile per workgroup) and the
+    split-bf16 one (128-row super tiles), chosen by launch size.  "wbf" forces the second at test sizes."""
+    from neural_lam_amd import _lib as L
+
+    lib = L.load()
+    if request.param == "wbf":
+        assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 0) == 0
+    yield request.param
+    assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
+
+
 LAYER_CASES = [
     "inet_sum_update_d8", "inet_mean_noupdate_b2_d8", "propnet_b2_d8", "propnet_noupdate_d16",
     "inet_chunked_d8", "inet_100to10_gap_d16", "inet_sum_update_b2_d64", "inet_highdeg_d32", "inet_hidden12_d8",
@@ -41,7 +54,7 @@ LAYER_CASES = [
 
 
 @pytest.mark.parametrize("name", LAYER_CASES)
-def test_layer_matches_reference_golden(dev, golden_layers, name):
+def test_layer_matches_reference_golden(dev, golden_layers, name, wide_family):
     hl = _hl()
     case = golden_layers[name]
     net = hl.get_gnn_class(case["cls"])(case["edge_index"].to(torch.int64), case["d"], **case["kwargs"])
@@ -65,7 +78,7 @@ MODEL_CASES = ["graphlam_30x27", "graphlam_30x27_variants", "graphlam_30x27_d128
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
-def test_model_training_step_matches_reference_golden(dev, name, tmp_path):
+def test_model_training_step_matches_reference_golden(dev, name, tmp_path, wide_family):
     from neural_lam_amd import models as hm
     from neural_lam_amd.datastore import SyntheticDatastore
 
@@ -94,7 +107,7 @@ def test_model_training_step_matches_reference_golden(dev, name, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["graphlam_30x27", "graphlam_30x27_d128", "hilam_81x30"])
-def test_model_step_under_bf16_autocast(dev, name, tmp_path):
+def test_model_step_under_bf16_autocast(dev, name, tmp_path, wide_family):
     """The whole training step inside torch.autocast(bfloat16) (= Lightning --precision bf16-mixed): runs, every
     parameter gets a finite gradient, and prediction / loss stay within bf16-operand distance (5e-2) of the fp32
     reference run stored in the golden file."""
@@ -164,7 +177,7 @@ def test_layer_matches_oracle(dev, cls_name, d, update_edges):
     ("PropagationNet", 256, True), ("InteractionNet", 512, True), ("InteractionNet", 96, False),
     ("InteractionNet", 200, True),
 ])
-def test_wide_layer_matches_oracle(dev, cls_name, d, update_edges):
+def test_wide_layer_matches_oracle(dev, cls_name, d, update_edges, wide_family):
     from oracle import gnn_layers as og
 
     hl = _hl()
@@ -196,7 +209,7 @@ def test_wide_layer_matches_oracle(dev, cls_name, d, update_edges):
     (56, 256, 256, True), (256, 256, 17, False), (3, 128, 128, True), (128, 64, 64, True), (130, 96, 40, True),
     (512, 512, 34, False), (18, 512, 512, True),
 ])
-def test_plain_mlp_matches_oracle(dev, kin, hid, dout, ln):
+def test_plain_mlp_matches_oracle(dev, kin, hid, dout, ln, wide_family):
     from oracle import gnn_layers as og
 
     hl = _hl()
@@ -436,7 +449,7 @@ def test_matmul_modes_match_oracle(dev, mode, tol):
 
 
 @pytest.mark.parametrize("d", [64, 128])
-def test_autocast_region_uses_bf16_operands(dev, d):
+def test_autocast_region_uses_bf16_operands(dev, d, wide_family):
     """Lightning ``--precision bf16-mixed`` wraps the step in torch.autocast: the fused MLPs then take plain bf16
     operands (what autocast does to the reference's nn.Linear), accept bf16 activations, keep fp32 outputs, and give
     bit-for-bit what set_matmul_mode("bf16") gives outside autocast.  Tolerance against the fp32 oracle: 3e-2."""
