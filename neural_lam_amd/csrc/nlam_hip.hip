@@ -45,7 +45,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifdef NLAM_TIMING
 __device__ unsigned long long g_phase_cycles[16];
 #define NLAM_T_DECL unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); \
-    unsigned int t_a0_ = 0, t_a1_ = 0, t_a2_ = 0, t_a3_ = 0, t_a4_ = 0, t_a5_ = 0, t_a6_ = 0, t_a7_ = 0;
+    unsigned int t_a0_ = 0, t_a1_ = 0, t_a2_ = 0, t_a3_ = 0, t_a4_ = 0, t_a5_ = 0, t_a6_ = 0, t_a7_ = 0, t_a8_ = 0, t_a9_ = 0, t_a10_ = 0, t_a11_ = 0;
 #define NLAM_T_DRAIN asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #define NLAM_T_MARK(k) { const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); t_a##k##_ += (unsigned int)(t_now_ - t_prev_); t_prev_ = t_now_; }
 #define NLAM_T_FLUSH(ntiles_) if ((threadIdx.x & 63) == 0) { \
@@ -53,6 +53,8 @@ __device__ unsigned long long g_phase_cycles[16];
     atomicAdd(&g_phase_cycles[2], (unsigned long long)t_a2_); atomicAdd(&g_phase_cycles[3], (unsigned long long)t_a3_); \
     atomicAdd(&g_phase_cycles[4], (unsigned long long)t_a4_); atomicAdd(&g_phase_cycles[5], (unsigned long long)t_a5_); \
     atomicAdd(&g_phase_cycles[6], (unsigned long long)t_a6_); atomicAdd(&g_phase_cycles[7], (unsigned long long)t_a7_); \
+    atomicAdd(&g_phase_cycles[8], (unsigned long long)t_a8_); atomicAdd(&g_phase_cycles[9], (unsigned long long)t_a9_); \
+    atomicAdd(&g_phase_cycles[10], (unsigned long long)t_a10_); atomicAdd(&g_phase_cycles[11], (unsigned long long)t_a11_); \
     atomicAdd(&g_phase_cycles[12], (unsigned long long)(ntiles_)); atomicAdd(&g_phase_cycles[13], 1ULL); }
 #else
 #define NLAM_T_DECL

@@ -32,7 +32,8 @@ rec = torch.randn(1, nr, d, device=dev)
 edge = torch.randn(1, E, d, device=dev)
 buf = (C.c_ulonglong * 16)()
 NAMES = ["row ids + sync", "first chunk load/split/sync", "GEMM1 chunks", "publish hidden (z1 store, SiLU, split) + sync",
-         "GEMM2", "bias2 + LayerNorm (2 syncs)", "msg/out stores, segment reduce, syncs", "*tail drain"]
+         "GEMM2", "LN: normalise, xhat store, affine", "msg/out stores, segment reduce, syncs", "*tail drain",
+         "LN: bias2, row sums", "LN: barrier 1", "LN: centre, squares", "LN: barrier 2"]
 
 
 def read(label):
