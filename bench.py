@@ -45,6 +45,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 CONFIGS = {
@@ -53,6 +54,13 @@ CONFIGS = {
                  graph=dict(n_max_levels=None, hierarchical=False), boundary="frame"),
     "cfg1": dict(nx=64, ny=64, ns=5, nf=2, nst=1, d=16, L=4, T=1, B=2, model="graph_lam",
                  graph=dict(n_max_levels=1, hierarchical=False), boundary="random"),
+    # the other BASELINE.json configs, one sample per GPU (not the default bench line; numbers go to profiles/)
+    "cfg3": dict(nx=238, ny=268, ns=17, nf=6, nst=4, d=256, L=8, T=4, B=1, model="graph_lam",
+                 graph=dict(n_max_levels=None, hierarchical=False), boundary="frame"),
+    "cfg4": dict(nx=238, ny=268, ns=17, nf=6, nst=4, d=128, L=4, T=1, B=1, model="hi_lam",
+                 graph=dict(n_max_levels=3, hierarchical=True), boundary="frame"),
+    "cfg5": dict(nx=238, ny=268, ns=17, nf=6, nst=4, d=512, L=8, T=8, B=1, model="graph_lam",
+                 graph=dict(n_max_levels=None, hierarchical=False), boundary="frame"),
 }
 
 
@@ -144,6 +152,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying a HIP graph")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = run the step inside torch.autocast(bfloat16), as Lightning --precision bf16-mixed does (cfg5)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -165,6 +175,8 @@ def main():
 
     ds, graph, raw, forecaster, step, batch = build(cfg, device, seed_offset=rank)
     trainer = Trainer(step, lr=1e-3, use_graph=not args.eager)
+    amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.precision == "bf16")
+    amp.__enter__()   # whole run (capture included) inside the autocast region; exited before the CPU baseline
 
     def sync():
         if world > 1:
@@ -236,12 +248,23 @@ def main():
                     traffic = json.loads(tfile.read_text()).get("m2g_edge_fwd_bytes_per_launch")
                 except Exception:
                     traffic = None
-            mode = ops.MATMUL_MODE
+            mode = "bf16" if args.precision == "bf16" else ops.MATMUL_MODE
+            terms = {"f32": 0, "bf16": 1, "bf16x2": 2, "bf16x3": 3}[mode]
+            if d > 64 and terms == 2:
+                terms = 3   # the wide kernels instantiate one and three terms
+            mfmas = terms * (terms + 1) // 2   # bf16 MFMAs executed per algorithmic product block
+            if d <= 64:
+                kname = "mlp_fwd_bf_kernel<2,2,%d>" % terms if terms else "mlp_fwd_kernel<2,2,FAST>"
+            else:
+                kname = "mlp_fwd_wbf_kernel<%d,..>" % terms if terms else "mlp_fwd_wide_kernel"
             roofline = {
                 "bound": "mfma",
-                "kernel": ("mlp_fwd_bf_kernel<2,2,%s>" % mode[-1] if mode.startswith("bf16") else "mlp_fwd_kernel<2,2,FAST>")
-                          + " (m2g edge set: gather + edge MLP + LayerNorm + aggregate, training mode)",
+                "kernel": kname + " (m2g edge set: gather + edge MLP + LayerNorm + aggregate, training mode)",
                 "matmul_mode": mode,
+                # fp32-result FLOPs against the fp32 MFMA peak (the contract of the path is fp32 results); the same
+                # launch on EXECUTED bf16 matrix FLOPs against the dense bf16 peak is reported next to it
+                "executed_bf16_tflops": (achieved * mfmas) if terms else None,
+                "frac_of_bf16_dense_peak": (achieved * mfmas / PEAK_BF16_MFMA_TFLOPS) if terms else None,
                 "achieved": achieved,
                 "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
@@ -255,6 +278,7 @@ def main():
                 "traffic": traffic,
             }
 
+    amp.__exit__(None, None, None)
     if rank == 0:
         out = {
             "metric": "training sample-steps/s (fwd+wmse+bwd+allreduce+AdamW), GraphCast-LAM, MEPS-shaped grid",
@@ -267,14 +291,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
-            "matmul_mode": ops.MATMUL_MODE,
+            "dtype": "f32" if args.precision == "fp32" else "bf16",
+            "matmul_mode": ops.MATMUL_MODE if args.precision == "fp32" else "bf16 (autocast)",
             "data": "synthetic",
             "launch_mode": "eager" if args.eager else "hip_graph (zero-grad + fwd + loss + bwd captured once; all-reduce + AdamW after each replay)",
             "forecast_steps_per_s": forecast_steps_per_s,
             "final_loss": float(loss),
             "config": {
-                "workload": f"{args.config}: GraphLAM multiscale, grid {cfg['nx']}x{cfg['ny']} ({ds.num_grid_points} nodes), "
+                "workload": f"{args.config}: {cfg['model']}, grid {cfg['nx']}x{cfg['ny']} ({ds.num_grid_points} nodes), "
                             f"{cfg['ns']} state vars, hidden_dim {cfg['d']}, {cfg['L']} processor layers, "
                             f"ar_steps {cfg['T']}, batch {cfg['B']}/GPU, g2m/m2m/m2g edges "
                             f"{raw['g2m_edge_index'].shape[1]}/{raw['m2m_edge_index'][0].shape[1]}/{raw['m2g_edge_index'].shape[1]}",
