@@ -526,6 +526,44 @@ def test_layer_is_bit_reproducible_at_meps_size(dev, mode):
         assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
 
 
+@pytest.mark.parametrize("d,which,update_edges", [(128, "m2g", False), (256, "m2m", True)])
+def test_wide_kernel_families_agree_at_meps_size(dev, d, which, update_edges):
+    """Full-size check without the oracle (too slow at this size): the fp32 MFMA kernels (one tile per workgroup,
+    weights streamed per tile) and the split-bf16 super-tile kernels share no device code beyond the tile schedule,
+    so agreement of outputs and of every gradient within 1e-4 at the MEPS edge sets pins both; the split-bf16 run
+    must also be bit-reproducible."""
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import ops
+
+    hl = _hl()
+    raw = G.create_regular_grid_graph(G.regular_grid_xy(238, 268))
+    ei = raw[f"{which}_edge_index"] if which != "m2m" else raw["m2m_edge_index"][0]
+    ns, nr, E = int(ei[0].max()) + 1, int(ei[1].max()) + 1, ei.shape[1]
+    torch.manual_seed(0)
+    net = hl.InteractionNet(ei, d, update_edges=update_edges).to(dev)
+    send, rec, edge = (torch.randn(1, n, d, device=dev, requires_grad=True) for n in (ns, nr, E))
+
+    def run(mode):
+        old = ops.MATMUL_MODE
+        try:
+            ops.set_matmul_mode(mode)
+            for t in (send, rec, edge):
+                t.grad = None
+            net.zero_grad(set_to_none=True)
+            out = net(send, rec, edge)
+            outs = out if isinstance(out, tuple) else (out,)
+            sum(o.square().sum() for o in outs).backward()
+            return [o.detach().clone() for o in outs] + [send.grad.clone(), rec.grad.clone(), edge.grad.clone()] + [
+                p.grad.clone() for p in net.parameters()]
+        finally:
+            ops.set_matmul_mode(old)
+
+    a, b, c = run("f32"), run("bf16x3"), run("bf16x3")
+    for x, y in zip(a, b):
+        assert rel_err(y.cpu(), x.cpu()) < TOL
+    assert all(torch.equal(x, y) for x, y in zip(b, c))
+
+
 def test_fused_wmse_loss_matches_reference_formula(dev):
     """nlam_wmse_fwd/bwd == metrics.wmse + mask_and_reduce_metric + batch/step means (metrics.py:37-137, module.py:463-510)."""
     from neural_lam_amd import models as hm

@@ -62,3 +62,21 @@ with torch.no_grad():
     out = net._node_update(rec, aggr.detach())
     torch.cuda.synchronize()
 read(f"node fwd {which} d={d} N={nr}")
+
+BNAMES = ["tile setup (descriptors, row pointers)", "A: dmsg / xhat loads, LN sums, column sums", "A: LN finish, dz2 store, db2, publish, barrier",
+          "GEMM dh = W2^T dz2", "B: barrier, z1 load, silu', dz1 store, db1, publish, barrier", "GEMMs dx_s = W1_s^T dz1",
+          "C: residual terms, row stores / segment sums", "*tail drain", "A: barrier (row statistics)", "end barrier", "-", "-"]
+NAMES[:] = BNAMES
+edge.requires_grad_(True)
+send.requires_grad_(True)
+rec.requires_grad_(True)
+for rep in range(2):
+    aggr, eo = net._messages_and_aggregate(send, rec, edge, net.update_edges, True)
+    torch.cuda.synchronize()
+    lib.nlam_debug_phase_cycles(buf)
+    (aggr.sum() + (eo.sum() if eo is not None else 0.0)).backward()
+    torch.cuda.synchronize()
+    if rep == 1:
+        read(f"edge bwd {which} d={d} E={E}")
+    else:
+        lib.nlam_debug_phase_cycles(buf)
