@@ -2636,7 +2636,7 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
         if (p->wpack == nullptr || p->wpack_floats < need) return NLAM_EINVAL;
         const int wns = fwd_wbf_ns(p);
         if (wns > 0) {   // split-bf16 matrix path (nlam_wbf.inc)
-            const WbfPlan pl = wbf_plan(p->hid > p->dout ? p->hid : p->dout);
+            const WbfPlan pl = wbf_plan(p->hid > p->dout ? p->hid : p->dout, wns);
             const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
             const int TK1 = fwd_wbf_tk1(p, pl.kg);
             int kin = 0;
