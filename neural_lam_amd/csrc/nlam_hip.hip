@@ -2902,19 +2902,20 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     for (int s = 0; s < p->nsrc; ++s) nb_total += (p->src[s].width + 31) / 32;
     if (wgrad_is_wide(p) && wgrad_wbf_ns(p) > 0) {   // split-bf16 matrix path (nlam_wbf.inc)
         const int wns = wgrad_wbf_ns(p);
-        const size_t lds = (size_t)2 * 8 * wns * 1024;
+        const int ksteps = 1;   // longer stages (KS = 4) lost 8 % with one term: the launch is at the HBM roof re-reading rows per window
+        const size_t lds = (size_t)2 * ksteps * 8 * wns * 1024;
         const dim3 grid(p->nparts, wgrad_windows(p));
-#define NLAM_LAUNCH_WG_WBF(NS_, S_)                                                              \
+#define NLAM_LAUNCH_WG_WBF(NS_, S_, KS_)                                                         \
     do {                                                                                         \
-        int rc = set_lds(wgrad_wbf_kernel<NS_, S_>, lds);                                        \
+        int rc = set_lds(wgrad_wbf_kernel<NS_, S_, KS_>, lds);                                   \
         if (rc != 0) return rc;                                                                  \
-        hipLaunchKernelGGL((wgrad_wbf_kernel<NS_, S_>), grid, dim3(256), lds, stream, *p);       \
+        hipLaunchKernelGGL((wgrad_wbf_kernel<NS_, S_, KS_>), grid, dim3(256), lds, stream, *p);  \
     } while (0)
         const bool silu = (p->flags & NLAM_F_SILU_B) != 0;
-        if (wns == 1 && silu) NLAM_LAUNCH_WG_WBF(1, true);
-        else if (wns == 1) NLAM_LAUNCH_WG_WBF(1, false);
-        else if (silu) NLAM_LAUNCH_WG_WBF(3, true);
-        else NLAM_LAUNCH_WG_WBF(3, false);
+        if (wns == 1 && silu) NLAM_LAUNCH_WG_WBF(1, true, 1);
+        else if (wns == 1) NLAM_LAUNCH_WG_WBF(1, false, 1);
+        else if (silu) NLAM_LAUNCH_WG_WBF(3, true, 1);
+        else NLAM_LAUNCH_WG_WBF(3, false, 1);
         return (int32_t)hipGetLastError();
     }
     if (wgrad_is_wide(p)) {
