@@ -2507,11 +2507,13 @@ bool wgrad_is_wide(const nlam_wgrad_t* p) {
     return ok;
 }
 
-int wgrad_windows(const nlam_wgrad_t* p) {
+int wgrad_windows_of(const nlam_wgrad_t* p, int winm, int winn) {
     int nw = 0;
-    for (int s = 0; s < p->nsrc; ++s) nw += (p->src[s].width + kWWin - 1) / kWWin;
-    return nw * ((p->m + kWWin - 1) / kWWin);
+    for (int s = 0; s < p->nsrc; ++s) nw += (p->src[s].width + winn - 1) / winn;
+    return nw * ((p->m + winm - 1) / winm);
 }
+
+int wgrad_windows(const nlam_wgrad_t* p) { return wgrad_windows_of(p, kWWin, kWWin); }
 
 }  // namespace
 
@@ -2585,6 +2587,7 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     if (p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) np = (total_chunks + 3) / 4;   // streaming kernel: >= 128 rows per workgroup
     if (wgrad_is_wide(p)) {
         cap = 1024 / wgrad_windows(p);
+        if (wgrad_wbf_ns(p) > 0 && p->m > 128) cap = 256 / wgrad_windows_of(p, 256, 256);   // one 8-wave workgroup per CU
         if (cap < 4) cap = 4;
     }
     if (np > cap) np = cap;
@@ -2902,20 +2905,27 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     for (int s = 0; s < p->nsrc; ++s) nb_total += (p->src[s].width + 31) / 32;
     if (wgrad_is_wide(p) && wgrad_wbf_ns(p) > 0) {   // split-bf16 matrix path (nlam_wbf.inc)
         const int wns = wgrad_wbf_ns(p);
-        const int ksteps = 1;   // longer stages (KS = 4) lost 8 % with one term: the launch is at the HBM roof re-reading rows per window
-        const size_t lds = (size_t)2 * ksteps * 8 * wns * 1024;
-        const dim3 grid(p->nparts, wgrad_windows(p));
-#define NLAM_LAUNCH_WG_WBF(NS_, S_, KS_)                                                         \
-    do {                                                                                         \
-        int rc = set_lds(wgrad_wbf_kernel<NS_, S_, KS_>, lds);                                   \
-        if (rc != 0) return rc;                                                                  \
-        hipLaunchKernelGGL((wgrad_wbf_kernel<NS_, S_, KS_>), grid, dim3(256), lds, stream, *p);  \
+        // 256 x 256 windows (8 waves) when the output has more than 128 rows, 128 x 128 windows (4 waves) otherwise
+        const bool big = p->m > 128;
+        const int winm = big ? 256 : 128, winn = big ? 256 : 128;
+        const size_t lds = (size_t)2 * ((winm + winn) / 32) * wns * 1024;
+        const dim3 grid(p->nparts, wgrad_windows_of(p, winm, winn));
+#define NLAM_LAUNCH_WG_WBF(NS_, S_, WM_, WN_, NBW_)                                                                       \
+    do {                                                                                                                  \
+        int rc = set_lds(wgrad_wbf_kernel<NS_, S_, 1, WM_, WN_, NBW_>, lds);                                              \
+        if (rc != 0) return rc;                                                                                           \
+        hipLaunchKernelGGL((wgrad_wbf_kernel<NS_, S_, 1, WM_, WN_, NBW_>), grid, dim3(WM_ * WN_ * 64), lds, stream, *p);  \
+    } while (0)
+#define NLAM_LAUNCH_WG_WBF2(NS_, S_)                 \
+    do {                                             \
+        if (big) NLAM_LAUNCH_WG_WBF(NS_, S_, 4, 2, 4); \
+        else NLAM_LAUNCH_WG_WBF(NS_, S_, 2, 2, 2);     \
     } while (0)
         const bool silu = (p->flags & NLAM_F_SILU_B) != 0;
-        if (wns == 1 && silu) NLAM_LAUNCH_WG_WBF(1, true, 1);
-        else if (wns == 1) NLAM_LAUNCH_WG_WBF(1, false, 1);
-        else if (silu) NLAM_LAUNCH_WG_WBF(3, true, 1);
-        else NLAM_LAUNCH_WG_WBF(3, false, 1);
+        if (wns == 1 && silu) NLAM_LAUNCH_WG_WBF2(1, true);
+        else if (wns == 1) NLAM_LAUNCH_WG_WBF2(1, false);
+        else if (silu) NLAM_LAUNCH_WG_WBF2(3, true);
+        else NLAM_LAUNCH_WG_WBF2(3, false);
         return (int32_t)hipGetLastError();
     }
     if (wgrad_is_wide(p)) {
