@@ -47,6 +47,43 @@ def inverse_sigmoid(x):
     return torch.log(xc / (1 - xc))
 
 
+# compute the rollout's static embeddings on a side stream (GPU only; see BaseGraphModel.static_cache).  Off: measured
+# at cfg2 it costs 1 % (2.18 vs 2.16 ms/step, forecast 1 560 vs 1 580 steps/s) -- the four embedders then share the
+# CUs with the grid MLPs they were meant to hide behind, and their backward competes with the weight-gradient streams.
+STATIC_EMBEDDINGS_ASYNC = False
+
+
+class _AsyncEmbeddings:
+    """dict-like: values are produced on a side stream in the given order; ``[key]`` makes the current stream wait
+    for that value only."""
+
+    def __init__(self, items):
+        self._values, self._events, self._waited = {}, {}, set()
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for key, thunk in items:
+                self._values[key] = thunk()
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self._events[key] = ev
+        self._side = side
+
+    def __getitem__(self, key):
+        if key not in self._waited:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._events[key])
+            v = self._values[key]
+            for t in v if isinstance(v, (list, tuple)) else (v,):
+                t.record_stream(cur)
+            self._waited.add(key)
+        return self._values[key]
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self._side)
+
+
 class BufferList(nn.Module):
     """utils/buffer_list.py:11: list of non-persistent buffers."""
 
@@ -222,19 +259,31 @@ class BaseGraphModel(StepPredictor):
         self._enc_geom = MlpGeometry(nsrc=1, flags=L.F_ADD_SRC0)  # grid_emb + encoding_grid_mlp(grid_emb)
 
     # ---- input-independent embeddings: once per rollout instead of once per AR step ----
+    def static_embedding_items(self):
+        """(key, thunk) in the order the step needs them (encoder first, decoder last)."""
+        return [
+            ("mesh", self.embedd_mesh_nodes),
+            ("g2m", lambda: self.g2m_embedder(self.g2m_features)),
+            ("m2g", lambda: self.m2g_embedder(self.m2g_features)),
+        ]
+
     def compute_static_embeddings(self) -> dict:
-        return {
-            "g2m": self.g2m_embedder(self.g2m_features),
-            "m2g": self.m2g_embedder(self.m2g_features),
-            "mesh": self.embedd_mesh_nodes(),
-        }
+        return {k: f() for k, f in self.static_embedding_items()}
 
     @contextlib.contextmanager
     def static_cache(self):
-        self._static = self.compute_static_embeddings()
+        """Embeddings of the static graph features for a whole rollout.  On the GPU they are computed on a side
+        stream while the grid-side MLPs of the first step run (in a captured step: a parallel branch of the HIP
+        graph); autograd then runs their backward and weight gradients on that stream too, off the critical chain."""
+        if STATIC_EMBEDDINGS_ASYNC and self.grid_static_features.is_cuda:
+            self._static = _AsyncEmbeddings(self.static_embedding_items())
+        else:
+            self._static = self.compute_static_embeddings()
         try:
             yield
         finally:
+            if isinstance(self._static, _AsyncEmbeddings):
+                self._static.join()   # a forked stream must be back before a capture ends, used or not
             self._static = None
 
     def forward(self, prev_state, prev_prev_state, forcing):
@@ -247,8 +296,10 @@ class BaseGraphModel(StepPredictor):
         mesh_rep = self.g2m_gnn(
             grid_emb, self.expand_to_batch(st["mesh"], B), self.expand_to_batch(st["g2m"], B)
         )
+        # graph/base.py:308.  Kept after the g2m step as in the reference: issuing it first (it is independent) measured
+        # 2 % slower at cfg2 -- its 16 MB output then sits cold through the whole processor before m2g reads it.
         if self.encoding_grid_mlp.fully_fused:
-            grid_rep, _ = self.encoding_grid_mlp.forward_fused(self._enc_geom, grid_emb)  # graph/base.py:308
+            grid_rep, _ = self.encoding_grid_mlp.forward_fused(self._enc_geom, grid_emb)
         else:
             grid_rep = grid_emb + self.encoding_grid_mlp(grid_emb)
         mesh_rep = self.process_step(mesh_rep, st)
@@ -286,10 +337,9 @@ class GraphLAM(BaseGraphModel):
     def embedd_mesh_nodes(self):
         return self.mesh_embedder(self.mesh_static_features)
 
-    def compute_static_embeddings(self):
-        st = super().compute_static_embeddings()
-        st["m2m"] = self.m2m_embedder(self.m2m_features)
-        return st
+    def static_embedding_items(self):
+        items = super().static_embedding_items()
+        return items[:2] + [("m2m", lambda: self.m2m_embedder(self.m2m_features))] + items[2:]
 
     def process_step(self, mesh_rep, st=None):
         B = mesh_rep.shape[0]
@@ -334,13 +384,15 @@ class BaseHiGraphModel(BaseGraphModel):
     def embedd_mesh_nodes(self):
         return self.mesh_embedders[0](self.mesh_static_features[0])
 
-    def compute_static_embeddings(self):
-        st = super().compute_static_embeddings()
-        st["levels"] = [emb(f) for emb, f in zip(list(self.mesh_embedders)[1:], self.mesh_static_features[1:])]
-        st["same"] = [emb(f) for emb, f in zip(self.mesh_same_embedders, self.m2m_features)]
-        st["up"] = [emb(f) for emb, f in zip(self.mesh_up_embedders, self.mesh_up_features)]
-        st["down"] = [emb(f) for emb, f in zip(self.mesh_down_embedders, self.mesh_down_features)]
-        return st
+    def static_embedding_items(self):
+        items = super().static_embedding_items()
+        mine = [
+            ("levels", lambda: [emb(f) for emb, f in zip(list(self.mesh_embedders)[1:], self.mesh_static_features[1:])]),
+            ("up", lambda: [emb(f) for emb, f in zip(self.mesh_up_embedders, self.mesh_up_features)]),
+            ("same", lambda: [emb(f) for emb, f in zip(self.mesh_same_embedders, self.m2m_features)]),
+            ("down", lambda: [emb(f) for emb, f in zip(self.mesh_down_embedders, self.mesh_down_features)]),
+        ]
+        return items[:2] + mine + items[2:]
 
     def process_step(self, mesh_rep, st=None):
         B = mesh_rep.shape[0]

@@ -62,20 +62,33 @@ class _WgradOverlap:
     right after the data-gradient kernel; ``end()`` joins before the optimizer.  Inside a HIP-graph capture the fork /
     join become parallel branches of the graph.  Tensors the side stream reads are kept alive until the join."""
 
+    NSTREAMS = int(os.environ.get("NLAM_WGRAD_STREAMS", "4"))
+
     def __init__(self):
-        self.stream = None
+        self.streams = []
+        self.turn = 0
         self.active = False
         self.keep = []
 
     def begin(self):
-        if self.stream is None:
-            self.stream = torch.cuda.Stream()
+        if not self.streams:
+            self.streams = [torch.cuda.Stream() for _ in range(max(1, self.NSTREAMS))]
         self.active = True
+        self.turn = 0
         self.keep = []
+
+    def next_stream(self):
+        """Side streams are dealt round-robin, one per fused-MLP backward: on a single side stream the ~45
+        weight-gradient / reduction launches of a cfg2 step formed a 1.25 ms serial chain -- longer than the
+        data-gradient chain they were moved off (rocprofv3 kernel trace of the replayed graph)."""
+        st = self.streams[self.turn % len(self.streams)]
+        self.turn += 1
+        return st
 
     def end(self):
         if self.active:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            for st in self.streams:
+                torch.cuda.current_stream().wait_stream(st)
         self.keep = []
         self.active = False
 
@@ -373,9 +386,10 @@ class FusedMLPFunction(torch.autograd.Function):
         ]
         on_side = OVERLAP.active and all(is_direct(pp, sh) for _, need, pp, sh in wanted if need)
         if on_side:
-            OVERLAP.stream.wait_stream(torch.cuda.current_stream())
+            side = OVERLAP.next_stream()
+            side.wait_stream(torch.cuda.current_stream())
             OVERLAP.keep.extend([dz1, dz2, vecp, z1, *bases])
-            side_ctx = torch.cuda.stream(OVERLAP.stream)
+            side_ctx = torch.cuda.stream(side)
         else:
             side_ctx = contextlib.nullcontext()
 
