@@ -239,6 +239,15 @@ int32_t nlam_wmse_bwd(const float* pred, const float* target, const float* inv_v
                       const float* gscalar, int64_t rows, int32_t nodes, int32_t nvars, float scale, float* dpred,
                       void* hip_stream);
 
+/* State update of one autoregressive step, all optional terms in one pass over (rows, width) fp32 rows:
+ *   out[r][f] = a[r % nodes] * x[r][f]  +  c[r % nodes] * ( y[r][f] + z[r][f] * s[f] + m[f] )
+ * NULL x (with a), y, z (with s), m drop their term; NULL c means 1.  Replaces the elementwise chains
+ *   prev_state + (delta * diff_std + diff_mean)                step_predictors/graph/base.py:331-343, base.py:335-396 (no clamp)
+ *   boundary_mask * true_state + interior_mask * pred_state    forecasters/autoregressive.py:128-131
+ * and, with the roles of the operands permuted, their backward (g * interior_mask, g * diff_std). */
+int32_t nlam_affine_mix(const float* x, const float* a, const float* y, const float* c, const float* z, const float* s,
+                        const float* m, float* out, int64_t rows, int32_t nodes, int32_t width, void* hip_stream);
+
 /* decoupled-weight-decay Adam on flat buffers; step_count is the 1-based step */
 int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step_count,

@@ -25,6 +25,7 @@ EXPORTS = [
     "nlam_num_blocks",
     "nlam_max_width",
     "nlam_set_tuning",
+    "nlam_affine_mix",
     "nlam_mlp_fwd_wpack_floats",
     "nlam_mlp_bwd_wpack_floats",
     "nlam_mlp_bwd_blocks",
@@ -184,6 +185,8 @@ def load():
     lib.nlam_abi_version.restype = i32
     lib.nlam_grid_waves.restype = i32
     lib.nlam_max_width.restype = i32
+    lib.nlam_affine_mix.restype = i32
+    lib.nlam_affine_mix.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
     lib.nlam_set_tuning.restype = i32
     lib.nlam_set_tuning.argtypes = [i32, i32]
     lib.nlam_num_blocks.argtypes = [i64]

@@ -2320,6 +2320,24 @@ __global__ __launch_bounds__(256) void wmse_fwd_kernel(const float* pred, const 
     if (threadIdx.x == 0) partials[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
 }
 
+// out = a[node] * x + c[node] * (y + z * s[var] + m[var]); every term optional (see nlam_affine_mix)
+__global__ void affine_mix_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ y,
+                                  const float* __restrict__ c, const float* __restrict__ z, const float* __restrict__ s,
+                                  const float* __restrict__ m, float* __restrict__ out, long total, int nodes, int width) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / width;
+        const int f = (int)(e - r * width);
+        const int n = (int)(r % nodes);
+        float inner = 0.f;
+        if (y != nullptr) inner += y[e];
+        if (z != nullptr) inner += z[e] * s[f];
+        if (m != nullptr) inner += m[f];
+        if (c != nullptr) inner *= c[n];
+        if (x != nullptr) inner += a[n] * x[e];
+        out[e] = inner;
+    }
+}
+
 __global__ void wmse_bwd_kernel(const float* pred, const float* target, const float* inv_var, const float* row_weight,
                                 const float* gscalar, long total, int nodes, int nvars, float scale, float* dpred) {
     const float g = 2.f * scale * gscalar[0];
@@ -3035,6 +3053,19 @@ int32_t nlam_wmse_bwd(const float* pred, const float* target, const float* inv_v
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(wmse_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, pred, target, inv_var, row_weight,
                        gscalar, total, nodes, nvars, scale, dpred);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_affine_mix(const float* x, const float* a, const float* y, const float* c, const float* z, const float* s,
+                        const float* m, float* out, int64_t rows, int32_t nodes, int32_t width, void* hip_stream) {
+    if (out == nullptr || rows < 1 || nodes < 1 || width < 1) return NLAM_EINVAL;
+    if ((x == nullptr) != (a == nullptr) || (z == nullptr) != (s == nullptr)) return NLAM_EINVAL;
+    if (x == nullptr && y == nullptr && z == nullptr && m == nullptr) return NLAM_EINVAL;
+    const long total = (long)rows * width;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(affine_mix_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, x, a, y, c, z, s, m, out, total,
+                       nodes, width);
     return (int32_t)hipGetLastError();
 }
 

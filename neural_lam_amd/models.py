@@ -47,6 +47,10 @@ def inverse_sigmoid(x):
     return torch.log(xc / (1 - xc))
 
 
+import os as _os
+
+FUSED_STATE_UPDATE = _os.environ.get("NLAM_FUSED_STATE_UPDATE", "1") == "1"   # nlam_affine_mix for the elementwise tail of a step
+
 # compute the rollout's static embeddings on a side stream (GPU only; see BaseGraphModel.static_cache).  Off: measured
 # at cfg2 it costs 1 % (2.18 vs 2.16 ms/step, forecast 1 560 vs 1 580 steps/s) -- the four embedders then share the
 # CUs with the grid MLPs they were meant to hide behind, and their backward competes with the weight-gradient streams.
@@ -310,6 +314,13 @@ class BaseGraphModel(StepPredictor):
             pred_std = torch.nn.functional.softplus(pred_std_raw)
         else:
             pred_delta_mean, pred_std = net_output, None
+        no_clamp = self.clamp_lower_upper_idx.numel() + self.clamp_lower_idx.numel() + self.clamp_upper_idx.numel() == 0
+        if FUSED_STATE_UPDATE and no_clamp and pred_delta_mean.is_cuda and self.diff_std.dim() == 1:
+            from .ops import AffineMixFunction
+
+            # prev_state + (delta * diff_std + diff_mean) in one pass (three elementwise launches in the reference)
+            new_state = AffineMixFunction.apply(None, None, prev_state, None, pred_delta_mean, self.diff_std, self.diff_mean)
+            return new_state, pred_std
         rescaled = pred_delta_mean * self.diff_std + self.diff_mean
         return self.get_clamped_new_state(rescaled, prev_state), pred_std
 
@@ -525,7 +536,14 @@ class ARForecaster(nn.Module):
         with cache:
             for i in range(forcing_features.shape[1]):
                 pred_state, pred_std = self.predictor(prev_state, prev_prev_state, forcing_features[:, i])
-                new_state = self.boundary_mask * boundary_states[:, i] + self.interior_mask * pred_state
+                if FUSED_STATE_UPDATE and pred_state.is_cuda and pred_state.dtype == torch.float32:
+                    from .ops import AffineMixFunction
+
+                    # autoregressive.py:128-131 in one pass
+                    new_state = AffineMixFunction.apply(boundary_states[:, i], self.boundary_mask.reshape(-1), pred_state,
+                                                        self.interior_mask.reshape(-1), None, None, None)
+                else:
+                    new_state = self.boundary_mask * boundary_states[:, i] + self.interior_mask * pred_state
                 preds.append(new_state)
                 if pred_std is not None:
                     stds.append(pred_std)

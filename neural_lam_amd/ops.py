@@ -503,6 +503,48 @@ class WmseLossFunction(torch.autograd.Function):
         return dpred, None, None, None
 
 
+def _affine_mix(x, a, y, c, z, s, m, like):
+    """out = a[node] * x + c[node] * (y + z * s[var] + m[var]) on (..., N, F) fp32 tensors; any term may be None."""
+    lib = L.load()
+    N, F = like.shape[-2], like.shape[-1]
+    out = torch.empty(like.shape, device=like.device, dtype=torch.float32)
+    rc = lib.nlam_affine_mix(_ptr(x), _ptr(a), _ptr(y), _ptr(c), _ptr(z), _ptr(s), _ptr(m), _ptr(out),
+                             out.numel() // F, N, F, _stream())
+    L.check(rc, "nlam_affine_mix")
+    return out
+
+
+class AffineMixFunction(torch.autograd.Function):
+    """One pass for the elementwise tail of an autoregressive step (include/nlam_hip.h, nlam_affine_mix):
+
+        out = a * x + c * (y + z * s + m)        a, c: per node (N,) or None; s, m: per variable (F,) or None
+
+    ``prev_state + (delta * diff_std + diff_mean)`` is (y = prev, z = delta, s, m); the boundary overwrite
+    ``boundary_mask * truth + interior_mask * pred`` is (a, x = truth, c, y = pred).  Gradients flow to y and z (x is
+    data, a / c / s / m are buffers); each is the same kernel with the operands permuted."""
+
+    @staticmethod
+    def forward(ctx, x, a, y, c, z, s, m):
+        like = y if y is not None else z
+        tens = [t for t in (x, a, y, c, z, s, m) if t is not None]
+        _require_gpu(*tens)
+        cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        x, a, y, c, z, s, m = map(cont, (x, a, y, c, z, s, m))
+        ctx.save_for_backward(c, s)
+        return _affine_mix(x, a, y, c, z, s, m, like)
+
+    @staticmethod
+    def backward(ctx, g):
+        c, s = ctx.saved_tensors
+        g = g.contiguous()
+        gy = gz = None
+        if ctx.needs_input_grad[2]:
+            gy = _affine_mix(None, None, g, c, None, None, None, g) if c is not None else g
+        if ctx.needs_input_grad[4]:
+            gz = _affine_mix(None, None, None, c, g, s, None, g)
+        return None, None, gy, None, gz, None, None
+
+
 class AdamWFlat:
     """torch.optim.AdamW(lr, betas=(0.9, 0.95)) semantics (models/module.py:293-304)
     on one flat fp32 buffer: a single HBM-bound kernel per step."""
