@@ -47,9 +47,8 @@ def inverse_sigmoid(x):
     return torch.log(xc / (1 - xc))
 
 
-import os as _os
-
-FUSED_STATE_UPDATE = _os.environ.get("NLAM_FUSED_STATE_UPDATE", "1") == "1"   # nlam_affine_mix for the elementwise tail of a step
+# nlam_affine_mix for the elementwise tail of a step (A/B on one box: +3 % forecast rate, +1 % training rate)
+FUSED_STATE_UPDATE = True
 
 # compute the rollout's static embeddings on a side stream (GPU only; see BaseGraphModel.static_cache).  Off: measured
 # at cfg2 it costs 1 % (2.18 vs 2.16 ms/step, forecast 1 560 vs 1 580 steps/s) -- the four embedders then share the
