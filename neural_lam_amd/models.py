@@ -314,7 +314,8 @@ class BaseGraphModel(StepPredictor):
         else:
             pred_delta_mean, pred_std = net_output, None
         no_clamp = self.clamp_lower_upper_idx.numel() + self.clamp_lower_idx.numel() + self.clamp_upper_idx.numel() == 0
-        if FUSED_STATE_UPDATE and no_clamp and pred_delta_mean.is_cuda and self.diff_std.dim() == 1:
+        if (FUSED_STATE_UPDATE and no_clamp and pred_delta_mean.is_cuda and self.diff_std.dim() == 1
+                and pred_delta_mean.dtype == torch.float32 and prev_state.dtype == torch.float32):
             from .ops import AffineMixFunction
 
             # prev_state + (delta * diff_std + diff_mean) in one pass (three elementwise launches in the reference)
@@ -535,7 +536,8 @@ class ARForecaster(nn.Module):
         with cache:
             for i in range(forcing_features.shape[1]):
                 pred_state, pred_std = self.predictor(prev_state, prev_prev_state, forcing_features[:, i])
-                if FUSED_STATE_UPDATE and pred_state.is_cuda and pred_state.dtype == torch.float32:
+                if (FUSED_STATE_UPDATE and pred_state.is_cuda and pred_state.dtype == torch.float32
+                        and boundary_states.dtype == torch.float32):
                     from .ops import AffineMixFunction
 
                     # autoregressive.py:128-131 in one pass
