@@ -204,6 +204,39 @@ def test_wide_layer_matches_oracle(dev, cls_name, d, update_edges, wide_family):
         assert rel_err(p.grad.cpu(), q.grad) < TOL, k
 
 
+@pytest.mark.parametrize("cls_name,d,ns,nr,e", [
+    ("InteractionNet", 128, 40, 7, 1500),     # in-degree ~214: every receiver spans several 32-row tiles (split tiles)
+    ("PropagationNet", 128, 5, 300, 1400),    # out-degree ~280 senders, mean aggregation, sender residual
+    ("InteractionNet", 256, 300, 300, 5),     # almost every node isolated; a handful of edges
+    ("PropagationNet", 256, 33, 65, 2081),    # ragged: 65 tiles + 1 row
+])
+def test_wide_layers_on_awkward_graphs(dev, cls_name, d, ns, nr, e, wide_family):
+    """Split receivers (atomic adds in the aggregate and in the receiver gradients), isolated nodes and ragged last
+    tiles through both wide kernel families."""
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    ei = _rand_ei(ns, nr, e, seed=e)
+    torch.manual_seed(e)
+    ref = getattr(og, cls_name)(ei, d)
+    net = getattr(hl, cls_name)(ei, d)
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    B = 2
+    send, rec, edge = torch.randn(B, ns, d), torch.randn(B, nr, d), torch.randn(B, e, d)
+    s1, r1, e1 = (t.clone().requires_grad_() for t in (send, rec, edge))
+    s2, r2, e2 = (t.to(dev).requires_grad_() for t in (send, rec, edge))
+    o1, o2 = ref(s1, r1, e1), net(s2, r2, e2)
+    for a, b in zip(o2, o1):
+        assert rel_err(a.cpu(), b) < TOL
+    sum((o * o).sum() for o in o1).backward()
+    sum((o * o).sum() for o in o2).backward()
+    for a, b in ((s2, s1), (r2, r1), (e2, e1)):
+        assert rel_err(a.grad.cpu(), b.grad) < TOL
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < TOL, k
+
+
 @pytest.mark.parametrize("kin,hid,dout,ln", [
     (3, 64, 64, True), (56, 64, 64, True), (64, 64, 17, False), (2, 16, 16, True), (7, 12, 5, False),
     (56, 256, 256, True), (256, 256, 17, False), (3, 128, 128, True), (128, 64, 64, True), (130, 96, 40, True),
