@@ -549,7 +549,10 @@ class ARForecaster(nn.Module):
                 if pred_std is not None:
                     stds.append(pred_std)
                 prev_prev_state, prev_state = prev_state, new_state
-        return torch.stack(preds, dim=1), (torch.stack(stds, dim=1) if stds else None)
+        def _stack(xs):   # a one-step rollout needs no copy
+            return xs[0].unsqueeze(1) if len(xs) == 1 else torch.stack(xs, dim=1)
+
+        return _stack(preds), (_stack(stds) if stds else None)
 
 
 def mask_and_reduce_metric(vals, mask, average_grid, sum_vars):
@@ -591,8 +594,10 @@ class ForecasterStep(nn.Module):
             w = torch.tensor([1.0 / n] * n, dtype=torch.float32)  # loss_weighting.py:60-79 (uniform)
             diff_std = torch.tensor(st.state_diff_std_standardized.values, dtype=torch.float32)
             self.register_buffer("per_var_std", diff_std / torch.sqrt(w), persistent=False)
+            self.register_buffer("inv_var", 1.0 / (self.per_var_std * self.per_var_std), persistent=False)   # 1 / std^2 of wmse
         else:
             self.per_var_std = None
+            self.inv_var = None
         self.register_buffer("state_mean", torch.tensor(st.state_mean.values, dtype=torch.float32), persistent=False)
         self.register_buffer(
             "state_std", torch.clamp(torch.tensor(st.state_std.values, dtype=torch.float32), min=eps), persistent=False
@@ -623,8 +628,7 @@ class ForecasterStep(nn.Module):
             # fixed per-variable std: wmse + interior mask + the grid / batch / step means in one HBM-bound kernel pair
             from .ops import WmseLossFunction
 
-            inv_var = 1.0 / (self.per_var_std * self.per_var_std)
-            return prediction, WmseLossFunction.apply(prediction, target_states, inv_var, self.interior_weight)
+            return prediction, WmseLossFunction.apply(prediction, target_states, self.inv_var, self.interior_weight)
         if pred_std is None:
             pred_std = self.per_var_std
         time_step_loss = torch.mean(wmse(prediction, target_states, pred_std, mask=self.interior_index), dim=0)
