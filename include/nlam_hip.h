@@ -202,6 +202,12 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream);
 int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order,
                          const float* scale, float* out, int32_t nseg, int32_t width, int32_t batch,
                          void* hip_stream);
+/* same, added onto what `out` already holds (out += ...): lets the sender-side gradient of a layer whose senders
+ * and receivers are the same nodes (mesh <-> mesh) land in the receiver-side gradient buffer instead of a second
+ * tensor that autograd would add with one more launch */
+int32_t nlam_segment_sum_acc(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order,
+                         const float* scale, float* out, int32_t nseg, int32_t width, int32_t batch,
+                         void* hip_stream);
 
 /* out[i] (+)= sum_p partials[p * stride + i], i < n ; accumulate != 0 adds into out */
 int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stride, int32_t n, float* out,

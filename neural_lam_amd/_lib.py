@@ -34,6 +34,7 @@ EXPORTS = [
     "nlam_mlp_bwd",
     "nlam_wgrad",
     "nlam_segment_sum",
+    "nlam_segment_sum_acc",
     "nlam_reduce_partials",
     "nlam_reduce_jobs",
     "nlam_wmse_fwd",
@@ -207,6 +208,8 @@ def load():
     lib.nlam_wgrad.restype = i32
     lib.nlam_segment_sum.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.nlam_segment_sum.restype = i32
+    lib.nlam_segment_sum_acc.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.nlam_segment_sum_acc.restype = i32
     lib.nlam_reduce_partials.argtypes = [vp, i32, i64, i32, vp, i32, vp]
     lib.nlam_reduce_partials.restype = i32
     lib.nlam_reduce_jobs.argtypes = [C.POINTER(ReduceJobs), vp]

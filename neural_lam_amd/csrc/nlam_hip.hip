@@ -2202,7 +2202,7 @@ __global__ __launch_bounds__(256) void wgrad_smalln_kernel(const nlam_wgrad_t p)
 // small HBM-bound kernels
 // ---------------------------------------------------------------------------
 __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32_t* ptr, const int32_t* order,
-                                   const float* scale, float* out, int nseg, int width, int batch) {
+                                   const float* scale, float* out, int nseg, int width, int batch, int accumulate) {
     const int w4 = (width + 3) >> 2;
     const long total = (long)batch * nseg * w4;
     for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
@@ -2232,7 +2232,9 @@ __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32
                 const long row = order != nullptr ? order[q] : q;
                 acc += *reinterpret_cast<const f32x4*>(base + row * width + 4 * c4);
             }
-            *reinterpret_cast<f32x4*>(o) = acc * sc;
+            if (accumulate) acc = acc * sc + *reinterpret_cast<const f32x4*>(o);   // every output row has exactly one writer
+            else acc = acc * sc;
+            *reinterpret_cast<f32x4*>(o) = acc;
         } else {
             for (int c = 0; c < 4 && 4 * c4 + c < width; ++c) {
                 float acc = 0.f;
@@ -2240,7 +2242,7 @@ __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32
                     const long row = order != nullptr ? order[q] : q;
                     acc += base[row * width + 4 * c4 + c];
                 }
-                o[c] = acc * sc;
+                o[c] = accumulate ? o[c] + acc * sc : acc * sc;
             }
         }
     }
@@ -2998,16 +3000,26 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     return (int32_t)hipGetLastError();
 }
 
-int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
-                         float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream) {
+static int32_t segment_sum_launch(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
+                                  float* out, int32_t nseg, int32_t width, int32_t batch, int accumulate, void* hip_stream) {
     if (in == nullptr || ptr == nullptr || out == nullptr || nseg < 0 || width < 1 || batch < 1) return NLAM_EINVAL;
     if (nseg == 0) return 0;
     const long total = (long)batch * nseg * ((width + 3) / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(segment_sum_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, in, (long)in_bstride,
-                       ptr, order, scale, out, nseg, width, batch);
+                       ptr, order, scale, out, nseg, width, batch, accumulate);
     return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
+                         float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream) {
+    return segment_sum_launch(in, in_bstride, ptr, order, scale, out, nseg, width, batch, 0, hip_stream);
+}
+
+int32_t nlam_segment_sum_acc(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
+                             float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream) {
+    return segment_sum_launch(in, in_bstride, ptr, order, scale, out, nseg, width, batch, 1, hip_stream);
 }
 
 int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stride, int32_t n, float* out,

@@ -202,12 +202,14 @@ def _fill_src(dst, tensor, bstride, width, idx):
     dst.width = width
 
 
-def segment_sum(inp, in_bstride, ptr, order, scale, nseg, width, batch, out=None):
-    """out[b, s] = scale[s] * sum_{q in ptr[s]:ptr[s+1]} inp[b, order[q]]"""
+def segment_sum(inp, in_bstride, ptr, order, scale, nseg, width, batch, out=None, accumulate=False):
+    """out[b, s] (+)= scale[s] * sum_{q in ptr[s]:ptr[s+1]} inp[b, order[q]]"""
     _require_gpu(inp)
     if out is None:
+        assert not accumulate
         out = torch.empty((batch, nseg, width), device=inp.device, dtype=torch.float32)
-    rc = L.load().nlam_segment_sum(
+    fn = L.load().nlam_segment_sum_acc if accumulate else L.load().nlam_segment_sum
+    rc = fn(
         _ptr(inp), in_bstride, _ptr(ptr), _ptr(order), _ptr(scale), _ptr(out), nseg, width, batch, _stream()
     )
     L.check(rc, "nlam_segment_sum")
@@ -283,6 +285,14 @@ class FusedMLPFunction(torch.autograd.Function):
             ctx.geom, ctx.B, ctx.rows, ctx.ntiles = geom, B, rows, ntiles
             ctx.binfo = [(b_, bstride) for (_, b_, bstride, _) in binfo]
             ctx.src_shapes = [tuple(s.shape) for s in srcs]
+            # a sender source (dmode 2) that is the very tensor also passed as the receiver source (dmode 3)
+            ctx.twin_of = {}
+            for k in range(geom.nsrc):
+                for t in range(geom.nsrc):
+                    if (t != k and geom.dmode[k] == 2 and geom.dmode[t] == 3 and srcs[k].data_ptr() == srcs[t].data_ptr()
+                            and srcs[k].shape == srcs[t].shape and srcs[k].stride() == srcs[t].stride()
+                            and ctx.needs_input_grad[7 + k] and ctx.needs_input_grad[7 + t]):
+                        ctx.twin_of[k] = t
             ctx.has_ln = ln_w is not None
             ctx.param_refs = (W1, b1, W2, b2, ln_w, ln_b)   # for .grad views only (DIRECT_PARAM_GRADS)
             ctx.save_for_backward(W1c, W2c, ln_w, z1, xhat, rstd, *[bi[0] for bi in binfo])
@@ -363,9 +373,17 @@ class FusedMLPFunction(torch.autograd.Function):
 
         for k in range(nsrc):
             if tmp2[k] is not None:  # finish scatter-by-sender as a CSC segment sum
-                dsrc[k] = segment_sum(
-                    tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B
-                )
+                tw = ctx.twin_of.get(k)
+                if tw is not None and dsrc[tw] is not None and dsrc[tw].shape == (B, geom.num_send, widths[k]):
+                    # senders and receivers are the same tensor (mesh <-> mesh layers): add onto the receiver-side
+                    # gradient and report nothing for this slot -- one autograd add launch less per layer
+                    segment_sum(tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B,
+                                out=dsrc[tw], accumulate=True)
+                    dsrc[k] = None
+                else:
+                    dsrc[k] = segment_sum(
+                        tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B
+                    )
 
         # ---- weight gradients: two TN GEMMs with deterministic two-stage reduction ----
         # ---- weight gradients: TN GEMMs with a deterministic two-stage reduction; on the side stream when the

@@ -597,6 +597,32 @@ def test_wide_kernel_families_agree_at_meps_size(dev, d, which, update_edges):
     assert all(torch.equal(x, y) for x, y in zip(b, c))
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_same_tensor_as_sender_and_receiver(dev, d, wide_family):
+    """Mesh <-> mesh layers get one tensor as both node sets (graph_lam.py:168-188): the sender-side gradient is then
+    accumulated into the receiver-side buffer inside the library (nlam_segment_sum_acc) and must equal the oracle's
+    sum of the two autograd contributions."""
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    n, e, B = 57, 1311, 2
+    ei = _rand_ei(n, n, e, seed=3)
+    torch.manual_seed(3)
+    ref = og.InteractionNet(ei, d)
+    net = hl.InteractionNet(ei, d)
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    x, edge = torch.randn(B, n, d), torch.randn(B, e, d)
+    x1, e1 = x.clone().requires_grad_(), edge.clone().requires_grad_()
+    x2, e2 = x.to(dev).requires_grad_(), edge.to(dev).requires_grad_()
+    o1, o2 = ref(x1, x1, e1), net(x2, x2, e2)
+    for a, b in zip(o2, o1):
+        assert rel_err(a.cpu(), b) < TOL
+    sum((o * o).sum() for o in o1).backward()
+    sum((o * o).sum() for o in o2).backward()
+    assert rel_err(x2.grad.cpu(), x1.grad) < TOL and rel_err(e2.grad.cpu(), e1.grad) < TOL
+
+
 def test_fused_wmse_loss_matches_reference_formula(dev):
     """nlam_wmse_fwd/bwd == metrics.wmse + mask_and_reduce_metric + batch/step means (metrics.py:37-137, module.py:463-510)."""
     from neural_lam_amd import models as hm
