@@ -205,8 +205,7 @@ class Trainer:
                 self.use_graph = False
                 torch.cuda.synchronize()
                 return self.step(*batch)
-        for s, b in zip(self._static_in, batch):
-            s.copy_(b)
+        torch._foreach_copy_(self._static_in, list(batch))   # one multi-tensor launch instead of one copy per input
         self._graph.replay()
         if self.world > 1:   # one flat buffer: a single collective (0.86 MB at cfg2, 20.6 MB at cfg3)
             dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.buckets.group)
