@@ -185,3 +185,51 @@ def test_two_rank_step_on_gpu_matches_single_process_average(tmp_path, use_graph
     for _ in range(4):
         ref.step(*both)
     assert torch.allclose(ref.fp.flat.cpu(), r0["flat"], rtol=2e-5, atol=2e-6)
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+    from neural_lam_amd import gnn_layers as hl
+    from neural_lam_amd.trainer import Trainer
+
+    warm = torch.ones(8, device=dev)
+    dist.all_reduce(warm)   # communicator + watchdog thread are live before the capture
+    torch.manual_seed(0)
+    ei = torch.stack([torch.randint(0, 60, (900,)), torch.randint(0, 50, (900,))])
+    ei[1, -1] = 49
+
+    class Step(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = hl.InteractionNet(ei, 64)
+
+        def forward(self, send, rec, edge):
+            r, e = self.net(send, rec, edge)
+            return (r.square().mean() + e.square().mean(),)
+
+    trainer = Trainer(Step().to(dev), lr=1e-2, use_graph=True)
+    batch = tuple(torch.randn(1, n, 64, device=dev) for n in (60, 50, 900))
+    losses = []
+    for _ in range(4):
+        losses.append(float(trainer.step(*batch)))
+        dist.all_reduce(trainer.fp.grad)   # what the N > 1 step issues after every replay
+    torch.cuda.synchronize()
+    torch.save({"losses": losses, "graph": trainer._graph is not None}, f"{out_dir}/rccl.pt")
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_graph_capture_with_live_rccl_process_group(tmp_path):
+    """One rank, backend "nccl" (= RCCL): the HIP-graph capture of the step has to coexist with an initialised
+    communicator and its watchdog thread (capture_error_mode="thread_local"), and collectives issued between
+    replays must keep working.  More ranks need more GPUs; the driver's multi-GPU bench covers those."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "rccl.pt", weights_only=False)
+    assert r["graph"], "capture fell back to eager launches"
+    assert all(l == l for l in r["losses"]) and r["losses"][-1] < r["losses"][0]
