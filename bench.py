@@ -164,11 +164,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); CPU numbers come from the cpu_baseline leg only")
+    # dry run of the N > 1 code on a 1-GPU box: NLAM_BENCH_DRYRUN=1 puts every rank on cuda:0 over gloo (numbers are
+    # meaningless then; it only checks the multi-rank control flow)
+    dryrun = os.environ.get("NLAM_BENCH_DRYRUN") == "1"
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if dryrun:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     from neural_lam_amd import ops
     from neural_lam_amd.trainer import Trainer
