@@ -59,6 +59,8 @@ CONFIGS = {
                  graph=dict(n_max_levels=None, hierarchical=False), boundary="frame"),
     "cfg4": dict(nx=238, ny=268, ns=17, nf=6, nst=4, d=128, L=4, T=1, B=1, model="hi_lam",
                  graph=dict(n_max_levels=3, hierarchical=True), boundary="frame"),
+    "cfg4p": dict(nx=238, ny=268, ns=17, nf=6, nst=4, d=128, L=4, T=1, B=1, model="hi_lam_parallel",
+                  graph=dict(n_max_levels=3, hierarchical=True), boundary="frame"),
     "cfg5": dict(nx=238, ny=268, ns=17, nf=6, nst=4, d=512, L=8, T=8, B=1, model="graph_lam",
                  graph=dict(n_max_levels=None, hierarchical=False), boundary="frame"),
 }

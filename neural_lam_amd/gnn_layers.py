@@ -259,7 +259,12 @@ class InteractionNet(nn.Module):
     def _messages_generic(self, csr, send_rep, rec_rep, edge_rep, want_out, add_edge):
         # chunked edge MLPs (HiLAMParallel): per-chunk fused MLP kernels over an explicit
         # gathered concat; aggregation by the CSR segment-sum kernel.
-        ei = self._edge_index_local.to(send_rep.device)
+        # device copy of the local edge index, made once per device (a host-to-device copy per call would also be
+        # illegal inside a HIP-graph capture; the trainer's warm-up steps populate this cache before capturing)
+        dkey = ("ei", str(send_rep.device))
+        if dkey not in self._geom_cache:
+            self._geom_cache[dkey] = self._edge_index_local.to(send_rep.device)
+        ei = self._geom_cache[dkey]
         x_j = send_rep.index_select(-2, ei[0])
         x_i = rec_rep.index_select(-2, ei[1])
         msgs = self.edge_mlp(torch.cat((edge_rep.expand(*x_j.shape[:-2], -1, -1), x_j, x_i), dim=-1))
