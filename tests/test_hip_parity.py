@@ -649,6 +649,8 @@ def test_fused_wmse_loss_matches_reference_formula(dev):
     ("graph_lam", dict(hidden_dim=16, processor_layers=2, output_clamping_lower={"state_var_0": 0.0},
                        output_clamping_upper={"state_var_0": 9.0, "state_var_2": 5.0})),
     ("graph_lam", dict(hidden_dim=128, processor_layers=1)),
+    ("graph_lam", dict(hidden_dim=16, processor_layers=1, output_std=True, g2m_gnn_type="PropagationNet",
+                       m2g_gnn_type="PropagationNet", mesh_aggr="mean")),
     ("hi_lam", dict(hidden_dim=16, processor_layers=2)),
     ("hi_lam_parallel", dict(hidden_dim=16, processor_layers=2)),
 ])
