@@ -264,7 +264,8 @@ def main():
                 terms = 3   # the wide kernels instantiate one and three terms
             mfmas = terms * (terms + 1) // 2   # bf16 MFMAs executed per algorithmic product block
             if d <= 64:
-                kname = "mlp_fwd_bf_kernel<2,2,%d>" % terms if terms else "mlp_fwd_kernel<2,2,FAST>"
+                hb = (d + 31) // 32
+                kname = ("mlp_fwd_bf_kernel<%d,%d,%d>" % (hb, hb, terms)) if terms and d % 32 == 0 else "mlp_fwd_kernel<%d,%d>" % (hb, hb)
             else:
                 kname = "mlp_fwd_wbf_kernel<%d,..>" % terms if terms else "mlp_fwd_wide_kernel"
             roofline = {
