@@ -27,8 +27,16 @@
  *         edge_rep + edge_diff                       gnn_layers.py:144-155, 168-189, 241-249
  *   nlam_wgrad
  *       autograd's weight gradients of the nn.Linear layers inside those MLPs.
- *   nlam_segment_sum
- *       autograd of index_select (= index_add by sender), as a CSC segment sum.
+ *   nlam_segment_sum, nlam_segment_sum_acc
+ *       autograd of index_select (= index_add by sender), as a CSC segment sum; _acc adds onto
+ *       an existing gradient buffer (what autograd's accumulation would do with one more launch).
+ *   nlam_affine_mix
+ *       the elementwise tail of an AR step: prev_state + delta * diff_std + diff_mean
+ *       (step_predictors/graph/base.py:331-343) and the boundary overwrite
+ *       (forecasters/autoregressive.py:128-131), forward and backward.
+ *   nlam_wmse_fwd / nlam_wmse_bwd
+ *       metrics.wmse + mask_and_reduce_metric (metrics.py:37-137) with the batch / step means of
+ *       models/module.py:463-510.
  *   nlam_reduce_partials
  *       deterministic second stage of the per-workgroup partial sums.
  *   nlam_adamw_step
