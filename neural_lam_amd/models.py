@@ -50,43 +50,6 @@ def inverse_sigmoid(x):
 # nlam_affine_mix for the elementwise tail of a step (A/B on one box: +3 % forecast rate, +1 % training rate)
 FUSED_STATE_UPDATE = True
 
-# compute the rollout's static embeddings on a side stream (GPU only; see BaseGraphModel.static_cache).  Off: measured
-# at cfg2 it costs 1 % (2.18 vs 2.16 ms/step, forecast 1 560 vs 1 580 steps/s) -- the four embedders then share the
-# CUs with the grid MLPs they were meant to hide behind, and their backward competes with the weight-gradient streams.
-STATIC_EMBEDDINGS_ASYNC = False
-
-
-class _AsyncEmbeddings:
-    """dict-like: values are produced on a side stream in the given order; ``[key]`` makes the current stream wait
-    for that value only."""
-
-    def __init__(self, items):
-        self._values, self._events, self._waited = {}, {}, set()
-        main = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            for key, thunk in items:
-                self._values[key] = thunk()
-                ev = torch.cuda.Event()
-                ev.record(side)
-                self._events[key] = ev
-        self._side = side
-
-    def __getitem__(self, key):
-        if key not in self._waited:
-            cur = torch.cuda.current_stream()
-            cur.wait_event(self._events[key])
-            v = self._values[key]
-            for t in v if isinstance(v, (list, tuple)) else (v,):
-                t.record_stream(cur)
-            self._waited.add(key)
-        return self._values[key]
-
-    def join(self):
-        torch.cuda.current_stream().wait_stream(self._side)
-
-
 class BufferList(nn.Module):
     """utils/buffer_list.py:11: list of non-persistent buffers."""
 
@@ -275,18 +238,13 @@ class BaseGraphModel(StepPredictor):
 
     @contextlib.contextmanager
     def static_cache(self):
-        """Embeddings of the static graph features for a whole rollout.  On the GPU they are computed on a side
-        stream while the grid-side MLPs of the first step run (in a captured step: a parallel branch of the HIP
-        graph); autograd then runs their backward and weight gradients on that stream too, off the critical chain."""
-        if STATIC_EMBEDDINGS_ASYNC and self.grid_static_features.is_cuda:
-            self._static = _AsyncEmbeddings(self.static_embedding_items())
-        else:
-            self._static = self.compute_static_embeddings()
+        """Embeddings of the static graph features, computed once for a whole rollout.  (Computing them on side
+        streams next to the first grid MLPs was measured and dropped: -1 % with one side stream, -3 % with one per
+        embedder -- DESIGN.md, "measured and dropped".)"""
+        self._static = self.compute_static_embeddings()
         try:
             yield
         finally:
-            if isinstance(self._static, _AsyncEmbeddings):
-                self._static.join()   # a forked stream must be back before a capture ends, used or not
             self._static = None
 
     def forward(self, prev_state, prev_prev_state, forcing):
