@@ -234,14 +234,54 @@ def check(rc: int, what: str):
         raise RuntimeError(f"{what} failed: {kind}")
 
 
-def build(verbose: bool = False, out: Path | None = None, defines=()) -> Path:
-    """Compile csrc/nlam_hip.hip for gfx950 into the in-tree shared library."""
-    import subprocess
+SLICES = (1, 2, 3, 4)   # -DNLAM_TU=k translation-unit slices of csrc/nlam_hip.hip (see the comment at its top)
 
-    src = HERE / "csrc" / "nlam_hip.hip"
+
+def build(verbose: bool = False, out: Path | None = None, defines=(), single_tu: bool | None = None) -> Path:
+    """Compile csrc/nlam_hip.hip for gfx950 into the in-tree shared library.
+
+    Default: the four -DNLAM_TU=k slices are compiled in parallel (objects under csrc/_obj/, re-used when neither the
+    sources nor the flags changed) and linked.  ``single_tu=True`` (and any build with extra ``defines``, e.g. the
+    NLAM_TIMING instrumentation) is the one-command build: one hipcc invocation, everything in one translation unit."""
+    import hashlib
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+
+    csrc = HERE / "csrc"
+    src = csrc / "nlam_hip.hip"
     out = Path(out) if out is not None else HERE / "libnlam_hip.so"
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", *[f"-D{d}" for d in defines], str(src), "-o", str(out)]
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *[f"-D{d}" for d in defines]]
+    if single_tu is None:
+        single_tu = bool(defines) or os.environ.get("NLAM_SINGLE_TU") == "1"
+    if single_tu:
+        cmd = [*base, "-shared", str(src), "-o", str(out)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        return out
+
+    objdir = csrc / "_obj"
+    objdir.mkdir(exist_ok=True)
+    h = hashlib.sha256(" ".join(base).encode())
+    for f in sorted([*csrc.glob("*.hip"), *csrc.glob("*.inc"), HERE.parent / "include" / "nlam_hip.h"]):
+        h.update(f.read_bytes())
+    stamp = h.hexdigest()[:16]
+
+    def compile_slice(k):
+        obj = objdir / f"nlam_tu{k}_{stamp}.o"
+        if not obj.exists():
+            for old in objdir.glob(f"nlam_tu{k}_*.o"):
+                old.unlink()
+            cmd = [*base, f"-DNLAM_TU={k}", "-c", str(src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(len(SLICES)) as ex:
+        objs = list(ex.map(compile_slice, SLICES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(out)]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -33,6 +33,35 @@
 
 #include "../../include/nlam_hip.h"
 
+// ---------------------------------------------------------------------------
+// Translation-unit slices.  Every kernel here is a template that is instantiated only where a launcher names it, so
+// the same source can be compiled several times with -DNLAM_TU=k, each time emitting one family's launchers (and with
+// them that family's kernels): the four objects build in parallel and link into one library (neural_lam_amd/_lib.py).
+// NLAM_TU undefined or 0 = everything in one translation unit (the one-command build of INTEGRATION.md, and the
+// -DNLAM_TIMING build, whose counters live in one device variable).
+//   1  C-ABI entry points, argument checks, HBM-bound helper kernels, narrow (d <= 64) forward
+//   2  narrow backward + weight gradients
+//   3  fp32 MFMA kernels for 64 < d <= 512 (nlam_wide.inc)
+//   4  split-bf16 kernels for 64 < d <= 512 (nlam_wbf.inc)
+// ---------------------------------------------------------------------------
+#ifndef NLAM_TU
+#define NLAM_TU 0
+#endif
+#define NLAM_IN_TU(k) (NLAM_TU == 0 || NLAM_TU == (k))
+
+namespace nlam_detail {   // launchers: external linkage, each defined in exactly one slice; arguments are already validated
+int32_t fwd_narrow(const nlam_mlp_fwd_t* p, hipStream_t stream);   // slice 1
+int32_t bwd_narrow(const nlam_mlp_bwd_t* p, hipStream_t stream);   // slice 2
+int32_t wgrad_narrow(const nlam_wgrad_t* p, hipStream_t stream);   // slice 2
+int32_t fwd_wide(const nlam_mlp_fwd_t* p, hipStream_t stream);     // slice 3
+int32_t bwd_wide(const nlam_mlp_bwd_t* p, hipStream_t stream);     // slice 3
+int32_t wgrad_wide(const nlam_wgrad_t* p, hipStream_t stream);     // slice 3
+int32_t fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream);      // slice 4
+int32_t bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream);      // slice 4
+int32_t wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream);      // slice 4
+extern int wbf_min_supertiles;                                     // nlam_set_tuning (defined in slice 1)
+}  // namespace nlam_detail
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -2540,6 +2569,11 @@ int wgrad_windows(const nlam_wgrad_t* p) { return wgrad_windows_of(p, kWWin, kWW
 // ---------------------------------------------------------------------------
 // C-ABI
 // ---------------------------------------------------------------------------
+#if NLAM_IN_TU(1)
+int nlam_detail::wbf_min_supertiles = 192;
+#endif
+
+#if NLAM_IN_TU(1)
 extern "C" {
 
 #ifdef NLAM_TIMING
@@ -2561,7 +2595,7 @@ int32_t nlam_max_width(void) { return kMaxWide; }
 int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_WBF_MIN_SUPERTILES) {
         if (value < 0) return NLAM_EINVAL;
-        g_wbf_min_supertiles = value;
+        nlam_detail::wbf_min_supertiles = value;
         return 0;
     }
     return NLAM_EINVAL;
@@ -2657,8 +2691,19 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
         if (cfg.nwv == 0) return NLAM_EUNSUP;
         const int64_t need = nlam_mlp_fwd_wpack_floats(p);
         if (p->wpack == nullptr || p->wpack_floats < need) return NLAM_EINVAL;
-        const int wns = fwd_wbf_ns(p);
-        if (wns > 0) {   // split-bf16 matrix path (nlam_wbf.inc)
+        if (fwd_wbf_ns(p) > 0) return nlam_detail::fwd_wbf(p, stream);   // split-bf16 matrix path (nlam_wbf.inc)
+        return nlam_detail::fwd_wide(p, stream);
+    }
+    return nlam_detail::fwd_narrow(p, stream);
+}
+
+}  // extern "C"
+#endif
+
+#if NLAM_IN_TU(4)
+int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
+    const int wns = fwd_wbf_ns(p);
+    {
             const WbfPlan pl = wbf_plan(p->hid > p->dout ? p->hid : p->dout, wns);
             const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
             const int TK1 = fwd_wbf_tk1(p, pl.kg);
@@ -2704,7 +2749,14 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
                 else NLAM_LAUNCH_FWD_WBF(3, 8, 8, 2, 2, 1);
             }
             return (int32_t)hipGetLastError();
-        }
+    }
+}
+#endif
+
+#if NLAM_IN_TU(3)
+int32_t nlam_detail::fwd_wide(const nlam_mlp_fwd_t* p, hipStream_t stream) {
+    const WideCfg cfg = wide_cfg(p->hid > p->dout ? p->hid : p->dout);
+    {
         const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32, NQ1 = fwd_nq1(p);
         int kin = 0;
         for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
@@ -2733,6 +2785,11 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
         else NLAM_LAUNCH_FWD_WIDE(8, 2);
         return (int32_t)hipGetLastError();
     }
+}
+#endif
+
+#if NLAM_IN_TU(1)
+int32_t nlam_detail::fwd_narrow(const nlam_mlp_fwd_t* p, hipStream_t stream) {
     // launch shape: one persistent workgroup of kFwdWaves waves per CU (fewer workgroups than CUs only when there
     // are fewer tiles than CUs); tiles are dealt to workgroups first, then to waves
     const long ttiles = (long)p->ntiles * p->batch;
@@ -2764,14 +2821,11 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
     else return NLAM_EUNSUP;
     return (int32_t)hipGetLastError();
 }
+#endif
 
-#define NLAM_LAUNCH_BWD(HB_, OB_)                                                                      \
-    do {                                                                                               \
-        const size_t lds = bwd_lds_bytes(p, HB_, OB_);                                                 \
-        int rc = set_lds(mlp_bwd_kernel<HB_, OB_>, lds);                                               \
-        if (rc != 0) return rc;                                                                        \
-        hipLaunchKernelGGL((mlp_bwd_kernel<HB_, OB_>), dim3(blocks), dim3(kBlockThreads), lds, stream, *p); \
-    } while (0)
+#if NLAM_IN_TU(1)
+extern "C" {
+
 
 int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
     if (p == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
@@ -2795,11 +2849,22 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
         if (cfg.nwv == 0) return NLAM_EUNSUP;
         const int64_t need = nlam_mlp_bwd_wpack_floats(p);
         if (p->wpack == nullptr || p->wpack_floats < need) return NLAM_EINVAL;
-        const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
-        int kin = 0;
-        for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
-        const int wns = bwd_wbf_ns(p);
-        if (wns > 0) {   // split-bf16 matrix path (nlam_wbf.inc)
+        if (bwd_wbf_ns(p) > 0) return nlam_detail::bwd_wbf(p, stream);   // split-bf16 matrix path (nlam_wbf.inc)
+        return nlam_detail::bwd_wide(p, stream);
+    }
+    return nlam_detail::bwd_narrow(p, stream);
+}
+
+}  // extern "C"
+#endif
+
+#if NLAM_IN_TU(4)
+int32_t nlam_detail::bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream) {
+    const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
+    int kin = 0;
+    for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
+    const int wns = bwd_wbf_ns(p);
+    {
             const WbfBwdPlan pl = wbf_bwd_plan(bwd_wide_maxw(p));
             const int TKA = 2 * OBT, TKB = 2 * HBT;
             u32x4* base = reinterpret_cast<u32x4*>(p->wpack);
@@ -2843,7 +2908,17 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
                 else NLAM_LAUNCH_BWD_WBF(3, 8, 2, 1);
             }
             return (int32_t)hipGetLastError();
-        }
+    }
+}
+#endif
+
+#if NLAM_IN_TU(3)
+int32_t nlam_detail::bwd_wide(const nlam_mlp_bwd_t* p, hipStream_t stream) {
+    const WideCfg cfg = wide_cfg(bwd_wide_maxw(p));
+    const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
+    int kin = 0;
+    for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
+    {
         pack_jobs_t jobs;
         jobs.njobs = 0;
         // A[m = hidden][k = out] = W2[k][m]
@@ -2874,6 +2949,18 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
         else NLAM_LAUNCH_BWD_WIDE(8, 2);
         return (int32_t)hipGetLastError();
     }
+}
+#endif
+
+#if NLAM_IN_TU(2)
+#define NLAM_LAUNCH_BWD(HB_, OB_)                                                                      \
+    do {                                                                                               \
+        const size_t lds = bwd_lds_bytes(p, HB_, OB_);                                                 \
+        int rc = set_lds(mlp_bwd_kernel<HB_, OB_>, lds);                                               \
+        if (rc != 0) return rc;                                                                        \
+        hipLaunchKernelGGL((mlp_bwd_kernel<HB_, OB_>), dim3(blocks), dim3(kBlockThreads), lds, stream, *p); \
+    } while (0)
+int32_t nlam_detail::bwd_narrow(const nlam_mlp_bwd_t* p, hipStream_t stream) {
     const int blocks = grid_blocks((long)p->ntiles * p->batch);
     const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
     bool fast = (p->hid % 32 == 0) && (p->dout % 32 == 0);
@@ -2909,6 +2996,10 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
     else return NLAM_EUNSUP;
     return (int32_t)hipGetLastError();
 }
+#endif
+
+#if NLAM_IN_TU(1)
+extern "C" {
 
 int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     if (p == nullptr || p->A == nullptr || p->partials == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC) return NLAM_EINVAL;
@@ -2916,14 +3007,18 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     for (int s = 0; s < p->nsrc; ++s) n += p->src[s].width;
     if (n != p->n || p->m < 1 || p->nparts < 1) return NLAM_EINVAL;
     hipStream_t stream = (hipStream_t)hip_stream;
-    if (p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) {
-        hipLaunchKernelGGL(wgrad_smalln_kernel, dim3(p->nparts), dim3(256), 0, stream, *p);
-        return (int32_t)hipGetLastError();
+    if (!(p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) && wgrad_is_wide(p)) {
+        if (wgrad_wbf_ns(p) > 0) return nlam_detail::wgrad_wbf(p, stream);   // split-bf16 matrix path (nlam_wbf.inc)
+        return nlam_detail::wgrad_wide(p, stream);
     }
-    const bool dma = wgrad_is_narrow_dma(p);
-    int nb_total = 0;
-    for (int s = 0; s < p->nsrc; ++s) nb_total += (p->src[s].width + 31) / 32;
-    if (wgrad_is_wide(p) && wgrad_wbf_ns(p) > 0) {   // split-bf16 matrix path (nlam_wbf.inc)
+    return nlam_detail::wgrad_narrow(p, stream);
+}
+
+}  // extern "C"
+#endif
+
+#if NLAM_IN_TU(4)
+int32_t nlam_detail::wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream) {
         const int wns = wgrad_wbf_ns(p);
         // 256 x 256 windows (8 waves) when the output has more than 128 rows, 128 x 128 windows (4 waves) otherwise
         const bool big = p->m > 128;
@@ -2948,7 +3043,10 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
         else NLAM_LAUNCH_WG_WBF2(3, false);
         return (int32_t)hipGetLastError();
     }
-    if (wgrad_is_wide(p)) {
+#endif
+
+#if NLAM_IN_TU(3)
+int32_t nlam_detail::wgrad_wide(const nlam_wgrad_t* p, hipStream_t stream) {
         const size_t lds = (size_t)4 * kWWTile * sizeof(float);
         if (p->flags & NLAM_F_SILU_B) {
             int rc = set_lds(wgrad_wide_kernel<true>, lds);
@@ -2961,6 +3059,17 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
         }
         return (int32_t)hipGetLastError();
     }
+#endif
+
+#if NLAM_IN_TU(2)
+int32_t nlam_detail::wgrad_narrow(const nlam_wgrad_t* p, hipStream_t stream) {
+    if (p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) {
+        hipLaunchKernelGGL(wgrad_smalln_kernel, dim3(p->nparts), dim3(256), 0, stream, *p);
+        return (int32_t)hipGetLastError();
+    }
+    const bool dma = wgrad_is_narrow_dma(p);
+    int nb_total = 0;
+    for (int s = 0; s < p->nsrc; ++s) nb_total += (p->src[s].width + 31) / 32;
     if (dma) {
         const int nblocks = ((p->m + 31) / 32) * nb_total;
         const int nbw = (nblocks + 3) / 4;
@@ -2999,6 +3108,10 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     else NLAM_LAUNCH_WG(3, ywin);
     return (int32_t)hipGetLastError();
 }
+#endif
+
+#if NLAM_IN_TU(1)
+extern "C" {
 
 static int32_t segment_sum_launch(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
                                   float* out, int32_t nseg, int32_t width, int32_t batch, int accumulate, void* hip_stream) {
@@ -3097,3 +3210,4 @@ int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* 
 }
 
 }  // extern "C"
+#endif
