@@ -47,6 +47,10 @@
 #ifndef NLAM_TU
 #define NLAM_TU 0
 #endif
+#ifndef NLAM_RES_PRE
+#define NLAM_RES_PRE 3   // narrow forward with a residual stash: input units prefetched a tile ahead (4 spilled in the tile loop;
+                         // A/B at cfg2: 3 vs 4 vs 2 = same training step, +2.5 % forecast rate for 3)
+#endif
 #define NLAM_IN_TU(k) (NLAM_TU == 0 || NLAM_TU == (k))
 
 namespace nlam_detail {   // launchers: external linkage, each defined in exactly one slice; arguments are already validated
@@ -955,7 +959,8 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
             if (s < p.nsrc && p.src[s].idx != nullptr) ridx[s] = p.src[s].idx[pr];
         }
     };
-    constexpr int kPre = RAG ? 2 : 4;   // units prefetched a tile ahead (the rest stream in at the top of their own tile)
+    constexpr int kPre = RAG ? 2 : (RES ? NLAM_RES_PRE : 4);   // units prefetched a tile ahead (the rest stream in at the top of their own tile); one fewer
+                                                    // when 32 registers hold the residual rows: four spilled inside the tile loop
     constexpr int kTop = MAXU - kPre > 0 ? MAXU - kPre : 1;
     f32x4 xp[kPre][4];        // loop-carried: rows of the next tile
     auto load_unit = [&](const float* const (&rp)[NLAM_MAX_SRC], int u, f32x4(&xu)[4]) {
