@@ -12,11 +12,12 @@ from neural_lam_amd import ops  # noqa: E402
 from neural_lam_amd.trainer import Trainer  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+cfgname = sys.argv[2] if len(sys.argv) > 2 else "cfg2"   # any bench.CONFIGS key (cfg3 / cfg4 exercise the wide kernels)
 dev = torch.device("cuda:0")
 traj = {}
 for mode in ("bf16x3", "f32"):
     ops.set_matmul_mode(mode)
-    ds, graph, raw, forecaster, step, batch = bench.build(bench.CONFIGS["cfg2"], dev)
+    ds, graph, raw, forecaster, step, batch = bench.build(bench.CONFIGS[cfgname], dev)
     tr = Trainer(step, lr=1e-3, use_graph=True)
     losses = []
     for i in range(steps):
