@@ -2709,7 +2709,7 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
 int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
     const int wns = fwd_wbf_ns(p);
     {
-            const WbfPlan pl = wbf_plan(p->hid > p->dout ? p->hid : p->dout, wns);
+            const WbfPlan pl = fwd_wbf_choose(p, wns);
             const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
             const int TK1 = fwd_wbf_tk1(p, pl.kg);
             int kin = 0;
@@ -2747,10 +2747,12 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
             if (wns == 1) {
                 if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(1, 8, 4, 1, 4, 2);
                 else if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF(1, 8, 8, 1, 4, 2);
+                else if (pl.cfg == 4) NLAM_LAUNCH_FWD_WBF(1, 8, 8, 1, 2, 2);
                 else NLAM_LAUNCH_FWD_WBF(1, 8, 8, 2, 2, 1);
             } else {
                 if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(3, 8, 4, 1, 4, 2);
                 else if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF(3, 8, 8, 1, 4, 2);
+                else if (pl.cfg == 4) NLAM_LAUNCH_FWD_WBF(3, 8, 8, 1, 2, 2);
                 else NLAM_LAUNCH_FWD_WBF(3, 8, 8, 2, 2, 1);
             }
             return (int32_t)hipGetLastError();
