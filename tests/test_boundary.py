@@ -145,3 +145,62 @@ def test_tile_schedule_covers_every_edge_and_receiver_once():
             assert int(csr.rowptr[seg0]) == row0 and int(csr.rowptr[seg0 + nseg]) == row0 + nrows
             cov_r[seg0 : seg0 + nseg] += 1
     assert torch.all(cov_e == 1) and torch.all(cov_r == 1)
+
+
+# ---------------------------------------------------------------------------
+# host-side planning of the C-ABI (no GPU needed: these entry points only compute sizes)
+# ---------------------------------------------------------------------------
+def _fwd_desc(widths, hid, dout, rows, mm_bits, batch=1):
+    p = L.MlpFwd()
+    p.nsrc, p.batch, p.rows, p.ntiles = len(widths), batch, rows, (rows + 31) // 32
+    for k, w in enumerate(widths):
+        p.src[k].width = w
+    p.hid, p.dout, p.flags = hid, dout, mm_bits << 8
+    return p
+
+
+def test_packed_weight_scratch_follows_the_kernel_family():
+    """nlam_mlp_fwd_wpack_floats: none for d <= 64 (weights live in LDS); fp32 A-operand quads for the one-tile wide
+    kernels (small launches or NLAM_MATMUL=f32); NS bf16 terms in K=16 groups for the split super-tile kernels."""
+    import ctypes as C
+
+    lib = L.load()
+    f = lambda p: lib.nlam_mlp_fwd_wpack_floats(C.byref(p))  # noqa: E731
+    assert f(_fwd_desc([64, 64, 64], 64, 64, 255136, 3)) == 0
+    d, E = 256, 255136
+    hbt = obt = d // 32
+    fp32 = (hbt * (3 * d // 32) + obt * hbt) * 1024
+    assert f(_fwd_desc([d, d, d], d, d, E, 0)) == fp32                       # matrix mode f32
+    assert f(_fwd_desc([d, d, d], d, d, 32 * 40, 3)) == fp32                 # 40 tiles: too few super tiles
+    for ns in (1, 3):
+        groups = hbt * (3 * d // 16) + obt * 2 * hbt
+        assert f(_fwd_desc([d, d, d], d, d, E, ns)) == groups * ns * 256
+    assert f(_fwd_desc([d, d, d], d, d, E, 2)) == (hbt * (3 * d // 16) + obt * 2 * hbt) * 3 * 256   # two terms run as three
+    # source widths that are not a multiple of 4 stay on the fp32 kernels
+    assert f(_fwd_desc([18, ], 128, 128, E, 3)) == (4 * 1 + 4 * 4) * 1024
+    # the tuning knob moves the boundary (and is restored)
+    assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 0) == 0
+    try:
+        assert f(_fwd_desc([d, d, d], d, d, 32 * 40, 3)) != fp32
+    finally:
+        assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
+
+
+def test_launch_shape_queries():
+    import ctypes as C
+
+    lib = L.load()
+    assert lib.nlam_num_blocks(0) == 1 and lib.nlam_num_blocks(255) == 255 and lib.nlam_num_blocks(256) == 256
+    q = L.Wgrad()
+    q.m, q.n, q.batch, q.rows, q.nsrc = 64, 192, 1, 255136, 3
+    for k in range(3):
+        q.src[k].width = 64
+    assert lib.nlam_wgrad_nparts(C.byref(q)) == 512          # narrow: one partial per 32-row chunk, capped
+    q.rows = 96
+    assert lib.nlam_wgrad_nparts(C.byref(q)) == 3
+    q.m, q.n, q.rows, q.flags = 256, 768, 255136, 3 << 8
+    for k in range(3):
+        q.src[k].width = 256
+    assert lib.nlam_wgrad_nparts(C.byref(q)) == 256 // 3      # split-bf16: three 256 x 256 windows, one workgroup per CU
+    q.flags = 0
+    assert lib.nlam_wgrad_nparts(C.byref(q)) == 1024 // 12    # fp32: twelve 128 x 128 windows
