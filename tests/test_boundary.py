@@ -204,3 +204,31 @@ def test_launch_shape_queries():
     assert lib.nlam_wgrad_nparts(C.byref(q)) == 256 // 3      # split-bf16: three 256 x 256 windows, one workgroup per CU
     q.flags = 0
     assert lib.nlam_wgrad_nparts(C.byref(q)) == 1024 // 12    # fp32: twelve 128 x 128 windows
+
+
+def test_backward_planning_queries():
+    """nlam_mlp_bwd_wpack_floats / nlam_mlp_bwd_blocks: transposed-weight scratch per source with a data gradient,
+    and the number of partial-sum rows the caller has to provide (workgroups x row groups)."""
+    import ctypes as C
+
+    lib = L.load()
+
+    def desc(d, rows, mm_bits, dmode=(1, 2, 3)):
+        p = L.MlpBwd()
+        p.nsrc, p.batch, p.rows, p.ntiles = 3, 1, rows, (rows + 31) // 32
+        for k in range(3):
+            p.src[k].width = d
+            p.dmode[k] = dmode[k]
+        p.hid, p.dout, p.flags = d, d, mm_bits << 8
+        return p
+
+    wp = lambda p: lib.nlam_mlp_bwd_wpack_floats(C.byref(p))  # noqa: E731
+    nb = lambda p: lib.nlam_mlp_bwd_blocks(C.byref(p))  # noqa: E731
+    assert wp(desc(64, 255136, 3)) == 0 and nb(desc(64, 255136, 3)) == 256
+    d, hbt = 256, 8
+    assert wp(desc(d, 255136, 0)) == (hbt * hbt + 3 * hbt * hbt) * 1024                       # fp32 quads, 3 sources
+    assert wp(desc(d, 255136, 3)) == (hbt * 2 * hbt + 3 * hbt * 2 * hbt) * 3 * 256            # split terms, K = 16 groups
+    assert wp(desc(d, 255136, 3, dmode=(1, 0, 0))) == (hbt * 2 * hbt + hbt * 2 * hbt) * 3 * 256
+    assert nb(desc(d, 255136, 3)) == 256                      # 64-row super tiles, one row group
+    assert nb(desc(128, 255136, 3)) == 512                    # d <= 128: two row groups per workgroup
+    assert nb(desc(d, 32 * 10, 3)) == 10                      # small launch: fp32 one-tile kernels, one workgroup per tile
