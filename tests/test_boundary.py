@@ -232,3 +232,41 @@ def test_backward_planning_queries():
     assert nb(desc(d, 255136, 3)) == 256                      # 64-row super tiles, one row group
     assert nb(desc(128, 255136, 3)) == 512                    # d <= 128: two row groups per workgroup
     assert nb(desc(d, 32 * 10, 3)) == 10                      # small launch: fp32 one-tile kernels, one workgroup per tile
+
+
+def test_argument_errors_are_reported_before_any_launch():
+    """Error convention of the C-ABI (include/nlam_hip.h): NLAM_EINVAL (-1) for inconsistent arguments, NLAM_EUNSUP (-2)
+    for widths this build does not instantiate, 0 for an empty problem -- all decided on the host, so this runs
+    without a GPU."""
+    import ctypes as C
+
+    lib = L.load()
+    EINVAL, EUNSUP = -1, -2
+    one = C.c_float(0.0)
+    ptr = C.cast(C.pointer(one), C.c_void_p)   # any non-null pointer: nothing below reaches a kernel
+    assert lib.nlam_mlp_fwd(None, None) == EINVAL
+    p = _fwd_desc([64, 64, 64], 64, 64, 320, 3)
+    assert lib.nlam_mlp_fwd(C.byref(p), None) == EINVAL          # no weights
+    p.W1 = p.W2 = ptr
+    p.nsrc = 0
+    assert lib.nlam_mlp_fwd(C.byref(p), None) == EINVAL
+    p.nsrc = 3
+    p.flags |= L.F_ADD_SRC0
+    p.src[0].width = 32
+    assert lib.nlam_mlp_fwd(C.byref(p), None) == EINVAL          # residual source narrower than the output
+    p.src[0].width = 64
+    p.flags = (3 << 8) | L.F_MEAN
+    assert lib.nlam_mlp_fwd(C.byref(p), None) == EINVAL          # mean aggregation without the degree table
+    p.flags = 3 << 8
+    p.rows = 0
+    assert lib.nlam_mlp_fwd(C.byref(p), None) == 0               # empty problem: nothing to do
+    w = _fwd_desc([256, 256, 256], 256, 256, 255136, 3)
+    w.W1 = w.W2 = ptr
+    assert lib.nlam_mlp_fwd(C.byref(w), None) == EINVAL          # wide shapes need the packed-weight scratch
+    big = _fwd_desc([1024], 1024, 1024, 320, 0)
+    big.W1 = big.W2 = ptr
+    assert lib.nlam_mlp_fwd(C.byref(big), None) == EUNSUP        # beyond nlam_max_width()
+    assert lib.nlam_wgrad(None, None) == EINVAL
+    assert lib.nlam_affine_mix(None, None, None, None, None, None, None, None, 1, 1, 1, None) == EINVAL
+    assert lib.nlam_segment_sum(None, 0, None, None, None, None, 1, 1, 1, None) == EINVAL
+    assert lib.nlam_segment_sum_acc(None, 0, None, None, None, None, 1, 1, 1, None) == EINVAL
