@@ -20,7 +20,7 @@
  *         aggr_mlp(cat(rec_rep, aggr)) + residual   gnn_layers.py:148-151
  *         grid_emb + encoding_grid_mlp(grid_emb)    models/step_predictors/graph/base.py:308
  *         grid_embedder / *_embedder / output_map    graph/base.py:286-295, 322
- *   nlam_edge_fwd / nlam_edge_bwd
+ *   nlam_mlp_fwd / nlam_mlp_bwd with three gathered sources, a tile schedule and `aggr` set
  *       InteractionNet / PropagationNet message + aggregate (+ edge update):
  *         PyG propagate: x_j/x_i index_select, message() = edge_mlp(cat(edge, x_j, x_i))
  *         [+ x_j], aggregate() = scatter sum/mean onto num_rec receivers,
@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define NLAM_ABI_VERSION 2
+#define NLAM_ABI_VERSION 3
 #define NLAM_MAX_SRC 3
 
 #define NLAM_EINVAL (-1)   /* inconsistent sizes / null pointers        */
@@ -261,6 +261,27 @@ int32_t nlam_wmse_bwd(const float* pred, const float* target, const float* inv_v
  * and, with the roles of the operands permuted, their backward (g * interior_mask, g * diff_std). */
 int32_t nlam_affine_mix(const float* x, const float* a, const float* y, const float* c, const float* z, const float* s,
                         const float* m, float* out, int64_t rows, int32_t nodes, int32_t width, void* hip_stream);
+
+/* ForecasterModule.on_after_batch_transfer (models/module.py:326-367): up to NLAM_MAX_STD_JOBS tensors
+ * standardised in ONE launch,  out[r][c] = (x[r][c] - mean[c / rep]) / std[c / rep].  `rep` = 1 for the states;
+ * for the forcing it is the window size: the per-feature statistics are tiled feature-major over the window
+ * (repeat_interleave, module.py:352-358).  IEEE subtraction and division: bit-equal to the reference's formula. */
+#define NLAM_MAX_STD_JOBS 4
+typedef struct {
+    const float* x;
+    float* out;
+    const float* mean;     /* (width / rep) */
+    const float* std;      /* (width / rep), already clamped to >= eps by the caller (module.py:306-324) */
+    int64_t rows;
+    int32_t width;
+    int32_t rep;
+} nlam_std_job_t;
+typedef struct {
+    nlam_std_job_t job[NLAM_MAX_STD_JOBS];
+    int32_t njobs;
+    int32_t _pad;
+} nlam_std_jobs_t;
+int32_t nlam_standardize(const nlam_std_jobs_t* jobs, void* hip_stream);
 
 /* decoupled-weight-decay Adam on flat buffers; step_count is the 1-based step */
 int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -40,6 +40,7 @@ EXPORTS = [
     "nlam_wmse_fwd",
     "nlam_wmse_bwd",
     "nlam_adamw_step",
+    "nlam_standardize",
 ]
 
 
@@ -158,6 +159,23 @@ class ReduceJobs(C.Structure):
     _fields_ = [("job", ReduceJob * 6), ("njobs", C.c_int32), ("_pad", C.c_int32)]
 
 
+class StdJob(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("out", C.c_void_p),
+        ("mean", C.c_void_p),
+        ("std", C.c_void_p),
+        ("rows", C.c_int64),
+        ("width", C.c_int32),
+        ("rep", C.c_int32),
+    ]
+
+
+class StdJobs(C.Structure):
+    _fields_ = [("job", StdJob * 4), ("njobs", C.c_int32), ("_pad", C.c_int32)]
+
+
+ABI_VERSION = 3
 _lib = None
 
 
@@ -220,7 +238,9 @@ def load():
     lib.nlam_wmse_bwd.restype = i32
     lib.nlam_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
     lib.nlam_adamw_step.restype = i32
-    if lib.nlam_abi_version() != 2:
+    lib.nlam_standardize.argtypes = [C.POINTER(StdJobs), vp]
+    lib.nlam_standardize.restype = i32
+    if lib.nlam_abi_version() != ABI_VERSION:
         raise RuntimeError("libnlam_hip.so ABI version mismatch")
     _lib = lib
     return lib

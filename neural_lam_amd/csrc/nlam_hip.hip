@@ -2374,6 +2374,17 @@ __global__ void affine_mix_kernel(const float* __restrict__ x, const float* __re
     }
 }
 
+// on_after_batch_transfer: (x - mean[c / rep]) / std[c / rep] for up to four tensors in one launch (blockIdx.y = job)
+__global__ void standardize_kernel(const nlam_std_jobs_t jobs) {
+    if ((int)blockIdx.y >= jobs.njobs) return;
+    const nlam_std_job_t jb = jobs.job[blockIdx.y];
+    const long total = jb.rows * jb.width;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(e % jb.width) / jb.rep;
+        jb.out[e] = __fdiv_rn(__fsub_rn(jb.x[e], jb.mean[f]), jb.std[f]);
+    }
+}
+
 __global__ void wmse_bwd_kernel(const float* pred, const float* target, const float* inv_var, const float* row_weight,
                                 const float* gscalar, long total, int nodes, int nvars, float scale, float* dpred) {
     const float g = 2.f * scale * gscalar[0];
@@ -3198,6 +3209,22 @@ int32_t nlam_affine_mix(const float* x, const float* a, const float* y, const fl
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(affine_mix_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, x, a, y, c, z, s, m, out, total,
                        nodes, width);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_standardize(const nlam_std_jobs_t* jobs, void* hip_stream) {
+    if (jobs == nullptr || jobs->njobs < 1 || jobs->njobs > NLAM_MAX_STD_JOBS) return NLAM_EINVAL;
+    long most = 0;
+    for (int k = 0; k < jobs->njobs; ++k) {
+        const nlam_std_job_t& j = jobs->job[k];
+        if (j.x == nullptr || j.out == nullptr || j.mean == nullptr || j.std == nullptr) return NLAM_EINVAL;
+        if (j.rows < 0 || j.width < 1 || j.rep < 1 || j.width % j.rep != 0) return NLAM_EINVAL;
+        if (j.rows * j.width > most) most = j.rows * j.width;
+    }
+    if (most == 0) return 0;
+    long blocks = (most + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(standardize_kernel, dim3((int)blocks, jobs->njobs), dim3(256), 0, (hipStream_t)hip_stream, *jobs);
     return (int32_t)hipGetLastError();
 }
 

@@ -537,9 +537,13 @@ class ForecasterStep(nn.Module):
     without Lightning: on-device standardisation (:326-367), rollout + masked
     ``wmse`` per step, mean over batch then over steps (:463-510, :412)."""
 
-    def __init__(self, forecaster: ARForecaster, datastore):
+    def __init__(self, forecaster: ARForecaster, datastore, standardize: bool = False, state_feature_weights=None):
+        """``standardize=True`` makes ``forward`` start with ``on_after_batch_transfer`` (the batch arrives
+        un-standardised, as ``WeatherDataset`` hands it over).  ``state_feature_weights``: per-variable loss weights
+        (``get_state_feature_weighting``, module.py:162-176 / loss_weighting.py); default = uniform ``1 / n``."""
         super().__init__()
         self.forecaster = forecaster
+        self.standardize_inputs = bool(standardize)
         bm = torch.tensor(datastore.boundary_mask.values, dtype=torch.float32)
         self.register_buffer("interior_mask_bool", (1.0 - bm).to(torch.bool), persistent=False)
         self.register_buffer("interior_index", torch.nonzero(1.0 - bm > 0.5).reshape(-1), persistent=False)
@@ -549,7 +553,12 @@ class ForecasterStep(nn.Module):
         eps = torch.finfo(torch.float32).eps
         if not forecaster.predicts_std:
             n = len(datastore.get_vars_names("state"))
-            w = torch.tensor([1.0 / n] * n, dtype=torch.float32)  # loss_weighting.py:60-79 (uniform)
+            if state_feature_weights is None:
+                w = torch.tensor([1.0 / n] * n, dtype=torch.float32)  # loss_weighting.py:60-79 (uniform)
+            else:   # ManualStateFeatureWeighting: one weight per state variable, in variable order
+                w = torch.as_tensor(state_feature_weights, dtype=torch.float32).reshape(-1)
+                if w.numel() != n or bool((w <= 0).any()):
+                    raise ValueError(f"state_feature_weights needs {n} positive entries, got {tuple(w.shape)}")
             diff_std = torch.tensor(st.state_diff_std_standardized.values, dtype=torch.float32)
             self.register_buffer("per_var_std", diff_std / torch.sqrt(w), persistent=False)
             self.register_buffer("inv_var", 1.0 / (self.per_var_std * self.per_var_std), persistent=False)   # 1 / std^2 of wmse
@@ -571,14 +580,20 @@ class ForecasterStep(nn.Module):
             self.forcing_mean = self.forcing_std = None
 
     def standardize(self, init_states, target_states, forcing):
-        init_states = (init_states - self.state_mean) / self.state_std
-        target_states = (target_states - self.state_mean) / self.state_std
-        if forcing.shape[-1] > 0 and self.forcing_mean is not None:
-            window = forcing.shape[-1] // self.forcing_mean.shape[-1]
-            forcing = (forcing - self.forcing_mean.repeat_interleave(window)) / self.forcing_std.repeat_interleave(window)
-        return init_states, target_states, forcing
+        """module.py:326-367: one launch for the three tensors (``nlam_standardize``)."""
+        from .ops import standardize as std_launch
 
-    def forward(self, init_states, target_states, forcing, standardize: bool = False):
+        items = [(init_states, self.state_mean, self.state_std, 1), (target_states, self.state_mean, self.state_std, 1)]
+        has_forcing = forcing.shape[-1] > 0 and self.forcing_mean is not None
+        if has_forcing:
+            window = forcing.shape[-1] // self.forcing_mean.shape[-1]
+            items.append((forcing, self.forcing_mean, self.forcing_std, window))
+        outs = std_launch(items)
+        return outs[0], outs[1], (outs[2] if has_forcing else forcing)
+
+    def forward(self, init_states, target_states, forcing, standardize: bool | None = None):
+        if standardize is None:
+            standardize = self.standardize_inputs
         if standardize:
             init_states, target_states, forcing = self.standardize(init_states, target_states, forcing)
         prediction, pred_std = self.forecaster(init_states, forcing, target_states)

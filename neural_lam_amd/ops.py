@@ -49,8 +49,25 @@ def _mm_flags() -> int:
 # When a trainer owns every parameter's .grad as a zero-initialised view of one flat buffer
 # (trainer.FlatParams), the backward of a fused MLP adds its weight / bias / LayerNorm gradients straight
 # into those views inside the partial-sum reduction and returns None for them: ~6 AccumulateGrad add
-# launches per MLP (~130 per step at cfg2) disappear.
+# launches per MLP (~130 per step at cfg2) disappear.  Off by default and only ever switched on for the duration
+# of a trainer's own backward (``direct_param_grads()``): autograd's AccumulateGrad hooks -- which
+# torch DistributedDataParallel / FSDP rely on -- are bypassed for those parameters while it is on.
 DIRECT_PARAM_GRADS = False
+# Object with ``note_use(params)`` / ``note_done(params)`` (trainer.GradBuckets): told, in direct mode, which
+# parameters a forward used and when a backward has finished accumulating into their .grad, so that gradient
+# buckets can be all-reduced as they complete although no AccumulateGrad hook fires.
+GRAD_LISTENER = None
+
+
+@contextlib.contextmanager
+def direct_param_grads(listener=None):
+    global DIRECT_PARAM_GRADS, GRAD_LISTENER
+    prev = (DIRECT_PARAM_GRADS, GRAD_LISTENER)
+    DIRECT_PARAM_GRADS, GRAD_LISTENER = True, listener
+    try:
+        yield
+    finally:
+        DIRECT_PARAM_GRADS, GRAD_LISTENER = prev
 
 
 class _WgradOverlap:
@@ -66,24 +83,43 @@ class _WgradOverlap:
 
     def __init__(self):
         self.streams = []
-        self.turn = 0
+        self.assigned = {}
         self.active = False
+        self.capturing = False
         self.keep = []
 
     def begin(self):
         if not self.streams:
             self.streams = [torch.cuda.Stream() for _ in range(max(1, self.NSTREAMS))]
         self.active = True
-        self.turn = 0
+        self.assigned = {}
         self.keep = []
+        self.capturing = torch.cuda.is_current_stream_capturing()
 
-    def next_stream(self):
-        """Side streams are dealt round-robin, one per fused-MLP backward: on a single side stream the ~45
-        weight-gradient / reduction launches of a cfg2 step formed a 1.25 ms serial chain -- longer than the
-        data-gradient chain they were moved off (rocprofv3 kernel trace of the replayed graph)."""
-        st = self.streams[self.turn % len(self.streams)]
-        self.turn += 1
-        return st
+    def stream_for(self, owner):
+        """Side streams are dealt round-robin over the fused MLPs in the order backward first meets them: on a single
+        side stream the ~45 weight-gradient / reduction launches of a cfg2 step formed a 1.25 ms serial chain -- longer
+        than the data-gradient chain they were moved off (rocprofv3 kernel trace of the replayed graph).  The stream is
+        a function of the MLP (``owner`` = its first weight), not of the call: in a rollout the same parameters are
+        back-propagated once per AR step, and the read-modify-write accumulations into one ``.grad`` must stay ordered
+        on one stream (two streams = lost updates)."""
+        k = self.assigned.get(id(owner))
+        if k is None:
+            k = self.assigned[id(owner)] = len(self.assigned) % len(self.streams)
+        return self.streams[k]
+
+    def hold(self, side, *tensors):
+        """Tensors the side stream reads must outlive its kernels.  Eager: ``record_stream`` hands that to the
+        caching allocator (a block returns to the pool once the side stream has passed the point of release, not at
+        the end of the whole backward).  During HIP-graph capture the private pool defers every cross-stream release
+        to the end of the capture anyway; a plain reference until the join does the same without allocator events."""
+        for t in tensors:
+            if t is None:
+                continue
+            if self.capturing:
+                self.keep.append(t)
+            else:
+                t.record_stream(side)
 
     def end(self):
         if self.active:
@@ -108,12 +144,16 @@ class _LaunchProfile:
     def __init__(self):
         self.enabled = False
         self._pairs = []
+        self.meta = {}
 
     def reset(self, enabled: bool):
         self.enabled = enabled
         self._pairs = []
+        self.meta = {}
 
-    def launch(self, key, fn):
+    def launch(self, key, fn, meta=None):
+        """``meta`` (a thunk, evaluated once per key and only while profiling): algorithmic FLOPs / HBM bytes of the launch
+        and the matrix instruction it issues, for bench.py's roofline block."""
         if not self.enabled:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -121,6 +161,8 @@ class _LaunchProfile:
         rc = fn()
         e1.record()
         self._pairs.append((key, e0, e1))
+        if meta is not None and key not in self.meta:
+            self.meta[key] = meta()
         return rc
 
     def collect(self):
@@ -136,6 +178,23 @@ PROFILE = _LaunchProfile()
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
+
+
+_MM_NAMES = {0: "f32", 1: "bf16", 2: "bf16x2", 3: "bf16x3"}
+
+
+def _mm_executed(mm_flags, hid, dout, widths):
+    """Matrix instruction a fused-MLP launch issues (mirrors the dispatch of csrc/nlam_hip.hip: shapes the split-bf16
+    kernels do not cover run the fp32 MFMA) -> (name, bf16 MFMAs executed per algorithmic product block; 0 = fp32 MFMA)."""
+    ns = (mm_flags >> 8) & 3
+    covered = hid % 32 == 0 and dout % 32 == 0 and all(w % 4 == 0 for w in widths)
+    if max([hid, dout, *widths]) <= 64:
+        covered = covered and (len(widths) == 1 or all(w % 32 == 0 for w in widths))
+    if ns == 0 or not covered:
+        return "f32", 0
+    if max(hid, dout) > 64 and ns == 2:
+        ns = 3
+    return _MM_NAMES[ns], ns * (ns + 1) // 2
 
 
 def _require_gpu(*tensors):
@@ -278,8 +337,25 @@ class FusedMLPFunction(torch.autograd.Function):
         if nwp > 0:  # wide kernels: scratch for the weights in MFMA A-operand order
             wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
             p.wpack, p.wpack_floats = _ptr(wpack), nwp
-        key = ("mlp_fwd", rows * B, kin, hid, dout)
-        L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_fwd(C.byref(p), _stream())), "nlam_mlp_fwd")
+        key = ("mlp_fwd", rows * B, kin, hid, dout, geom.nsrc, bool(geom.aggregate), need_grad)
+
+        def fwd_meta():
+            # algorithmic HBM bytes: every distinct source row once (a gathered node table counts as the table), the
+            # outputs, and in training mode the tensors saved for backward; weights / indices / descriptors are noise
+            nbytes = sum(s_.shape[-2] * w_ * 4 * (B if bi[2] != 0 or B == 1 else 1) for s_, w_, bi in zip(srcs, widths, binfo))
+            if out is not None:
+                nbytes += out.numel() * 4
+            if aggr is not None:
+                nbytes += aggr.numel() * 4
+            for t_ in (z1, xhat, rstd):
+                if t_ is not None:
+                    nbytes += t_.numel() * 4
+            name, mf = _mm_executed(mm_flags, hid, dout, widths)
+            return {"flops": 2.0 * rows * B * (kin * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
+                    "what": ("gather + " if geom.nsrc == 3 else "") + "Linear-SiLU-Linear" + ("-LayerNorm" if ln_w is not None else "")
+                            + (" + segment aggregate" if geom.aggregate else "") + (" (saves z1/xhat/rstd)" if need_grad else "")}
+
+        L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_fwd(C.byref(p), _stream()), fwd_meta), "nlam_mlp_fwd")
 
         if need_grad:
             ctx.geom, ctx.B, ctx.rows, ctx.ntiles = geom, B, rows, ntiles
@@ -295,6 +371,8 @@ class FusedMLPFunction(torch.autograd.Function):
                         ctx.twin_of[k] = t
             ctx.has_ln = ln_w is not None
             ctx.param_refs = (W1, b1, W2, b2, ln_w, ln_b)   # for .grad views only (DIRECT_PARAM_GRADS)
+            if GRAD_LISTENER is not None:
+                GRAD_LISTENER.note_use([q for q in ctx.param_refs if q is not None and q.requires_grad])
             ctx.save_for_backward(W1c, W2c, ln_w, z1, xhat, rstd, *[bi[0] for bi in binfo])
             ctx.set_materialize_grads(False)
         if out is not None:
@@ -368,8 +446,17 @@ class FusedMLPFunction(torch.autograd.Function):
         vs = _vec_stride(hid, dout)
         vecp = torch.empty((nblk, 4, vs), device=dev, dtype=torch.float32)
         p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(vecp), nblk, vs
-        key = ("mlp_bwd", rows * B, kin, hid, dout)
-        L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_bwd(C.byref(p), _stream())), "nlam_mlp_bwd")
+        key = ("mlp_bwd", rows * B, kin, hid, dout, nsrc, g_aggr is not None)
+
+        def bwd_meta():
+            nbytes = sum(t_.numel() * 4 for t_ in (g_out, g_aggr, z1, xhat, rstd, dz1, dz2) if t_ is not None)
+            nbytes += sum(t_.numel() * 4 for t_ in (*dsrc, *tmp2) if t_ is not None)
+            kin_live = sum(w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0)
+            name, mf = _mm_executed(ctx.mm_flags, hid, dout, [w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0] or [hid])
+            return {"flops": 2.0 * rows * B * (kin_live * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
+                    "what": "LayerNorm/SiLU backward + dh = dz2 W2 + dx = dz1 W1 (data gradients; writes dz1, dz2 for the weight gradients)"}
+
+        L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_bwd(C.byref(p), _stream()), bwd_meta), "nlam_mlp_bwd")
 
         for k in range(nsrc):
             if tmp2[k] is not None:  # finish scatter-by-sender as a CSC segment sum
@@ -404,9 +491,9 @@ class FusedMLPFunction(torch.autograd.Function):
         ]
         on_side = OVERLAP.active and all(is_direct(pp, sh) for _, need, pp, sh in wanted if need)
         if on_side:
-            side = OVERLAP.next_stream()
+            side = OVERLAP.stream_for(prm[0])
             side.wait_stream(torch.cuda.current_stream())
-            OVERLAP.keep.extend([dz1, dz2, vecp, z1, *bases])
+            OVERLAP.hold(side, dz1, dz2, vecp, z1, *bases)
             side_ctx = torch.cuda.stream(side)
         else:
             side_ctx = contextlib.nullcontext()
@@ -420,7 +507,16 @@ class FusedMLPFunction(torch.autograd.Function):
             partials = torch.empty((nparts, m, n), device=dev, dtype=torch.float32)
             q.partials, q.nparts = _ptr(partials), nparts
             key = ("wgrad", rows * B, m, n)
-            L.check(PROFILE.launch(key, lambda: lib.nlam_wgrad(C.byref(q), _stream())), "nlam_wgrad")
+
+            def wg_meta():
+                nbytes = A.numel() * 4 + partials.numel() * 4
+                nbytes += sum(t.shape[-2] * w * 4 * (B if bstride != 0 or B == 1 else 1) for (t, bstride, w, idx) in src_list)
+                narrow = m <= 64 and all(w <= 64 for (_, _, w, _) in src_list)
+                name, mf = ("f32", 0) if narrow else _mm_executed(ctx.mm_flags, m, m, [w for (_, _, w, _) in src_list])
+                return {"flops": 2.0 * rows * B * m * n, "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
+                        "what": "weight gradient dW = A^T [gathered B], rows = MFMA K"}
+
+            L.check(PROFILE.launch(key, lambda: lib.nlam_wgrad(C.byref(q), _stream()), wg_meta), "nlam_wgrad")
             return partials
 
         src_list = []
@@ -467,7 +563,9 @@ class FusedMLPFunction(torch.autograd.Function):
             if jobs.njobs > 0:
                 L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
             if on_side:
-                OVERLAP.keep.extend([part1, part2])
+                OVERLAP.hold(side, part1, part2)
+            if GRAD_LISTENER is not None:   # inside the side-stream context: a collective launched from here waits on it
+                GRAD_LISTENER.note_done([pp for _, need, pp, sh in wanted if need and is_direct(pp, sh)])
         dW1, db1, dW2, db2, dg, dbt = results
 
         grads_src = []
@@ -561,6 +659,32 @@ class AffineMixFunction(torch.autograd.Function):
         if ctx.needs_input_grad[4]:
             gz = _affine_mix(None, None, None, c, g, s, None, g)
         return None, None, gy, None, gz, None, None
+
+
+def standardize(items):
+    """``ForecasterModule.on_after_batch_transfer`` (models/module.py:326-367) for up to four tensors in one launch.
+
+    items: list of (x, mean, std, rep) -> list of ``(x - mean.repeat_interleave(rep)) / std.repeat_interleave(rep)``
+    (fp32, last dim = features).  The batch is data: no autograd."""
+    lib = L.load()
+    assert 1 <= len(items) <= 4
+    jobs = L.StdJobs()
+    outs, keep = [], []
+    for k, (x, mean, std, rep) in enumerate(items):
+        _require_gpu(x, mean, std)
+        xc, mc, sc = x.detach().contiguous(), mean.contiguous(), std.contiguous()
+        width = xc.shape[-1]
+        if width % rep != 0 or mc.numel() * rep != width or sc.numel() != mc.numel():
+            raise RuntimeError(f"standardize: {mc.numel()} statistics x window {rep} do not cover {width} features")
+        out = torch.empty_like(xc)
+        j = jobs.job[k]
+        j.x, j.out, j.mean, j.std = _ptr(xc), _ptr(out), _ptr(mc), _ptr(sc)
+        j.rows, j.width, j.rep = (xc.numel() // width if width else 0), width, rep
+        outs.append(out)
+        keep.extend((xc, mc, sc))
+    jobs.njobs = len(items)
+    L.check(lib.nlam_standardize(C.byref(jobs), _stream()), "nlam_standardize")
+    return outs
 
 
 class AdamWFlat:

@@ -11,9 +11,15 @@ MI355X-first choices:
     multi-tensor launch per ~100 small tensors, and a gradient bucket is a
     contiguous slice: the all-reduce needs no flatten / unflatten copies;
   * buckets are laid out in reverse registration order (= the order backward
-    produces them) and each bucket's all-reduce is launched from a
-    post-accumulate hook as soon as its last gradient lands, overlapping RCCL
-    with the rest of backward; the 1/world scaling is folded into the AdamW kernel;
+    produces them).  Eager step: a bucket's all-reduce is launched as soon as its
+    last gradient has landed -- the fused-MLP backward reports each finished
+    accumulation (``ops.GRAD_LISTENER``; parameters that go through autograd's own
+    accumulation report through post-accumulate hooks) -- so RCCL overlaps the
+    rest of backward.  HIP-graph step (the default of bench.py): the collective
+    is NOT overlapped: one all-reduce of the whole flat buffer follows each
+    replay (0.86 MB at cfg2, 20.6 MB at cfg3; RCCL calls stay outside the
+    capture so a communicator fault can never poison the graph).  The 1/world
+    scaling is folded into the AdamW kernel;
   * xGMI is point-to-point: a ring all-reduce is per-link bound, so buckets are
     large (default 32 MiB) -- at cfg2/cfg3 sizes (0.86 / 20.6 MB) that is one
     collective per step.
@@ -77,28 +83,62 @@ class GradBuckets:
         if cur_members:
             self.bounds.append((cur_start, fp.numel, cur_members))
         self.bucket_of = {i: b for b, (_, _, mem) in enumerate(self.bounds) for i in mem}
+        self.index_of = {id(p): i for i, p in enumerate(fp.params)}
         self.pending = [0] * len(self.bounds)
+        self.uses = {}        # parameter index -> fused-MLP forwards that used it and have not yet back-propagated
+        self.done = set()
         self.handles = []
+        self.launched = []    # bucket indices in launch order (tests read it)
         self.enabled = True   # False while a HIP graph owns the step (collectives run after the replay)
+        self.join_streams = lambda: None   # set by the trainer: make the launching stream wait for every producer stream
         if self.world > 1:
             for i, p in enumerate(fp.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
+    def _param_done(self, i):
+        if i in self.done:
+            return
+        self.done.add(i)
+        b = self.bucket_of[i]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            s, e, _ = self.bounds[b]
+            self.join_streams()   # the bucket's gradients were written from several streams
+            self.launched.append(b)
+            self.handles.append(dist.all_reduce(self.fp.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def _make_hook(self, i):
-        def hook(_param):
-            if not self.enabled:
-                return
-            b = self.bucket_of[i]
-            self.pending[b] -= 1
-            if self.pending[b] == 0:
-                s, e, _ = self.bounds[b]
-                self.handles.append(dist.all_reduce(self.fp.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        def hook(_param):   # autograd accumulated this parameter's (complete) gradient
+            if self.enabled:
+                self._param_done(i)
 
         return hook
 
+    # ---- ops.GRAD_LISTENER protocol: parameters whose gradients the fused-MLP backward accumulates itself ----
+    def note_use(self, params):
+        if not self.enabled or self.world == 1:
+            return
+        for p in params:
+            i = self.index_of.get(id(p))
+            if i is not None:
+                self.uses[i] = self.uses.get(i, 0) + 1
+
+    def note_done(self, params):
+        if not self.enabled or self.world == 1:
+            return
+        for p in params:
+            i = self.index_of.get(id(p))
+            if i is None:
+                continue
+            left = self.uses.get(i, 1) - 1
+            self.uses[i] = left
+            if left <= 0:   # the last AR step's contribution is in: the gradient is complete
+                self._param_done(i)
+
     def begin_step(self):
         self.pending = [len(mem) for (_, _, mem) in self.bounds]
-        self.handles = []
+        self.uses, self.done = {}, set()
+        self.handles, self.launched = [], []
 
     def finish_step(self):
         """Wait for the collectives; buckets whose hooks never fired (parameters
@@ -109,6 +149,7 @@ class GradBuckets:
         for b, left in enumerate(self.pending):
             if left > 0:
                 s, e, _ = self.bounds[b]
+                self.launched.append(b)
                 self.handles.append(dist.all_reduce(self.fp.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                 self.pending[b] = 0
         for h in self.handles:
@@ -130,17 +171,13 @@ class Trainer:
         self.module = module
         self.use_graph = use_graph
         self.overlap_wgrad = overlap_wgrad
-        try:   # the fused-MLP backward may now add parameter gradients straight into the flat views
-            from . import ops
-
-            ops.DIRECT_PARAM_GRADS = True
-        except Exception:   # CPU-only test environments without the HIP library
-            pass
         self._graph = None
         self._static_in = None
+        self._static_sig = None
         self._static_loss = None
         self.fp = FlatParams(module)
         self.buckets = GradBuckets(self.fp, bucket_bytes, group)
+        self.buckets.join_streams = self._join_producers
         self.world = self.buckets.world
         if optimizer_factory is None:
             from .ops import AdamWFlat
@@ -151,31 +188,58 @@ class Trainer:
 
     # ---- HIP-graph step: zero-grad + forward + loss + backward are ~330 launches of 3-150 us at cfg2,
     # which eager Python cannot issue as fast as the GPU retires them; captured once, replayed per step ----
-    def _backward(self, loss):
-        """backward with the weight-gradient kernels forked onto a second stream (ops._WgradOverlap)."""
-        ov = None
+    def _ops(self):
         try:
             from . import ops
 
-            ov = ops.OVERLAP if loss.is_cuda and self.overlap_wgrad else None
-        except Exception:
-            ov = None
-        if ov is not None:
-            ov.begin()
-        try:
+            return ops
+        except Exception:   # CPU-only test environments without the HIP library
+            return None
+
+    def _join_producers(self):
+        """Make the current stream wait for every stream that wrote gradients (weight-gradient side streams + the
+        backward stream) before a collective is launched from it."""
+        ops = self._ops()
+        if ops is None or not torch.cuda.is_available():
+            return
+        cur = torch.cuda.current_stream()
+        for st in [*ops.OVERLAP.streams, self._main_stream]:
+            if st is not None and st != cur:
+                cur.wait_stream(st)
+
+    _main_stream = None
+
+    def _fwd_bwd_on(self, batch):
+        """forward + backward.  For their duration the fused-MLP backward owns the parameter gradients
+        (``ops.direct_param_grads``: partial sums reduced straight into the flat views, bucket completion reported to
+        ``self.buckets``) and the weight-gradient kernels are forked onto side streams (``ops._WgradOverlap``)."""
+        ops = self._ops()
+        on_gpu = ops is not None and self.fp.flat.is_cuda
+        if not on_gpu:
+            out = self.module(*batch)
+            loss = out[-1] if isinstance(out, tuple) else out
             loss.backward()
-        finally:
+            return loss.detach()
+        self._main_stream = torch.cuda.current_stream()
+        with ops.direct_param_grads(self.buckets):
+            out = self.module(*batch)
+            loss = out[-1] if isinstance(out, tuple) else out
+            ov = ops.OVERLAP if self.overlap_wgrad else None
             if ov is not None:
-                ov.end()
+                ov.begin()
+            try:
+                loss.backward()
+            finally:
+                if ov is not None:
+                    ov.end()
+        return loss.detach()   # nothing that references the autograd graph survives this frame
 
     def _fwd_bwd(self):
-        out = self.module(*self._static_in)
-        loss = out[-1] if isinstance(out, tuple) else out
-        self._backward(loss)
-        return loss.detach()   # nothing that references the autograd graph survives this frame
+        return self._fwd_bwd_on(self._static_in)
 
     def _capture(self, *batch):
         self._static_in = [b.clone() for b in batch]
+        self._static_sig = [(tuple(b.shape), b.dtype) for b in batch]
         self.buckets.enabled = False
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -205,12 +269,21 @@ class Trainer:
                 self.use_graph = False
                 torch.cuda.synchronize()
                 return self.step(*batch)
+        sig = [(tuple(b.shape), b.dtype) for b in batch]
+        if sig != self._static_sig:
+            # a HIP graph is one shape: a batch of another shape (a last partial batch, say) takes the eager step --
+            # copying it into the captured buffers would broadcast or fail, and the replay would answer for the wrong batch
+            self.use_graph = False
+            try:
+                return self.step(*batch)
+            finally:
+                self.use_graph = True
         torch._foreach_copy_(self._static_in, list(batch))   # one multi-tensor launch instead of one copy per input
         self._graph.replay()
         if self.world > 1:   # one flat buffer: a single collective (0.86 MB at cfg2, 20.6 MB at cfg3)
             dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.buckets.group)
         self.opt.step(1.0 / self.world)
-        return self._static_loss
+        return self._static_loss.clone()   # the static tensor is overwritten by the next replay
 
     def step(self, *batch):
         if self.use_graph:
@@ -218,9 +291,7 @@ class Trainer:
         self.buckets.enabled = True
         self.fp.zero_grad()
         self.buckets.begin_step()
-        out = self.module(*batch)
-        loss = out[-1] if isinstance(out, tuple) else out
-        self._backward(loss)
+        loss = self._fwd_bwd_on(batch)
         self.buckets.finish_step()
         self.opt.step(1.0 / self.world)
-        return loss.detach()
+        return loss

@@ -693,6 +693,73 @@ def test_hip_graph_step_equals_eager_step(dev, tmp_path, model, kw):
     assert t_graph._graph is not None   # really captured, not the eager fallback
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("d,L,T", [(128, 3, 4), (64, 4, 5)])
+def test_rollout_gradients_identical_with_and_without_wgrad_side_streams(dev, tmp_path, d, L, T, use_graph):
+    """In a rollout every MLP is back-propagated once per AR step and each time accumulates into the same ``.grad``
+    (read-modify-write).  With the weight-gradient work on side streams those accumulations must stay ordered: the
+    side stream is a function of the MLP, not of the call (the MLP counts here, 13 and 15, are not multiples of the 4
+    streams, so a round-robin deal would put consecutive uses of one MLP on different streams).  Bitwise equality with
+    the serial (no side stream) step over several steps, eager and captured."""
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import models as hm
+    from neural_lam_amd.datastore import SyntheticDatastore
+    from neural_lam_amd.trainer import Trainer
+
+    def make(overlap):
+        ds = SyntheticDatastore(60, 54, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+        ext = ds.get_xy_extent("state")
+        raw = G.create_regular_grid_graph(ds.get_xy("state"))
+        graph = G.normalise_graph(raw, max(ext[1] - ext[0], ext[3] - ext[2]))
+        torch.manual_seed(1)
+        fc = hm.ARForecaster(hm.GraphLAM(ds, graph=graph, hidden_dim=d, processor_layers=L), ds)
+        return ds, Trainer(hm.ForecasterStep(fc, ds).to(dev), lr=1e-3, use_graph=use_graph, overlap_wgrad=overlap)
+
+    ds, t_par = make(True)
+    _, t_ser = make(False)
+    N = ds.num_grid_points
+    g = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        batch = [torch.randn(1, 2, N, 5, generator=g).to(dev), torch.randn(1, T, N, 5, generator=g).to(dev),
+                 torch.randn(1, T, N, 6, generator=g).to(dev)]
+        lp, ls = float(t_par.step(*batch)), float(t_ser.step(*batch))
+        assert lp == ls
+        assert torch.equal(t_par.fp.grad, t_ser.fp.grad) and torch.equal(t_par.fp.flat, t_ser.fp.flat)
+    assert (t_par._graph is not None) == use_graph
+
+
+def test_graph_step_falls_back_to_eager_for_another_batch_shape(dev, tmp_path):
+    """A HIP graph is one shape: a batch of a different shape must not be copied (broadcast) into the captured
+    buffers; it takes the eager step, and each returned loss is its own tensor."""
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import models as hm
+    from neural_lam_amd.datastore import SyntheticDatastore
+    from neural_lam_amd.trainer import Trainer
+
+    ds = SyntheticDatastore(30, 27, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+    ext = ds.get_xy_extent("state")
+    graph = G.normalise_graph(G.create_regular_grid_graph(ds.get_xy("state")), max(ext[1] - ext[0], ext[3] - ext[2]))
+
+    def make(use_graph):
+        torch.manual_seed(1)
+        fc = hm.ARForecaster(hm.GraphLAM(ds, graph=graph, hidden_dim=16, processor_layers=1), ds)
+        return Trainer(hm.ForecasterStep(fc, ds).to(dev), lr=1e-3, use_graph=use_graph)
+
+    tg, te = make(True), make(False)
+    N = ds.num_grid_points
+    g = torch.Generator().manual_seed(0)
+    losses = []
+    for B in (2, 2, 1, 2):
+        batch = [torch.randn(B, 2, N, 5, generator=g).to(dev), torch.randn(B, 2, N, 5, generator=g).to(dev),
+                 torch.randn(B, 2, N, 6, generator=g).to(dev)]
+        lg, le = tg.step(*batch), te.step(*batch)
+        losses.append(lg)
+        assert float(lg) == float(le)
+    assert tg._graph is not None and tg.use_graph
+    assert len({float(x) for x in losses}) == 4 and losses[0].data_ptr() != losses[1].data_ptr()
+    assert torch.equal(tg.fp.flat, te.fp.flat)
+
+
 @pytest.mark.parametrize("hidden_layers", [0, 2, 3])
 def test_other_mlp_depths_match_oracle(dev, hidden_layers):
     """utils.make_mlp with hidden_layers != 1 (utils/networks.py:8-40): composed from the fused kernel + library GEMMs."""

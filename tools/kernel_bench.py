@@ -40,7 +40,7 @@ for key, v in recs.items():
     med = v[len(v) // 2]
     name, rows = key[0], key[1]
     if name in ("mlp_fwd", "mlp_bwd"):
-        kin, hid, dout = key[2:]
+        kin, hid, dout = key[2:5]
         fl = 2.0 * rows * (kin * hid + hid * dout)
     else:
         fl = 2.0 * rows * key[2] * key[3]
