@@ -63,6 +63,16 @@ extern "C" {
 #define NLAM_F_ADD_SRC1   2u   /* msg  = mlp + src[1]   (PropagationNet sender / aggr residual) */
 #define NLAM_F_MEAN       4u   /* aggregate = mean over in-edges (sum otherwise)               */
 #define NLAM_F_SILU_B     8u   /* wgrad: apply SiLU to the B operand while loading             */
+/* Factorised first Linear of an edge MLP (gnn_layers.py:168-172, edge_mlp(cat(edge_attr, x_j, x_i))):
+ *   W1 [e | x_j | x_i] = W1_e e + (W1_j x)[sender] + (W1_i x)[receiver],
+ * the two node-level products being computed once per NODE (nlam_linear) instead of once per EDGE.  With this flag
+ * only src[0] goes through the first GEMM (columns 0 .. src[0].width of W1, whose rows are `ldw1` floats apart);
+ * src[1..] are gathered pre-activation ADDENDS of width hid:  z1 = W1_e src0 + b1 + sum_k src[k][idx_k].
+ * Backward: dmode[0] as usual; dmode[k >= 1] = 3 segment-sums dz1 over the tile's receivers into dsrc[k]
+ * ((nseg_total, hid): the gradient of a receiver-gathered addend), 0 / 2 leave it to the caller (a CSC
+ * nlam_segment_sum over the dz1 rows gives the gradient of a sender-gathered addend).  Split-bf16 matrix modes,
+ * widths that are multiples of 32 and <= 64 (NLAM_EUNSUP otherwise); not combined with NLAM_F_ADD_SRC1. */
+#define NLAM_F_PRE_ADD   16u
 /* matrix path of the GEMMs (bits 8-9): 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains);
  * n = 1..3: operands split into n bf16 terms on the bf16 matrix cores, fp32 accumulate
  * (1 = plain bf16 operands, 2 = ~2^-16 product error, 3 = fp32-class ~2^-24).  Shapes the
@@ -114,7 +124,7 @@ typedef struct {
     const int32_t* rowptr; /* (nseg_total + 1) CSR row pointers (needed with aggr)  */
     const float* inv_deg;  /* (nseg_total) 1/max(deg,1) (needed with NLAM_F_MEAN)   */
     int32_t nseg_total;
-    int32_t _pad;
+    int32_t ldw1;          /* NLAM_F_PRE_ADD: floats between rows of W1 (0 = sum of the source widths) */
     /* ---- saved for backward (all nullable; tile-row order) ---- */
     float* z1;             /* (batch, rows, hid)  pre-activation  */
     float* xhat;           /* (batch, rows, dout) normalised, pre-affine (LN only) */
@@ -156,7 +166,7 @@ typedef struct {
     int32_t dmode[NLAM_MAX_SRC];   /* 0 none | 1 rows scattered through src[k].idx (unique)
                                       | 2 tile-row order (rows, width) for a later segment sum
                                       | 3 segment-summed over the tile's receivers -> (nseg_total, width) */
-    int32_t _pad;
+    int32_t ldw1;          /* NLAM_F_PRE_ADD: floats between rows of W1 (0 = sum of the source widths) */
     float* vec_partials;   /* (nblocks, 4, vec_stride): per-workgroup db1, db2, dgamma, dbeta partial sums */
     int32_t vec_partials_rows; /* capacity in rows; must be >= nlam_mlp_bwd_blocks(p) */
     int32_t vec_stride;    /* row stride of vec_partials: multiple of 64, >= max(hid, dout) */
@@ -192,6 +202,10 @@ int32_t nlam_max_width(void);
  *   a 128-row super tile per workgroup needs that many to occupy 256 CUs).
  * Returns 0, or NLAM_EINVAL for an unknown key / negative value. */
 #define NLAM_TUNE_WBF_MIN_SUPERTILES 1
+/*   NLAM_TUNE_WGRAD_CHUNKS: 32-row chunks a weight-gradient workgroup streams through before it writes its (m x n)
+ *   partial, for problems of more than 128 chunks (default 8; 1 = one partial per chunk up to the cap of 512 workgroups;
+ *   larger values trade launch width for less partial-sum traffic). */
+#define NLAM_TUNE_WGRAD_CHUNKS 2
 int32_t nlam_set_tuning(int32_t key, int32_t value);
 /* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this
  * call; 0 when the call runs on the narrow (weights-in-LDS) kernels. */
@@ -232,6 +246,8 @@ typedef struct {
     int32_t nparts;
     int32_t n;
     int32_t accumulate;
+    int32_t ncols;         /* > 0: element i of the reduction goes to out[(i / ncols) * ld + i % ncols] (a column block */
+    int32_t ld;            /*      of a wider row-major matrix: one source's slice of W1.grad); 0: out[i]                */
     int32_t _pad;
 } nlam_reduce_job_t;
 typedef struct {
@@ -240,6 +256,25 @@ typedef struct {
     int32_t _pad;
 } nlam_reduce_jobs_t;
 int32_t nlam_reduce_jobs(const nlam_reduce_jobs_t* jobs, void* hip_stream);
+
+/* Node-level product of the factorised edge MLP (NLAM_F_PRE_ADD) and its data gradient:
+ *   out[r][h] (+)= sum_c x[r][c] * W[h * ldn + c * ldk],   r < rows, h < n, c < k
+ * (forward: W = W1 + column offset, ldn = row stride of W1, ldk = 1; backward: the transposed product with
+ * ldn = 1, ldk = row stride of W1).  x (rows, k) and out (rows, n) are contiguous; k, n in {32, 64, 128};
+ * matrix mode from flags (NLAM_F_MM_BF16X1..3; the fp32-MFMA mode is not instantiated: NLAM_EUNSUP). */
+typedef struct {
+    const float* x;
+    const float* W;
+    float* out;
+    int64_t rows;
+    int64_t ldn;
+    int64_t ldk;
+    int32_t k;
+    int32_t n;
+    int32_t accumulate;    /* != 0: out += */
+    uint32_t flags;
+} nlam_linear_t;
+int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream);
 
 /* Training loss of ForecasterModule.training_step (models/module.py:463-510) with metrics.wmse /
  * mask_and_reduce_metric (metrics.py:37-137) for a per-variable std:

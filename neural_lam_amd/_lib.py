@@ -15,8 +15,9 @@ HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["NLAM_LIB"]) if os.environ.get("NLAM_LIB") else HERE / "libnlam_hip.so"
 
 NLAM_MAX_SRC = 3
-F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B = 1, 2, 4, 8
-TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning key (include/nlam_hip.h)
+F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD = 1, 2, 4, 8, 16
+TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning keys (include/nlam_hip.h)
+TUNE_WGRAD_CHUNKS = 2
 TILE_SPLIT = 1 << 30
 
 EXPORTS = [
@@ -41,6 +42,7 @@ EXPORTS = [
     "nlam_wmse_bwd",
     "nlam_adamw_step",
     "nlam_standardize",
+    "nlam_linear",
 ]
 
 
@@ -79,7 +81,7 @@ class MlpFwd(C.Structure):
         ("rowptr", C.c_void_p),
         ("inv_deg", C.c_void_p),
         ("nseg_total", C.c_int32),
-        ("_pad", C.c_int32),
+        ("ldw1", C.c_int32),
         ("z1", C.c_void_p),
         ("xhat", C.c_void_p),
         ("rstd", C.c_void_p),
@@ -118,7 +120,7 @@ class MlpBwd(C.Structure):
         ("dsrc", C.c_void_p * NLAM_MAX_SRC),
         ("dsrc_bstride", C.c_int64 * NLAM_MAX_SRC),
         ("dmode", C.c_int32 * NLAM_MAX_SRC),
-        ("_pad", C.c_int32),
+        ("ldw1", C.c_int32),
         ("vec_partials", C.c_void_p),
         ("vec_partials_rows", C.c_int32),
         ("vec_stride", C.c_int32),
@@ -151,12 +153,29 @@ class ReduceJob(C.Structure):
         ("nparts", C.c_int32),
         ("n", C.c_int32),
         ("accumulate", C.c_int32),
+        ("ncols", C.c_int32),
+        ("ld", C.c_int32),
         ("_pad", C.c_int32),
     ]
 
 
 class ReduceJobs(C.Structure):
     _fields_ = [("job", ReduceJob * 6), ("njobs", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Linear(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("W", C.c_void_p),
+        ("out", C.c_void_p),
+        ("rows", C.c_int64),
+        ("ldn", C.c_int64),
+        ("ldk", C.c_int64),
+        ("k", C.c_int32),
+        ("n", C.c_int32),
+        ("accumulate", C.c_int32),
+        ("flags", C.c_uint32),
+    ]
 
 
 class StdJob(C.Structure):
@@ -238,10 +257,14 @@ def load():
     lib.nlam_wmse_bwd.restype = i32
     lib.nlam_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
     lib.nlam_adamw_step.restype = i32
+    lib.nlam_linear.argtypes = [C.POINTER(Linear), vp]
+    lib.nlam_linear.restype = i32
     lib.nlam_standardize.argtypes = [C.POINTER(StdJobs), vp]
     lib.nlam_standardize.restype = i32
     if lib.nlam_abi_version() != ABI_VERSION:
         raise RuntimeError("libnlam_hip.so ABI version mismatch")
+    if os.environ.get("NLAM_WGRAD_CHUNKS"):
+        lib.nlam_set_tuning(TUNE_WGRAD_CHUNKS, int(os.environ["NLAM_WGRAD_CHUNKS"]))
     _lib = lib
     return lib
 
@@ -254,7 +277,7 @@ def check(rc: int, what: str):
         raise RuntimeError(f"{what} failed: {kind}")
 
 
-SLICES = (1, 2, 3, 4)   # -DNLAM_TU=k translation-unit slices of csrc/nlam_hip.hip (see the comment at its top)
+SLICES = (1, 2, 3, 4, 5)   # -DNLAM_TU=k translation-unit slices of csrc/nlam_hip.hip (see the comment at its top)
 
 
 def build(verbose: bool = False, out: Path | None = None, defines=(), single_tu: bool | None = None) -> Path:

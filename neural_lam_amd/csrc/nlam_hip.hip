@@ -43,6 +43,7 @@
 //   2  narrow backward + weight gradients
 //   3  fp32 MFMA kernels for 64 < d <= 512 (nlam_wide.inc)
 //   4  split-bf16 kernels for 64 < d <= 512 (nlam_wbf.inc)
+//   5  node-level linear kernels of the factorised edge MLP (nlam_linear)
 // ---------------------------------------------------------------------------
 #ifndef NLAM_TU
 #define NLAM_TU 0
@@ -64,6 +65,7 @@ int32_t fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream);      // slice 4
 int32_t bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream);      // slice 4
 int32_t wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream);      // slice 4
 extern int wbf_min_supertiles;                                     // nlam_set_tuning (defined in slice 1)
+extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
 }  // namespace nlam_detail
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -880,7 +882,9 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
 // RES = the launch adds a residual row (NLAM_F_ADD_SRC0 with an output, or NLAM_F_ADD_SRC1): only then are the 32
 // VGPRs of the stashed residual chunks allocated (the kernel sits at the 256-VGPR limit; spills are VMEM ops and
 // would queue behind the tile's stores)
-template <int HB, int OB, int NS, bool RAG, bool RES>
+// PRE (NLAM_F_PRE_ADD, the factorised edge MLP): only source 0 goes through GEMM1; sources 1.. are gathered
+// pre-activation addends of width hid, fetched in accumulator ("chunk") layout a tile ahead and added to GEMM1's result.
+template <int HB, int OB, int NS, bool RAG, bool RES, bool PRE = false>
 __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_fwd_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int DPH = HB * 32, OP = OB * 32;
@@ -889,15 +893,17 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
 #ifdef NLAM_TIMING
     int t_ntiles_ = 0;
 #endif
-    constexpr int MAXU = RAG ? 2 : 2 * NLAM_MAX_SRC;  // 32-column units per tile row (widths <= 64; RAG: a single source)
+    constexpr int MAXU = (RAG || PRE) ? 2 : 2 * NLAM_MAX_SRC;  // 32-column units per tile row (widths <= 64; RAG / PRE: a single GEMM source)
 
     // every source is padded to whole 32-column units (zero weights / zero-filled loads past its width), so
     // narrow or odd inputs (the 2- / 3-feature embedder inputs, kin = 56) run on the same path
+    const int ngemm = PRE ? 1 : p.nsrc;   // sources that feed GEMM1
     int kin = 0, nunits = 0;
-    for (int s = 0; s < p.nsrc; ++s) {
+    for (int s = 0; s < ngemm; ++s) {
         kin += p.src[s].width;
         nunits += (p.src[s].width + 31) >> 5;
     }
+    const int ldw1 = (PRE && p.ldw1 > 0) ? p.ldw1 : kin;   // floats between rows of W1
     const int S1 = 2 * nunits;
 
     u32x4* W1s = reinterpret_cast<u32x4*>(smem);                       // [NS][HB][S1][64] x 16 B
@@ -923,7 +929,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
             usrc[k2] = 0;
             ucol[k2] = 0;
         }
-        for (int s = 0; s < p.nsrc; ++s)
+        for (int s = 0; s < ngemm; ++s)
             for (int c = 0; c < ((p.src[s].width + 31) >> 5); ++c) {
 #pragma unroll
                 for (int k = 0; k < MAXU; ++k)
@@ -959,7 +965,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
             if (s < p.nsrc && p.src[s].idx != nullptr) ridx[s] = p.src[s].idx[pr];
         }
     };
-    constexpr int kPre = RAG ? 2 : (RES ? NLAM_RES_PRE : 4);   // units prefetched a tile ahead (the rest stream in at the top of their own tile); one fewer
+    constexpr int kPre = (RAG || PRE) ? 2 : (RES ? NLAM_RES_PRE : 4);   // units prefetched a tile ahead (the rest stream in at the top of their own tile); one fewer
                                                     // when 32 registers hold the residual rows: four spilled inside the tile loop
     constexpr int kTop = MAXU - kPre > 0 ? MAXU - kPre : 1;
     f32x4 xp[kPre][4];        // loop-carried: rows of the next tile
@@ -981,10 +987,18 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
             }
         }
     };
+    f32x4 pa[PRE ? 2 : 1][PRE ? HB * 4 : 1];   // loop-carried: the next tile's addend rows, chunk layout (PRE)
     auto load_pre = [&](const float* const (&rp)[NLAM_MAX_SRC]) {
 #pragma unroll
         for (int u = 0; u < kPre; ++u)
             if (u < nunits) load_unit(rp, u, xp[u]);
+        if constexpr (PRE) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int t = 0; t < HB * 4; ++t)
+                    pa[k][t] = 1 + k < p.nsrc ? *reinterpret_cast<const f32x4*>(rp[1 + k] + 8 * t + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     };
     // ---- pipeline prologue: tile 0 fully resolved and loaded, tile 1's descriptor requested ----
     TileInfo tl = {0, 0, 0, 0, false}, tln = {0, 0, 0, 0, false};
@@ -1002,9 +1016,9 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
     // ---- weights -> LDS while the first tile's descriptor / index / row loads are in flight ----
     {
         int s0 = 0, off = 0;
-        for (int s = 0; s < p.nsrc; ++s) {
+        for (int s = 0; s < ngemm; ++s) {
             const int w = p.src[s].width;
-            stage_split<NS>(W1s, S1, s0, p.W1 + off, kin, p.hid, HB, w, false, 1, ((w + 31) >> 5) * 32);
+            stage_split<NS>(W1s, S1, s0, p.W1 + off, ldw1, p.hid, HB, w, false, 1, ((w + 31) >> 5) * 32);
             off += w;
             s0 += 2 * ((w + 31) >> 5);
         }
@@ -1054,6 +1068,16 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[hb][r] = 0.f;
+        if constexpr (PRE) {
+            // (W1_j x)[sender] + (W1_i x)[receiver]: the addend rows prefetched a tile ago ARE the initial accumulators
+            // (chunk layout = accumulator layout), so they cost no registers of their own during GEMM1
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc1[hb][4 * tt + c] = pa[0][hb * 4 + tt][c] + pa[1][hb * 4 + tt][c];
+        }
         f32x4 resid[RES ? 2 : 1][4];   // the 64 columns of source 0 (edge / node residual) or source 1 (PropagationNet)
 #pragma unroll
         for (int u = 0; u < MAXU; ++u) {
@@ -1572,8 +1596,13 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
     int t_ntiles_ = 0;
 #endif
 
+    // NLAM_F_PRE_ADD (factorised edge MLP): only source 0 has columns in W1; sources 1.. are pre-activation addends whose
+    // gradient is dz1 itself (segment-summed over the tile's receivers for dmode 3, left to the caller otherwise)
+    const bool pre = (p.flags & NLAM_F_PRE_ADD) != 0;
     int kin = 0;
-    for (int s = 0; s < p.nsrc; ++s) kin += p.src[s].width;
+    for (int s = 0; s < (pre ? 1 : p.nsrc); ++s) kin += p.src[s].width;
+    if (pre && p.ldw1 > 0) kin = p.ldw1;   // floats between rows of W1
+    auto gemm_src = [&](int s) { return s < p.nsrc && p.dmode[s] != 0 && (!pre || s == 0); };
 
     // ---- weights: W2^T (hid x dout) then W1_s^T (w_s x hid) per source with a data gradient ----
     const size_t w2_floats = NS > 0 ? (size_t)NS * DPH * OP / 2 : (size_t)DPH * OP;
@@ -1584,7 +1613,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
 #pragma unroll
     for (int s = 0; s < NLAM_MAX_SRC; ++s) {
         w1_off[s] = (int)w1_floats;
-        if (s < p.nsrc && p.dmode[s] != 0) w1_floats += NS > 0 ? (size_t)NS * p.src[s].width * DPH / 2 : (size_t)p.src[s].width * DPH;
+        if (gemm_src(s)) w1_floats += NS > 0 ? (size_t)NS * p.src[s].width * DPH / 2 : (size_t)p.src[s].width * DPH;
     }
     float* gml = W1t + w1_floats;                         // OP
     float* stg_all = gml + OP;                            // kWavesPerBlock x 32 x kStgStride
@@ -1595,7 +1624,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
         int off = 0;
         for (int s = 0; s < p.nsrc; ++s) {
             const int w = p.src[s].width;
-            if (p.dmode[s] != 0)   // A[m = source column][k = hidden (slot-permuted)] = W1[k][off + m]
+            if (gemm_src(s))   // A[m = source column][k = hidden (slot-permuted)] = W1[k][off + m]
                 stage_split<NSW>(reinterpret_cast<u32x4*>(W1t + w1_off[s]), S1, 0, p.W1 + off, 1, w, w >> 5, p.hid, true, kin);
             off += w;
         }
@@ -1604,7 +1633,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
         int off = 0;
         for (int s = 0; s < p.nsrc; ++s) {
             const int w = p.src[s].width;
-            if (p.dmode[s] != 0) stage_packed(W1t + w1_off[s], T1, 0, p.W1 + off, 1, kin, w, w >> 5, p.hid);
+            if (gemm_src(s)) stage_packed(W1t + w1_off[s], T1, 0, p.W1 + off, 1, kin, w, w >> 5, p.hid);
             off += w;
         }
     }
@@ -1782,6 +1811,12 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
                 float* dbase = p.dz1 + tile_row0 * p.hid + 32 * hb;
                 block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return dbase + (size_t)r * p.hid; });
             }
+            if (pre) {   // gradient of a receiver-gathered addend = dz1 summed over each receiver's rows (all inside this tile)
+#pragma unroll
+                for (int s = 1; s < NLAM_MAX_SRC; ++s)
+                    if (s < p.nsrc && p.dmode[s] == 3)
+                        block_segment_reduce(stg, tl, raw_ptr, 1.f, p.dsrc[s] + (long)b * p.dsrc_bstride[s] + 32 * hb, p.hid, 32, lane);
+            }
             wave_lds_sync();
         }
 
@@ -1803,7 +1838,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
         }
 #pragma unroll
         for (int s = 0; s < NLAM_MAX_SRC; ++s) {
-            if (s >= p.nsrc || p.dmode[s] == 0) continue;
+            if (!gemm_src(s)) continue;
             const int mode = p.dmode[s];
             const int w = p.src[s].width;
             const int MBs = w >> 5;   // 1 or 2
@@ -2308,26 +2343,60 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* parti
 }
 
 // several partial-sum reductions in one launch (blockIdx.y = job): the weight and vector
-// gradients of one fused-MLP backward, optionally accumulated straight into the flat gradient buffer
+// gradients of one fused-MLP backward, optionally accumulated straight into the flat gradient buffer.
+// The partials of one step add up to several hundred MB at cfg2 (up to 512 x 48 KB per edge MLP): lanes read
+// 16 B each (a wave = 1 KiB of one partial per load), the block's 4 waves split the parts, fixed summation order.
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(const nlam_reduce_jobs_t jobs) {
-    __shared__ float red[4][64];
+    __shared__ f32x4 red[4][64];
     if ((int)blockIdx.y >= jobs.njobs) return;
     const nlam_reduce_job_t jb = jobs.job[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (jb.nparts + 3) / 4;
+    const int q0 = wave * per, q1 = min(jb.nparts, q0 + per);
+    const bool vec = ((jb.n | (int)(jb.stride & 3) | jb.ncols | jb.ld) & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(jb.partials) | reinterpret_cast<uintptr_t>(jb.out)) & 15) == 0;
+    if (vec) {
+        for (int base = blockIdx.x * 256; base < jb.n; base += gridDim.x * 256) {
+            const int idx = base + 4 * lane;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (idx < jb.n) {
+                const float* pp = jb.partials + idx;
+                int q = q0;
+                for (; q + 4 <= q1; q += 4) {   // four independent loads in flight per lane
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(pp + (size_t)q * jb.stride);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(pp + (size_t)(q + 1) * jb.stride);
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(pp + (size_t)(q + 2) * jb.stride);
+                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(pp + (size_t)(q + 3) * jb.stride);
+                    s += (v0 + v1) + (v2 + v3);
+                }
+                for (; q < q1; ++q) s += *reinterpret_cast<const f32x4*>(pp + (size_t)q * jb.stride);
+            }
+            red[wave][lane] = s;
+            __syncthreads();
+            if (wave == 0 && idx < jb.n) {
+                f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+                float* o = jb.out + (jb.ncols > 0 ? (size_t)(idx / jb.ncols) * jb.ld + idx % jb.ncols : (size_t)idx);   // ncols % 4 == 0 here
+                if (jb.accumulate) t += *reinterpret_cast<const f32x4*>(o);
+                *reinterpret_cast<f32x4*>(o) = t;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    float* redf = reinterpret_cast<float*>(&red[0][0]);
     for (int base = blockIdx.x * 64; base < jb.n; base += gridDim.x * 64) {
         const int idx = base + lane;
         float s = 0.f;
         if (idx < jb.n) {
-            const int per = (jb.nparts + 3) / 4;
-            const int q0 = wave * per, q1 = min(jb.nparts, q0 + per);
 #pragma unroll 8
             for (int q = q0; q < q1; ++q) s += jb.partials[(size_t)q * jb.stride + idx];
         }
-        red[wave][lane] = s;
+        redf[wave * 64 + lane] = s;
         __syncthreads();
         if (wave == 0 && idx < jb.n) {
-            const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-            jb.out[idx] = jb.accumulate ? jb.out[idx] + t : t;
+            const float t = (redf[lane] + redf[64 + lane]) + (redf[128 + lane] + redf[192 + lane]);
+            float* o = jb.out + (jb.ncols > 0 ? (size_t)(idx / jb.ncols) * jb.ld + idx % jb.ncols : (size_t)idx);
+            *o = jb.accumulate ? *o + t : t;
         }
         __syncthreads();
     }
@@ -2411,6 +2480,81 @@ __global__ void adamw_kernel(float* param, const float* grad, float* m, float* v
     }
 }
 
+// ---------------------------------------------------------------------------
+// node-level products of the factorised edge MLP (nlam_linear):
+//   out[r][h] (+)= sum_c x[r][c] * W[h * ldn + c * ldk],  k = 32 * KB, n = 32 * MB
+// One wave = one 32-row tile; W staged once per persistent workgroup as split-bf16 A fragments (the GEMM1 machinery of
+// mlp_fwd_bf_kernel: rows are the N side of the MFMA, output features the M side).
+// ---------------------------------------------------------------------------
+template <int KB, int MB, int NS>
+__global__ __launch_bounds__(kFwdThreads) void linear_bf_kernel(const nlam_linear_t p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int S = 2 * KB;
+    u32x4* Ws = reinterpret_cast<u32x4*>(smem);                              // [NS][MB][S][64] x 16 B
+    float* stg_all = reinterpret_cast<float*>(Ws + (size_t)NS * MB * S * 64);   // kFwdWaves x 32 x kStgStride
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    float* stg = stg_all + (size_t)wave * 32 * kStgStride;
+    const long ntiles = (p.rows + 31) / 32;
+    const int nwaves = blockDim.x >> 6;
+    long gt = (long)wave * gridDim.x + blockIdx.x;
+    const long stride = (long)gridDim.x * nwaves;
+
+    auto load_rows = [&](long t, f32x4(&xu)[KB][4]) {
+        const long r = min(t * 32 + j, p.rows - 1);   // clamped: rows past the end are discarded at the store
+        const float* row = p.x + r * p.k + 8 * hi;
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            xu[u][0] = *reinterpret_cast<const f32x4*>(row + 32 * u);
+            xu[u][1] = *reinterpret_cast<const f32x4*>(row + 32 * u + 4);
+            xu[u][2] = *reinterpret_cast<const f32x4*>(row + 32 * u + 16);
+            xu[u][3] = *reinterpret_cast<const f32x4*>(row + 32 * u + 20);
+        }
+    };
+    f32x4 xu[KB][4];
+    if (gt < ntiles) load_rows(gt, xu);
+    stage_split<NS>(Ws, S, 0, p.W, p.ldn, p.n, MB, p.k, false, p.ldk);
+    __syncthreads();
+
+    for (; gt < ntiles; gt += stride) {
+        f32x16 acc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < KB; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float xs8[8] = {xu[u][2 * h][0], xu[u][2 * h][1], xu[u][2 * h][2], xu[u][2 * h][3],
+                                      xu[u][2 * h + 1][0], xu[u][2 * h + 1][1], xu[u][2 * h + 1][2], xu[u][2 * h + 1][3]};
+                const BfFrag<NS> B = split8<NS>(xs8);
+                mma_split_lds<NS, MB>(acc, Ws, MB, S, 2 * u + h, lane, B);
+            }
+        const long t0 = gt;
+        if (gt + stride < ntiles) load_rows(gt + stride, xu);   // next tile's rows ahead of this tile's stores
+        const int nrows = (int)min((long)32, p.rows - t0 * 32);
+        float* obase = p.out + t0 * 32 * p.n;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(acc[mb], tt);
+            wave_lds_sync();
+            for (int base = 0; base < nrows * 8; base += 64) {   // lane -> (row, float4 column): whole 128-B lines per row
+                const int item = base + lane;
+                if (item < nrows * 8) {
+                    const int r = item >> 3, c4 = item & 7;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&stg[r * kStgStride + 4 * c4]);
+                    float* d = obase + (size_t)r * p.n + 32 * mb + 4 * c4;
+                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(d);
+                    *reinterpret_cast<f32x4*>(d) = v;
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
 #include "nlam_wide.inc"
 #include "nlam_wbf.inc"
 
@@ -2419,12 +2563,13 @@ __global__ void adamw_kernel(float* param, const float* grad, float* m, float* v
 // ---------------------------------------------------------------------------
 size_t fwd_lds_bytes(const nlam_mlp_fwd_t* p, int HB, int OB, int NS = 0) {
     const int DPH = HB * 32, OP = OB * 32;
+    const int ngemm = (p->flags & NLAM_F_PRE_ADD) ? 1 : p->nsrc;   // sources whose W1 columns are staged
     size_t T1 = 0;
-    for (int s = 0; s < p->nsrc; ++s) T1 += (p->src[s].width + 7) / 8;
+    for (int s = 0; s < ngemm; ++s) T1 += (p->src[s].width + 7) / 8;
     size_t wf = (size_t)DPH * 8 * T1 + (size_t)OP * DPH;   // weights, in floats
     if (NS > 0) {                                            // NS bf16 copies, sources padded to 32-column units
         size_t k1 = 0;
-        for (int s = 0; s < p->nsrc; ++s) k1 += (size_t)((p->src[s].width + 31) / 32) * 32;
+        for (int s = 0; s < ngemm; ++s) k1 += (size_t)((p->src[s].width + 31) / 32) * 32;
         wf = ((size_t)DPH * k1 + (size_t)OP * DPH) * NS / 2;
     }
     size_t f = wf + DPH + 3 * OP;
@@ -2444,8 +2589,9 @@ size_t bwd_lds_bytes(const nlam_mlp_bwd_t* p, int HB, int OB) {
 size_t bwd_fast_lds_bytes(const nlam_mlp_bwd_t* p, int HB, int OB, int NS) {
     const int DPH = HB * 32, OP = OB * 32;
     size_t wf = (size_t)DPH * OP;
+    const bool pre = (p->flags & NLAM_F_PRE_ADD) != 0;
     for (int s = 0; s < p->nsrc; ++s)
-        if (p->dmode[s] != 0) wf += (size_t)p->src[s].width * DPH;
+        if (p->dmode[s] != 0 && (!pre || s == 0)) wf += (size_t)p->src[s].width * DPH;
     if (NS > 0) wf = wf * NS / 2;
     return (wf + OP + (size_t)kWavesPerBlock * 32 * kStgStride + (size_t)kWavesPerBlock * 8 * 64) * sizeof(float);
 }
@@ -2587,6 +2733,7 @@ int wgrad_windows(const nlam_wgrad_t* p) { return wgrad_windows_of(p, kWWin, kWW
 // ---------------------------------------------------------------------------
 #if NLAM_IN_TU(1)
 int nlam_detail::wbf_min_supertiles = 192;
+int nlam_detail::wgrad_chunks_per_wg = 8;   // A/B at cfg2 (tools/ab_bench.sh): 2.13 -> 2.06 ms per step against one chunk per workgroup
 #endif
 
 #if NLAM_IN_TU(1)
@@ -2612,6 +2759,11 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_WBF_MIN_SUPERTILES) {
         if (value < 0) return NLAM_EINVAL;
         nlam_detail::wbf_min_supertiles = value;
+        return 0;
+    }
+    if (key == NLAM_TUNE_WGRAD_CHUNKS) {
+        if (value < 1) return NLAM_EINVAL;
+        nlam_detail::wgrad_chunks_per_wg = value;
         return 0;
     }
     return NLAM_EINVAL;
@@ -2652,7 +2804,12 @@ int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p) {
 int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     if (p == nullptr) return 0;
     const long total_chunks = (long)p->batch * ((p->rows + kWgradRows - 1) / kWgradRows);
-    long np = total_chunks;   // small problems: one 32-row chunk per workgroup (latency-bound otherwise)
+    // small problems: one 32-row chunk per workgroup (latency-bound otherwise); larger ones give every workgroup ~8 chunks
+    // to stream through its double buffer -- each workgroup writes an (m x n) partial that the reduction reads back, and
+    // with 512 partials per weight matrix those were ~0.7 GB of traffic per cfg2 step (reduce_jobs: 290 us of 3.7 ms of kernel time)
+    const long cpw = nlam_detail::wgrad_chunks_per_wg < 1 ? 1 : nlam_detail::wgrad_chunks_per_wg;   // nlam_set_tuning
+    long np = total_chunks <= 128 ? total_chunks : (total_chunks + cpw - 1) / cpw;
+    if (np < 128 && total_chunks > 128) np = 128;
     long cap = 512;
     if (p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) np = (total_chunks + 3) / 4;   // streaming kernel: >= 128 rows per workgroup
     if (wgrad_is_wide(p)) {
@@ -2684,6 +2841,19 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
         else if (resid) NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, false, true); \
         else NLAM_LAUNCH_FWDBF1(HB_, OB_, NS_, false, false);          \
     } while (0)
+#define NLAM_LAUNCH_FWDPRE1(HB_, OB_, NS_, RES_)                                                                                \
+    do {                                                                                                                       \
+        const size_t lds = fwd_lds_bytes(p, HB_, OB_, NS_);                                                                    \
+        int rc = set_lds(mlp_fwd_bf_kernel<HB_, OB_, NS_, false, RES_, true>, lds);                                            \
+        if (rc != 0) return rc;                                                                                                \
+        hipLaunchKernelGGL((mlp_fwd_bf_kernel<HB_, OB_, NS_, false, RES_, true>), dim3(blocks), dim3(nwaves * 64), lds, stream, *p); \
+    } while (0)
+#define NLAM_LAUNCH_FWDPRE(HB_, OB_)                                   \
+    do {                                                               \
+        if (ns == 3) { if (resid) NLAM_LAUNCH_FWDPRE1(HB_, OB_, 3, true); else NLAM_LAUNCH_FWDPRE1(HB_, OB_, 3, false); } \
+        else if (ns == 2) { if (resid) NLAM_LAUNCH_FWDPRE1(HB_, OB_, 2, true); else NLAM_LAUNCH_FWDPRE1(HB_, OB_, 2, false); } \
+        else { if (resid) NLAM_LAUNCH_FWDPRE1(HB_, OB_, 1, true); else NLAM_LAUNCH_FWDPRE1(HB_, OB_, 1, false); } \
+    } while (0)
 #define NLAM_LAUNCH_FWD(HB_, OB_)                            \
     do {                                                     \
         if (ns == 3) NLAM_LAUNCH_FWDBF(HB_, OB_, 3);         \
@@ -2703,6 +2873,7 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
     if (p->rows == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
     if (fwd_is_wide(p)) {
+        if (p->flags & NLAM_F_PRE_ADD) return NLAM_EUNSUP;
         const WideCfg cfg = wide_cfg(p->hid > p->dout ? p->hid : p->dout);
         if (cfg.nwv == 0) return NLAM_EUNSUP;
         const int64_t need = nlam_mlp_fwd_wpack_floats(p);
@@ -2832,6 +3003,15 @@ int32_t nlam_detail::fwd_narrow(const nlam_mlp_fwd_t* p, hipStream_t stream) {
     int ns = 0;
     if (fast_out && w64) ns = (int)((p->flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
     if (ns > 3) return NLAM_EINVAL;
+    if (p->flags & NLAM_F_PRE_ADD) {   // factorised edge MLP: split-bf16 modes, whole 32-column units, addends of width hid
+        bool ok = ns > 0 && !ragged && p->nsrc >= 2 && (p->flags & NLAM_F_ADD_SRC1) == 0 && HB == OB;
+        for (int s = 1; s < p->nsrc; ++s) ok = ok && p->src[s].width == p->hid;
+        if (!ok) return NLAM_EUNSUP;
+        if (HB == 1) NLAM_LAUNCH_FWDPRE(1, 1);
+        else if (HB == 2) NLAM_LAUNCH_FWDPRE(2, 2);
+        else return NLAM_EUNSUP;
+        return (int32_t)hipGetLastError();
+    }
     if (HB == 1 && OB == 1) NLAM_LAUNCH_FWD(1, 1);
     else if (HB == 2 && OB == 1) NLAM_LAUNCH_FWD(2, 1);
     else if (HB == 1 && OB == 2) NLAM_LAUNCH_FWD(1, 2);
@@ -2862,6 +3042,7 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
     }
     if (p->rows == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
+    if (bwd_is_wide(p) && (p->flags & NLAM_F_PRE_ADD)) return NLAM_EUNSUP;
     if (bwd_is_wide(p)) {
         const WideCfg cfg = wide_cfg(bwd_wide_maxw(p));
         if (cfg.nwv == 0) return NLAM_EUNSUP;
@@ -2985,6 +3166,12 @@ int32_t nlam_detail::bwd_narrow(const nlam_mlp_bwd_t* p, hipStream_t stream) {
     for (int s = 0; s < p->nsrc; ++s)
         if (p->dmode[s] != 0) fast = fast && (p->src[s].width == 32 || p->src[s].width == 64);
     if ((p->flags & NLAM_F_ADD_SRC0) && p->dmode[0] != 0 && p->src[0].width != p->dout) fast = false;
+    if (p->flags & NLAM_F_PRE_ADD) {   // factorised edge MLP: FAST shapes and split-bf16 modes only
+        bool ok = fast && ((p->flags & NLAM_F_MM_MASK) != 0) && (p->flags & NLAM_F_ADD_SRC1) == 0 && p->nsrc >= 2;
+        ok = ok && (p->src[0].width == 32 || p->src[0].width == 64);
+        for (int s = 1; s < p->nsrc; ++s) ok = ok && p->src[s].width == p->hid && (p->dmode[s] == 0 || p->dmode[s] == 2 || p->dmode[s] == 3);
+        if (!ok) return NLAM_EUNSUP;
+    }
     if (fast) {
         const int ns = (int)((p->flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
 #define NLAM_LAUNCH_BWDF1(HB_, OB_, NS_)                                                                            \
@@ -3128,6 +3315,43 @@ int32_t nlam_detail::wgrad_narrow(const nlam_wgrad_t* p, hipStream_t stream) {
 }
 #endif
 
+#if NLAM_IN_TU(5)
+extern "C" {
+
+int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream) {
+    if (p == nullptr || p->x == nullptr || p->W == nullptr || p->out == nullptr || p->rows < 0 || p->k < 1 || p->n < 1) return NLAM_EINVAL;
+    if (p->rows == 0) return 0;
+    const int ns = (int)((p->flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
+    if (ns == 0 || p->k % 32 != 0 || p->n % 32 != 0) return NLAM_EUNSUP;
+    if (((reinterpret_cast<uintptr_t>(p->x) | reinterpret_cast<uintptr_t>(p->out)) & 15) != 0) return NLAM_EINVAL;
+    const int KB = p->k / 32, MB = p->n / 32;
+    const long ntiles = (p->rows + 31) / 32;
+    const int blocks = (int)(ntiles < kMaxGridBlocks ? ntiles : kMaxGridBlocks);
+    const size_t lds = (size_t)ns * MB * 2 * KB * 64 * 16 + (size_t)kFwdWaves * 32 * kStgStride * sizeof(float);
+    hipStream_t stream = (hipStream_t)hip_stream;
+#define NLAM_LAUNCH_LIN1(KB_, MB_, NS_)                                                                          \
+    do {                                                                                                        \
+        int rc = set_lds(linear_bf_kernel<KB_, MB_, NS_>, lds);                                                 \
+        if (rc != 0) return rc;                                                                                 \
+        hipLaunchKernelGGL((linear_bf_kernel<KB_, MB_, NS_>), dim3(blocks), dim3(kFwdThreads), lds, stream, *p); \
+    } while (0)
+#define NLAM_LAUNCH_LIN(KB_, MB_)                         \
+    do {                                                  \
+        if (ns == 3) NLAM_LAUNCH_LIN1(KB_, MB_, 3);       \
+        else if (ns == 2) NLAM_LAUNCH_LIN1(KB_, MB_, 2);  \
+        else NLAM_LAUNCH_LIN1(KB_, MB_, 1);               \
+    } while (0)
+    if (KB == 1 && MB == 1) NLAM_LAUNCH_LIN(1, 1);
+    else if (KB == 2 && MB == 1) NLAM_LAUNCH_LIN(2, 1);
+    else if (KB == 1 && MB == 2) NLAM_LAUNCH_LIN(1, 2);
+    else if (KB == 2 && MB == 2) NLAM_LAUNCH_LIN(2, 2);
+    else return NLAM_EUNSUP;
+    return (int32_t)hipGetLastError();
+}
+
+}  // extern "C"
+#endif
+
 #if NLAM_IN_TU(1)
 extern "C" {
 
@@ -3169,9 +3393,10 @@ int32_t nlam_reduce_jobs(const nlam_reduce_jobs_t* jobs, void* hip_stream) {
     for (int k = 0; k < jobs->njobs; ++k) {
         const nlam_reduce_job_t& j = jobs->job[k];
         if (j.partials == nullptr || j.out == nullptr || j.nparts < 1 || j.n < 1) return NLAM_EINVAL;
+        if (j.ncols < 0 || (j.ncols > 0 && (j.ld < j.ncols || j.n % j.ncols != 0))) return NLAM_EINVAL;
         if (j.n > nmax) nmax = j.n;
     }
-    int blocks = (nmax + 63) / 64;
+    int blocks = (nmax + 255) / 256;   // 256 elements per block and pass on the 16-B path (the scalar path strides by gridDim.x * 64)
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(reduce_jobs_kernel, dim3(blocks, jobs->njobs), dim3(256), 0, (hipStream_t)hip_stream, *jobs);
     return (int32_t)hipGetLastError();

@@ -22,7 +22,19 @@ from torch import nn
 
 from . import _lib as L
 from .graph import EdgeCSR, build_edge_csr, build_tile_schedule
-from .ops import FusedMLPFunction, MlpGeometry, as_batched, segment_sum
+import os
+
+from . import ops
+from .ops import FusedMLPFunction, MlpGeometry, NodeLinearFunction, as_batched, segment_sum
+
+# Edge sets with at least this many edges (per batch item) run the FACTORISED edge MLP:
+#   W1 [e | x_j | x_i] = W1_e e + (W1_j x)[sender] + (W1_i x)[receiver]
+# -- the two node-level products are computed once per node (nlam_linear) and gathered as pre-activation addends, so the
+# edge kernels run one third of the first GEMM (half of all their matrix work, a third of the weight staging and of the
+# dW1 weight gradient), and the sender-side data gradient is a segment sum of dz1 instead of a (E, d) round trip.
+# Below the threshold the two extra node-level launches cost more than they save (the mesh-level layers of cfg2 are
+# latency-bound single-tile-per-wave launches).
+FACTORISE_MIN_EDGES = int(os.environ.get("NLAM_FACTORISE_MIN_EDGES", str(1 << 30)))
 
 
 class FusedMLP(nn.Sequential):
@@ -78,6 +90,7 @@ class FusedMLP(nn.Sequential):
                 y = torch.nn.functional.layer_norm(y, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
             return y
         k = 0
+        leaf_input = not x.requires_grad
         if n % 2 == 1:   # leftover leading Linear -> SiLU
             x = torch.nn.functional.silu(torch.nn.functional.linear(x, lin[0].weight, lin[0].bias))
             k = 1
@@ -90,7 +103,8 @@ class FusedMLP(nn.Sequential):
             )
             x = out if last else torch.nn.functional.silu(out)
             k += 2
-        return x
+        # an MLP of input data / static features: nothing upstream needs its data gradient (ops.early_backward_leaf)
+        return ops.early_backward_leaf(x) if leaf_input else x
 
     def forward_fused(self, geom: MlpGeometry, *srcs):
         """Run with a caller-supplied geometry (concatenated sources, residuals, ...); hidden_layers == 1 only."""
@@ -201,10 +215,10 @@ class InteractionNet(nn.Module):
             self._csr_cache[key] = csr
         return self._csr_cache[key]
 
-    def _edge_geom(self, csr: EdgeCSR, want_out: bool, add_edge: bool, key) -> MlpGeometry:
-        gkey = (key, want_out, add_edge)
+    def _edge_geom(self, csr: EdgeCSR, want_out: bool, add_edge: bool, key, pre: bool = False) -> MlpGeometry:
+        gkey = (key, want_out, add_edge, pre)
         if gkey not in self._geom_cache:
-            flags = 0
+            flags = L.F_PRE_ADD if pre else 0
             if add_edge:
                 flags |= L.F_ADD_SRC0
             if self.propagates_sender:
@@ -252,9 +266,30 @@ class InteractionNet(nn.Module):
         csr = self._csr(send_rep.device, send_rep.shape[-2])
         if isinstance(self.edge_mlp, SplitMLPs) or not self.edge_mlp.fully_fused:
             return self._messages_generic(csr, send_rep, rec_rep, edge_rep, want_out, add_edge)
-        geom = self._edge_geom(csr, want_out, add_edge, (str(send_rep.device), send_rep.shape[-2]))
+        key = (str(send_rep.device), send_rep.shape[-2])
+        if self._factorise(csr, send_rep, rec_rep, edge_rep):
+            W1 = self.edge_mlp[0].weight
+            d = edge_rep.shape[-1]
+            p_send = NodeLinearFunction.apply(send_rep, W1, d)                         # (W1_j x) per sender node
+            p_rec = NodeLinearFunction.apply(rec_rep, W1, d + send_rep.shape[-1])      # (W1_i x) per receiver node
+            geom = self._edge_geom(csr, want_out, add_edge, key, pre=True)
+            edge_out, aggr = self.edge_mlp.forward_fused(geom, edge_rep, p_send, p_rec)
+            return aggr, edge_out
+        geom = self._edge_geom(csr, want_out, add_edge, key)
         edge_out, aggr = self.edge_mlp.forward_fused(geom, edge_rep, send_rep, rec_rep)
         return aggr, edge_out
+
+    def _factorise(self, csr, send_rep, rec_rep, edge_rep) -> bool:
+        """Factorised edge MLP (see FACTORISE_MIN_EDGES): InteractionNet messages (no ``x_j +`` term), split-bf16 matrix
+        modes, widths that the narrow kernels take as whole 32-column units."""
+        if self.propagates_sender or csr.num_edges < FACTORISE_MIN_EDGES:
+            return False
+        if (ops._mm_flags() >> 8) & 3 == 0:
+            return False
+        d, hid = edge_rep.shape[-1], self.edge_mlp[0].out_features
+        dout = self.edge_mlp[2].out_features
+        ok = lambda w: w in (32, 64)  # noqa: E731
+        return ok(d) and ok(hid) and hid == dout and send_rep.shape[-1] == d and rec_rep.shape[-1] == d
 
     def _messages_generic(self, csr, send_rep, rec_rep, edge_rep, want_out, add_edge):
         # chunked edge MLPs (HiLAMParallel): per-chunk fused MLP kernels over an explicit

@@ -59,15 +59,43 @@ DIRECT_PARAM_GRADS = False
 GRAD_LISTENER = None
 
 
+# Early backward of "leaf" MLPs (see early_backward_leaf); switched on together with DIRECT_PARAM_GRADS.
+EARLY_LEAF_BACKWARD = False
+
+
 @contextlib.contextmanager
-def direct_param_grads(listener=None):
-    global DIRECT_PARAM_GRADS, GRAD_LISTENER
-    prev = (DIRECT_PARAM_GRADS, GRAD_LISTENER)
-    DIRECT_PARAM_GRADS, GRAD_LISTENER = True, listener
+def direct_param_grads(listener=None, early_leaf=True):
+    global DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD
+    prev = (DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD)
+    DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD = True, listener, bool(early_leaf)
     try:
         yield
     finally:
-        DIRECT_PARAM_GRADS, GRAD_LISTENER = prev
+        DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD = prev
+
+
+def early_backward_leaf(out):
+    """Cut the autograd graph behind an MLP whose inputs need no gradient (the embedders of the static grid / mesh /
+    edge features, the grid embedder of the first AR step) and run its backward as soon as the gradient of its output
+    is complete, instead of when the autograd engine gets to it.
+
+    The engine executes backward nodes in reverse order of their creation, so these first-created MLPs come last: at
+    cfg2 their five data-gradient launches (86 + 41 + 45 + 33 + 21 us) formed a serial 270 us tail of the step although
+    e.g. the gradient of the m2g edge embedding is final 900 us earlier.  Nothing downstream depends on them -- only
+    the optimizer needs their parameter gradients -- so the consumer sees a detached leaf, and the leaf's
+    post-accumulate hook (AccumulateGrad nodes have top priority in the engine) runs the MLP's own backward right
+    there; FusedMLPFunction.backward puts all of it (data-gradient kernel included) on a weight-gradient side stream.
+    """
+    if not (EARLY_LEAF_BACKWARD and torch.is_grad_enabled() and out.requires_grad):
+        return out
+    leaf = out.detach().requires_grad_()
+
+    def hook(t):
+        g, t.grad = t.grad, None
+        torch.autograd.backward(out, g)   # nested (re-entrant) backward of the small graph behind `out`
+
+    leaf.register_post_accumulate_grad_hook(hook)
+    return leaf
 
 
 class _WgradOverlap:
@@ -298,7 +326,11 @@ class FusedMLPFunction(torch.autograd.Function):
             if b_ not in (1, B):
                 raise RuntimeError(f"inconsistent batch sizes among sources: {b_} vs {B}")
         widths = [s.shape[-1] for s in srcs]
-        if sum(widths) != kin:
+        pre = bool(geom.flags & L.F_PRE_ADD)   # factorised edge MLP: sources 1.. are pre-activation addends (width hid)
+        if pre:
+            if widths[0] > kin or any(w != hid for w in widths[1:]):
+                raise RuntimeError(f"factorised edge MLP: source widths {widths} do not fit W1 {tuple(W1.shape)}")
+        elif sum(widths) != kin:
             raise RuntimeError(f"source widths {widths} do not add up to the first Linear's in_features {kin}")
         rows = geom.rows if geom.rows is not None else srcs[0].shape[-2]
         ntiles = geom.tiles.shape[0] if geom.tiles is not None else (rows + 31) // 32
@@ -315,6 +347,7 @@ class FusedMLPFunction(torch.autograd.Function):
         p.W1, p.b1, p.W2, p.b2 = _ptr(W1c), _ptr(b1c), _ptr(W2c), _ptr(b2c)
         p.ln_w, p.ln_b = _ptr(ln_w), _ptr(ln_b)
         p.eps, p.hid, p.dout, p.flags = 1e-5, hid, dout, geom.flags | mm_flags
+        p.ldw1 = kin if pre else 0
         ctx.mm_flags = mm_flags
         out = aggr = None
         if geom.want_out:
@@ -351,8 +384,9 @@ class FusedMLPFunction(torch.autograd.Function):
                 if t_ is not None:
                     nbytes += t_.numel() * 4
             name, mf = _mm_executed(mm_flags, hid, dout, widths)
-            return {"flops": 2.0 * rows * B * (kin * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
-                    "what": ("gather + " if geom.nsrc == 3 else "") + "Linear-SiLU-Linear" + ("-LayerNorm" if ln_w is not None else "")
+            k1 = widths[0] if pre else kin
+            return {"flops": 2.0 * rows * B * (k1 * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
+                    "what": ("gather + " if geom.nsrc == 3 else "") + ("factorised " if pre else "") + "Linear-SiLU-Linear" + ("-LayerNorm" if ln_w is not None else "")
                             + (" + segment aggregate" if geom.aggregate else "") + (" (saves z1/xhat/rstd)" if need_grad else "")}
 
         L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_fwd(C.byref(p), _stream()), fwd_meta), "nlam_mlp_fwd")
@@ -408,6 +442,8 @@ class FusedMLPFunction(torch.autograd.Function):
         p.tiles = _ptr(geom.tiles)
         p.W1, p.W2, p.ln_w = _ptr(W1), _ptr(W2), _ptr(ln_w) if ctx.has_ln else None
         p.hid, p.dout, p.flags, p.nseg_total = hid, dout, geom.flags | ctx.mm_flags, geom.nseg_total
+        pre = bool(geom.flags & L.F_PRE_ADD)
+        p.ldw1 = kin if pre else 0
         if g_out is not None:
             p.g_out, p.out_idx, p.out_bstride = _ptr(g_out), _ptr(geom.out_idx), g_out.shape[1] * dout
         if g_aggr is not None:
@@ -427,6 +463,9 @@ class FusedMLPFunction(torch.autograd.Function):
             w = widths[k]
             n_src_rows = ctx.src_shapes[k][-2]
             p.dmode[k] = mode
+            if pre and k > 0 and mode == 2:
+                p.dmode[k] = 0   # gradient of a sender-gathered addend: a CSC segment sum over the dz1 rows, below
+                continue
             if mode == 1:
                 # rows scattered through the (unique, covering) gather index, or identity
                 dsrc[k] = torch.empty((B, n_src_rows, w), device=dev, dtype=torch.float32)
@@ -439,6 +478,7 @@ class FusedMLPFunction(torch.autograd.Function):
                 dsrc[k] = alloc((B, geom.nseg_total, w), device=dev, dtype=torch.float32)
                 p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), geom.nseg_total * w
         nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
+        wpack = None
         if nwp > 0:
             wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
             p.wpack, p.wpack_floats = _ptr(wpack), nwp
@@ -446,35 +486,10 @@ class FusedMLPFunction(torch.autograd.Function):
         vs = _vec_stride(hid, dout)
         vecp = torch.empty((nblk, 4, vs), device=dev, dtype=torch.float32)
         p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(vecp), nblk, vs
-        key = ("mlp_bwd", rows * B, kin, hid, dout, nsrc, g_aggr is not None)
 
-        def bwd_meta():
-            nbytes = sum(t_.numel() * 4 for t_ in (g_out, g_aggr, z1, xhat, rstd, dz1, dz2) if t_ is not None)
-            nbytes += sum(t_.numel() * 4 for t_ in (*dsrc, *tmp2) if t_ is not None)
-            kin_live = sum(w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0)
-            name, mf = _mm_executed(ctx.mm_flags, hid, dout, [w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0] or [hid])
-            return {"flops": 2.0 * rows * B * (kin_live * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
-                    "what": "LayerNorm/SiLU backward + dh = dz2 W2 + dx = dz1 W1 (data gradients; writes dz1, dz2 for the weight gradients)"}
-
-        L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_bwd(C.byref(p), _stream()), bwd_meta), "nlam_mlp_bwd")
-
-        for k in range(nsrc):
-            if tmp2[k] is not None:  # finish scatter-by-sender as a CSC segment sum
-                tw = ctx.twin_of.get(k)
-                if tw is not None and dsrc[tw] is not None and dsrc[tw].shape == (B, geom.num_send, widths[k]):
-                    # senders and receivers are the same tensor (mesh <-> mesh layers): add onto the receiver-side
-                    # gradient and report nothing for this slot -- one autograd add launch less per layer
-                    segment_sum(tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B,
-                                out=dsrc[tw], accumulate=True)
-                    dsrc[k] = None
-                else:
-                    dsrc[k] = segment_sum(
-                        tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B
-                    )
-
-        # ---- weight gradients: two TN GEMMs with deterministic two-stage reduction ----
-        # ---- weight gradients: TN GEMMs with a deterministic two-stage reduction; on the side stream when the
-        # trainer owns the parameter gradients (see _WgradOverlap) ----
+        # ---- where the launches go.  Weight gradients (needed only by the optimizer) run on a side stream when the
+        # trainer owns the parameter gradients (see _WgradOverlap); an MLP none of whose inputs needs a gradient is a
+        # dead end of backward, so its data-gradient kernel goes there as well ----
         prm = ctx.param_refs
 
         def is_direct(param, shape):
@@ -490,13 +505,50 @@ class FusedMLPFunction(torch.autograd.Function):
             (5, ctx.has_ln and ctx.needs_input_grad[6], prm[5], (dout,)),
         ]
         on_side = OVERLAP.active and all(is_direct(pp, sh) for _, need, pp, sh in wanted if need)
-        if on_side:
-            side = OVERLAP.stream_for(prm[0])
+        whole_side = on_side and not any(ctx.needs_input_grad[n_fixed:])
+        streams = contextlib.ExitStack()
+        side = OVERLAP.stream_for(prm[0]) if on_side else None
+        if whole_side:
             side.wait_stream(torch.cuda.current_stream())
+            OVERLAP.hold(side, g_out, g_aggr, xhat, rstd, wpack)
+            streams.enter_context(torch.cuda.stream(side))
+        key = ("mlp_bwd", rows * B, kin, hid, dout, nsrc, g_aggr is not None)
+
+        def bwd_meta():
+            nbytes = sum(t_.numel() * 4 for t_ in (g_out, g_aggr, z1, xhat, rstd, dz1, dz2) if t_ is not None)
+            nbytes += sum(t_.numel() * 4 for t_ in (*dsrc, *tmp2) if t_ is not None)
+            kin_live = sum(w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0 and not (pre and k_ > 0))
+            name, mf = _mm_executed(ctx.mm_flags, hid, dout, [w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0] or [hid])
+            return {"flops": 2.0 * rows * B * (kin_live * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
+                    "what": "LayerNorm/SiLU backward + dh = dz2 W2 + dx = dz1 W1 (data gradients; writes dz1, dz2 for the weight gradients)"}
+
+        L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_bwd(C.byref(p), _stream()), bwd_meta), "nlam_mlp_bwd")
+
+        if pre:
+            for k in range(1, nsrc):
+                if ctx.needs_input_grad[n_fixed + k] and geom.dmode[k] == 2:   # no (rows, w) round trip: dz1 is the data
+                    dsrc[k] = segment_sum(dz1, rows * hid, geom.colptr, geom.cperm, None, geom.num_send, hid, B)
+        for k in range(nsrc):
+            if tmp2[k] is not None:  # finish scatter-by-sender as a CSC segment sum
+                tw = ctx.twin_of.get(k)
+                if tw is not None and dsrc[tw] is not None and dsrc[tw].shape == (B, geom.num_send, widths[k]):
+                    # senders and receivers are the same tensor (mesh <-> mesh layers): add onto the receiver-side
+                    # gradient and report nothing for this slot -- one autograd add launch less per layer
+                    segment_sum(tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B,
+                                out=dsrc[tw], accumulate=True)
+                    dsrc[k] = None
+                else:
+                    dsrc[k] = segment_sum(
+                        tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B
+                    )
+
+        # ---- weight gradients: TN GEMMs with a deterministic two-stage reduction ----
+        if on_side:
+            if not whole_side:
+                side.wait_stream(torch.cuda.current_stream())
+                streams.enter_context(torch.cuda.stream(side))
             OVERLAP.hold(side, dz1, dz2, vecp, z1, *bases)
-            side_ctx = torch.cuda.stream(side)
-        else:
-            side_ctx = contextlib.nullcontext()
+        side_ctx = streams
 
         def wgrad(A, m, src_list, n, flags):
             q = L.Wgrad()
@@ -520,19 +572,21 @@ class FusedMLPFunction(torch.autograd.Function):
             return partials
 
         src_list = []
-        for k in range(nsrc):
+        for k in range(1 if pre else nsrc):   # factorised: W1 has columns for source 0 only (the node-level products own the rest)
             b_, bstride = ctx.binfo[k]
             src_list.append((bases[k], bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k]))
+        kin1 = widths[0] if pre else kin
         results = [None] * 6   # dW1, db1, dW2, db2, dgamma, dbeta
         with side_ctx:
-            part1 = wgrad(dz1, hid, src_list, kin, 0) if ctx.needs_input_grad[1] else None
+            part1 = wgrad(dz1, hid, src_list, kin1, 0) if ctx.needs_input_grad[1] else None
             part2 = wgrad(dz2, dout, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if ctx.needs_input_grad[3] else None
 
             # ---- one launch reduces every partial sum; with DIRECT_PARAM_GRADS it accumulates into .grad ----
             jobs = L.ReduceJobs()
             keep = []
 
-            def add_job(slot, partials_ptr, nparts, stride, shape, param):
+            def add_job(slot, partials_ptr, nparts, stride, shape, param, ncols=0):
+                """``ncols`` > 0: the partials are the leading (shape[0], ncols) column block of the (shape) matrix."""
                 n = 1
                 for d_ in shape:
                     n *= d_
@@ -540,16 +594,17 @@ class FusedMLPFunction(torch.autograd.Function):
                 if direct:
                     out = param.grad
                 else:
-                    out = torch.empty(shape, device=dev, dtype=torch.float32)
+                    out = (torch.zeros if ncols else torch.empty)(shape, device=dev, dtype=torch.float32)
                     results[slot] = out
                 keep.append(out)
                 j = jobs.job[jobs.njobs]
-                j.partials, j.out, j.stride, j.nparts, j.n, j.accumulate = partials_ptr, _ptr(out), stride, nparts, n, 1 if direct else 0
+                j.partials, j.out, j.stride, j.nparts, j.accumulate = partials_ptr, _ptr(out), stride, nparts, 1 if direct else 0
+                j.n, j.ncols, j.ld = (shape[0] * ncols, ncols, shape[1]) if ncols else (n, 0, 0)
                 jobs.njobs += 1
 
             vbase = vecp.data_ptr()
             if part1 is not None:
-                add_job(0, _ptr(part1), part1.shape[0], hid * kin, (hid, kin), prm[0])
+                add_job(0, _ptr(part1), part1.shape[0], hid * kin1, (hid, kin), prm[0], ncols=kin1 if pre else 0)
             if ctx.needs_input_grad[2]:
                 add_job(1, vbase + 0 * vs * 4, nblk, 4 * vs, (hid,), prm[1])
             if part2 is not None:
@@ -582,6 +637,107 @@ class FusedMLPFunction(torch.autograd.Function):
                 g = g.reshape(shape)
             grads_src.append(g)
         return (None, dW1, db1, dW2, db2, dg, dbt, *grads_src)
+
+
+def _linear_launch(x2d, W, ldn, ldk, k, n, out=None, accumulate=False, mm_flags=None):
+    """out (rows, n) (+)= x2d (rows, k) . A^T with A[h][c] = W[h * ldn + c * ldk] (nlam_linear)."""
+    lib = L.load()
+    rows = x2d.shape[0]
+    if out is None:
+        out = torch.empty((rows, n), device=x2d.device, dtype=torch.float32)
+    q = L.Linear()
+    q.x, q.W, q.out, q.rows, q.ldn, q.ldk, q.k, q.n = _ptr(x2d), W, _ptr(out), rows, ldn, ldk, k, n
+    q.accumulate, q.flags = 1 if accumulate else 0, mm_flags if mm_flags is not None else _mm_flags()
+    key = ("linear", rows, k, n)
+    L.check(PROFILE.launch(key, lambda: lib.nlam_linear(C.byref(q), _stream()),
+                           lambda: {"flops": 2.0 * rows * k * n, "bytes": 4.0 * rows * (k + n), "mm": _MM_NAMES[(q.flags >> 8) & 3],
+                                    "mfmas_per_block": ((q.flags >> 8) & 3) * (((q.flags >> 8) & 3) + 1) // 2,
+                                    "what": "node-level product of the factorised edge MLP"}), "nlam_linear")
+    return out
+
+
+class NodeLinearFunction(torch.autograd.Function):
+    """``x @ W1[:, col0 : col0 + k].T`` per NODE: one of the two node-level products of the factorised edge MLP
+    (``edge_mlp(cat(e, x_j, x_i))`` of gnn_layers.py:168-172 with the first Linear split by column blocks).
+
+    forward(x (..., N, k), W1 (hid, kin), col0) -> (..., N, hid).  A batch that is a stride-0 expansion is computed
+    once.  Backward: dx = g @ W1[:, col0 : col0 + k] (nlam_linear, transposed strides), dW1[:, col0 : col0 + k] = g^T x
+    (nlam_wgrad + nlam_reduce_jobs with a strided destination, on a weight-gradient side stream under the trainer)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, col0: int):
+        _require_gpu(x, W1)
+        xb, B, bstride, lead = as_batched(x)
+        N, k = xb.shape[-2], xb.shape[-1]
+        hid, kin = W1.shape
+        shared = bstride == 0 and B > 1
+        x2d = xb.reshape(-1, k)
+        W1c = W1.contiguous()
+        mm = _mm_flags()
+        out = _linear_launch(x2d, W1c.data_ptr() + 4 * col0, kin, 1, k, hid, mm_flags=mm)
+        ctx.save_for_backward(x2d, W1c)
+        ctx.meta = (col0, tuple(x.shape), B, N, shared, mm)
+        ctx.param_ref = W1
+        if GRAD_LISTENER is not None and W1.requires_grad:
+            GRAD_LISTENER.note_use([W1])   # W1 collects gradient from the edge kernel AND from both node-level products
+        ctx.set_materialize_grads(False)
+        out = out.reshape(N, hid).expand(*lead, N, hid) if shared else out.reshape(*lead, N, hid)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        lib = L.load()
+        x2d, W1 = ctx.saved_tensors
+        col0, xshape, B, N, shared, mm = ctx.meta
+        hid, kin = W1.shape
+        k = x2d.shape[1]
+        dev = g.device
+        g2d = g.reshape(B, N, hid).sum(0) if shared else g.reshape(-1, hid)
+        g2d = g2d.contiguous()
+        rows = g2d.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _linear_launch(g2d, W1.data_ptr() + 4 * col0, 1, kin, hid, k, mm_flags=mm)
+            dx = dx.reshape(N, k).expand(xshape) if shared else dx.reshape(xshape)
+        dW = None
+        if ctx.needs_input_grad[1]:
+            prm = ctx.param_ref
+            direct = (DIRECT_PARAM_GRADS and prm.grad is not None and prm.grad.is_contiguous()
+                      and tuple(prm.grad.shape) == (hid, kin) and prm.grad.dtype == torch.float32)
+            on_side = OVERLAP.active and direct
+            streams = contextlib.ExitStack()
+            if on_side:
+                side = OVERLAP.stream_for(prm)
+                side.wait_stream(torch.cuda.current_stream())
+                OVERLAP.hold(side, g2d, x2d)
+                streams.enter_context(torch.cuda.stream(side))
+            with streams:
+                q = L.Wgrad()
+                q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(g2d), hid, 1, rows, 1, mm, k
+                _fill_src(q.src[0], x2d, 0, k, None)
+                nparts = lib.nlam_wgrad_nparts(C.byref(q))
+                partials = torch.empty((nparts, hid, k), device=dev, dtype=torch.float32)
+                q.partials, q.nparts = _ptr(partials), nparts
+                key = ("wgrad", rows, hid, k)
+                L.check(PROFILE.launch(key, lambda: lib.nlam_wgrad(C.byref(q), _stream()),
+                                       lambda: {"flops": 2.0 * rows * hid * k, "bytes": 4.0 * (rows * (hid + k) + nparts * hid * k),
+                                                "mm": "f32", "mfmas_per_block": 0, "what": "node-level weight gradient of the factorised edge MLP"}),
+                        "nlam_wgrad")
+                out = prm.grad if direct else torch.zeros((hid, kin), device=dev, dtype=torch.float32)
+                jobs = L.ReduceJobs()
+                j = jobs.job[0]
+                j.partials, j.out, j.stride, j.nparts, j.accumulate = _ptr(partials), out.data_ptr() + 4 * col0, hid * k, nparts, 1 if direct else 0
+                j.n, j.ncols, j.ld = hid * k, k, kin
+                jobs.njobs = 1
+                L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
+                if on_side:
+                    OVERLAP.hold(side, partials)
+                if GRAD_LISTENER is not None and direct:
+                    GRAD_LISTENER.note_done([prm])
+            dW = None if direct else out
+        return dx, dW, None
 
 
 class WmseLossFunction(torch.autograd.Function):

@@ -46,7 +46,7 @@ class FlatParams:
         off = 0
         for i in self.order:
             self.offsets[i] = off
-            off += self.params[i].numel()
+            off += (self.params[i].numel() + 3) // 4 * 4   # every view starts on a 16-byte boundary (vector loads / stores)
         self.numel = off
         self.flat = torch.zeros(off, device=dev, dtype=dt)
         self.grad = torch.zeros(off, device=dev, dtype=dt)
@@ -167,10 +167,15 @@ class Trainer:
 
     def __init__(self, module: nn.Module, lr=1e-3, betas=(0.9, 0.95), weight_decay=1e-2, eps=1e-8,
                  bucket_bytes: int = 32 << 20, optimizer_factory=None, group=None, use_graph: bool = False,
-                 overlap_wgrad: bool = True):
+                 overlap_wgrad: bool = True, early_leaf_backward: bool | None = None):
         self.module = module
         self.use_graph = use_graph
         self.overlap_wgrad = overlap_wgrad
+        if early_leaf_backward is None:
+            import os
+
+            early_leaf_backward = os.environ.get("NLAM_EARLY_LEAF", "0") == "1"
+        self.early_leaf_backward = early_leaf_backward
         self._graph = None
         self._static_in = None
         self._static_sig = None
@@ -221,7 +226,7 @@ class Trainer:
             loss.backward()
             return loss.detach()
         self._main_stream = torch.cuda.current_stream()
-        with ops.direct_param_grads(self.buckets):
+        with ops.direct_param_grads(self.buckets, early_leaf=self.early_leaf_backward):
             out = self.module(*batch)
             loss = out[-1] if isinstance(out, tuple) else out
             ov = ops.OVERLAP if self.overlap_wgrad else None

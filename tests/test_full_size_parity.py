@@ -178,7 +178,8 @@ def test_cfg2_hip_graph_trainer_step_matches_oracle_adamw(dev):
     o_sd = o_fc.state_dict()
     for k, v in h_fc.state_dict().items():
         # three Adam steps of lr 1e-3 move a weight by <= 3e-3; compare the weights themselves
-        assert float((v.cpu() - o_sd[k]).abs().max()) < 2e-4, k
+        if v.numel():   # the (empty) clamping buffers are part of the state dict too
+            assert float((v.cpu() - o_sd[k]).abs().max()) < 2e-4, k
 
 
 def test_standardize_matches_reference_formula(dev, tmp_path):

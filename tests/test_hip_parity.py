@@ -46,6 +46,19 @@ def wide_family(request):
     assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
 
 
+@pytest.fixture(params=["auto", "factorised"])
+def factorise(request):
+    """"factorised" forces the factorised edge MLP (node-level products + gathered pre-activation addends, normally
+    used from 65 536 edges up) at test sizes; it applies to InteractionNet layers with 32- / 64-wide features."""
+    from neural_lam_amd import gnn_layers as hl
+
+    old = hl.FACTORISE_MIN_EDGES
+    if request.param == "factorised":
+        hl.FACTORISE_MIN_EDGES = 0
+    yield request.param
+    hl.FACTORISE_MIN_EDGES = old
+
+
 LAYER_CASES = [
     "inet_sum_update_d8", "inet_mean_noupdate_b2_d8", "propnet_b2_d8", "propnet_noupdate_d16",
     "inet_chunked_d8", "inet_100to10_gap_d16", "inet_sum_update_b2_d64", "inet_highdeg_d32", "inet_hidden12_d8",
@@ -54,9 +67,11 @@ LAYER_CASES = [
 
 
 @pytest.mark.parametrize("name", LAYER_CASES)
-def test_layer_matches_reference_golden(dev, golden_layers, name, wide_family):
+def test_layer_matches_reference_golden(dev, golden_layers, name, wide_family, factorise):
     hl = _hl()
     case = golden_layers[name]
+    if factorise == "factorised" and (case["d"] not in (32, 64) or wide_family == "wbf"):
+        pytest.skip("the factorised edge MLP covers 32- / 64-wide layers")
     net = hl.get_gnn_class(case["cls"])(case["edge_index"].to(torch.int64), case["d"], **case["kwargs"])
     net.load_state_dict(case["state_dict"], strict=True)
     net.to(dev)
@@ -144,7 +159,7 @@ def _rand_ei(ns, nr, e, seed):
 @pytest.mark.parametrize("cls_name", ["InteractionNet", "PropagationNet"])
 @pytest.mark.parametrize("d", [4, 16, 24, 64])
 @pytest.mark.parametrize("update_edges", [True, False])
-def test_layer_matches_oracle(dev, cls_name, d, update_edges):
+def test_layer_matches_oracle(dev, cls_name, d, update_edges, factorise):
     from oracle import gnn_layers as og
 
     hl = _hl()
@@ -758,6 +773,29 @@ def test_graph_step_falls_back_to_eager_for_another_batch_shape(dev, tmp_path):
     assert tg._graph is not None and tg.use_graph
     assert len({float(x) for x in losses}) == 4 and losses[0].data_ptr() != losses[1].data_ptr()
     assert torch.equal(tg.fp.flat, te.fp.flat)
+
+
+@pytest.mark.parametrize("k,n,rows,batched", [(64, 64, 6561, False), (32, 64, 100, True), (64, 32, 33, False), (32, 32, 1, False)])
+def test_node_linear_matches_torch(dev, k, n, rows, batched):
+    """nlam_linear through NodeLinearFunction: x @ W1[:, col0:col0+k].T, its data gradient and the strided weight
+    gradient (only the addressed column block of W1.grad is written)."""
+    from neural_lam_amd.ops import NodeLinearFunction
+
+    torch.manual_seed(3)
+    kin, col0 = 3 * k, k
+    W = torch.randn(n, kin, device=dev, requires_grad=True)
+    shape = (2, rows, k) if batched else (rows, k)
+    x = torch.randn(*shape, device=dev, requires_grad=True)
+    out = NodeLinearFunction.apply(x, W, col0)
+    cot = torch.randn_like(out)
+    (out * cot).sum().backward()
+    xr, Wr = x.detach().double().requires_grad_(), W.detach().double().requires_grad_()
+    ref = xr @ Wr[:, col0 : col0 + k].T
+    (ref * cot.double()).sum().backward()
+    assert rel_err(out.double().cpu(), ref.cpu()) < 1e-5
+    assert rel_err(x.grad.double().cpu(), xr.grad.cpu()) < 1e-5
+    assert rel_err(W.grad.double().cpu(), Wr.grad.cpu()) < 1e-5
+    assert float(W.grad[:, :col0].abs().max()) == 0.0 and float(W.grad[:, col0 + k :].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("hidden_layers", [0, 2, 3])

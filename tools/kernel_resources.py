@@ -25,13 +25,13 @@ def main():
         if t.startswith("Function Name:"):
             name = t.split(":", 1)[1].strip()
             name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
-            cur = {"name": name.replace("(anonymous namespace)::", "").split("(")[0][:44]}
+            cur = {"name": name.replace("(anonymous namespace)::", "").split("(")[0][:58]}
             rows.append(cur)
         elif cur is not None and ":" in t:
             k, v = t.split(":", 1)
             cur[k.strip()] = v.strip()
     for r in rows:
-        print("{:44s} VGPR {:>4s} AGPR {:>4s} SGPR {:>4s} scratch {:>5s} occ {:>2s}".format(
+        print("{:58s} VGPR {:>4s} AGPR {:>4s} SGPR {:>4s} scratch {:>5s} occ {:>2s}".format(
             r["name"], r.get("VGPRs", "?"), r.get("AGPRs", "?"), r.get("TotalSGPRs", "?"),
             r.get("ScratchSize [bytes/lane]", "?"), r.get("Occupancy [waves/SIMD]", "?")))
     return out.returncode
