@@ -25,7 +25,7 @@ from .graph import EdgeCSR, build_edge_csr, build_tile_schedule
 import os
 
 from . import ops
-from .ops import FusedMLPFunction, MlpGeometry, NodeLinearFunction, as_batched, segment_sum
+from .ops import ChunkedGeometry, ChunkedMLPFunction, FusedMLPFunction, MlpGeometry, NodeLinearFunction, as_batched, segment_sum
 
 # Edge sets with at least this many edges (per batch item) run the FACTORISED edge MLP:
 #   W1 [e | x_j | x_i] = W1_e e + (W1_j x)[sender] + (W1_i x)[receiver]
@@ -126,7 +126,28 @@ class SplitMLPs(nn.Module):
         self.mlps = nn.ModuleList(mlps)
         self.chunk_sizes = chunk_sizes
 
+    @property
+    def fully_fused(self) -> bool:
+        """Every chunk is a one-kernel MLP of the same shape: the chunked native path (ops.ChunkedMLPFunction) applies."""
+        first = self.mlps[0]
+        return all(isinstance(m, FusedMLP) and m.fully_fused and m.has_layer_norm == first.has_layer_norm
+                   and m[0].weight.shape == first[0].weight.shape and m[2].weight.shape == first[2].weight.shape for m in self.mlps)
+
+    def flat_params(self):
+        return [q for m in self.mlps for q in m.params()]
+
     def forward(self, x):
+        if x.is_cuda and self.fully_fused and sum(self.chunk_sizes) == x.shape[-2]:
+            # one launch per chunk on its row window of x, written into one output buffer: no split / cat copies
+            key = ("plain", str(x.device))
+            if getattr(self, "_geom", None) is None or self._geom[0] != key:
+                bounds, r = [], 0
+                for n in self.chunk_sizes:
+                    bounds.append((r, r + n))
+                    r += n
+                self._geom = (key, ChunkedGeometry(nsrc=1, chunks=bounds, rows=r, src_mode=["slice"], src_idx=[None]))
+            out, _ = ChunkedMLPFunction.apply(self._geom[1], len(self.mlps), *self.flat_params(), x)
+            return out
         chunks = torch.split(x, self.chunk_sizes, dim=-2)
         return torch.cat([mlp(c.contiguous()) for mlp, c in zip(self.mlps, chunks)], dim=-2)
 
@@ -192,6 +213,11 @@ class InteractionNet(nn.Module):
         self.update_edges = update_edges
         self._csr_cache: dict = {}
         self._geom_cache: dict = {}
+        # receiver-sorted CSR / sender-sorted CSC views and the wave-tile schedule: built here, once, on the host (the
+        # first forward only copies them to the device; a sender tensor with more rows than the largest sender index
+        # + 1 -- legal, gnn_layers.py:73 only fixes num_rec -- gets its own CSC built on demand)
+        self._num_send_default = int(self._edge_index_local[0].max()) + 1
+        self._host_csr = self._build_host_csr(self._num_send_default)
 
     # reference hook points kept for API parity (gnn_layers.py:159-166, 231-239)
     propagates_sender = False  # message() adds x_j               (PropagationNet)
@@ -204,16 +230,19 @@ class InteractionNet(nn.Module):
     def _csr(self, device, num_send: int) -> EdgeCSR:
         key = (str(device), num_send)
         if key not in self._csr_cache:
-            n_rec = int(self.num_rec)
             if num_send <= int(self._edge_index_local[0].max()):
                 raise RuntimeError("send_rep has fewer rows than the largest sender index in edge_index")
-            csr = build_edge_csr(self._edge_index_local, num_send=num_send, num_rec=n_rec)
-            tiles, has_split = build_tile_schedule(csr.rowptr)
-            csr = csr.to(device)
+            host, tiles, has_split = self._host_csr if num_send == self._num_send_default else self._build_host_csr(num_send)
+            csr = host.to(device)
             csr.tiles = tiles.to(device)
             csr.has_split = has_split
             self._csr_cache[key] = csr
         return self._csr_cache[key]
+
+    def _build_host_csr(self, num_send: int):
+        csr = build_edge_csr(self._edge_index_local, num_send=num_send, num_rec=int(self.num_rec))
+        tiles, has_split = build_tile_schedule(csr.rowptr)
+        return csr, tiles, has_split
 
     def _edge_geom(self, csr: EdgeCSR, want_out: bool, add_edge: bool, key, pre: bool = False) -> MlpGeometry:
         gkey = (key, want_out, add_edge, pre)
@@ -264,6 +293,8 @@ class InteractionNet(nn.Module):
         """-> (aggr, edge_out | None); edge_out = msg (+ edge_rep if add_edge), original edge order."""
         self._check_inputs(send_rep, rec_rep, edge_rep)
         csr = self._csr(send_rep.device, send_rep.shape[-2])
+        if isinstance(self.edge_mlp, SplitMLPs) and self.edge_mlp.fully_fused:
+            return self._messages_chunked(csr, send_rep, rec_rep, edge_rep, want_out, add_edge)
         if isinstance(self.edge_mlp, SplitMLPs) or not self.edge_mlp.fully_fused:
             return self._messages_generic(csr, send_rep, rec_rep, edge_rep, want_out, add_edge)
         key = (str(send_rep.device), send_rep.shape[-2])
@@ -291,6 +322,41 @@ class InteractionNet(nn.Module):
         ok = lambda w: w in (32, 64)  # noqa: E731
         return ok(d) and ok(hid) and hid == dout and send_rep.shape[-1] == d and rec_rep.shape[-1] == d
 
+    def _chunk_bounds(self, sizes):
+        bounds, r = [], 0
+        for n in sizes:
+            bounds.append((r, r + n))
+            r += n
+        return bounds, r
+
+    def _messages_chunked(self, csr, send_rep, rec_rep, edge_rep, want_out, add_edge):
+        """Chunked edge MLPs (HiLAMParallel, hi_lam_parallel.py:127-143) natively: per chunk one fused gather + MLP
+        launch on its window of the edge rows, one CSR segment sum for the aggregation; deterministic backward
+        (ops.ChunkedMLPFunction).  Rows stay in the original edge order."""
+        gkey = ("chunked_edge", str(send_rep.device), send_rep.shape[-2])
+        if gkey not in self._geom_cache:
+            dev = send_rep.device
+            ei = self._edge_index_local
+            bounds, total = self._chunk_bounds(self.edge_mlp.chunk_sizes)
+            assert total == ei.shape[1], "edge_chunk_sizes must add up to the number of edges"
+            send_i, rec_i = ei[0].to(torch.int32).contiguous().to(dev), ei[1].to(torch.int32).contiguous().to(dev)
+            order_send = torch.argsort(ei[0], stable=True).to(torch.int32).contiguous().to(dev)   # CSC position -> edge id
+            flags = (L.F_ADD_SRC1 if self.propagates_sender else 0) | (L.F_MEAN if self.aggr == "mean" else 0)
+            self._geom_cache[gkey] = ChunkedGeometry(
+                nsrc=3, chunks=bounds, rows=total, src_mode=["slice", "gather", "gather"], src_idx=[None, send_i, rec_i],
+                flags_fwd=flags, flags_bwd=flags,   # the edge residual (edge_rep + messages) is added outside: the aggregate needs the bare messages
+                rowptr=csr.rowptr, perm=csr.perm, inv_deg=csr.inv_deg, seg_of_row=rec_i, num_rec=csr.num_rec, mean=self.aggr == "mean",
+                scatter=[None, (csr.colptr, order_send, csr.num_send), (csr.rowptr, csr.perm, csr.num_rec)],
+            )
+        geom = self._geom_cache[gkey]
+        lead = max((t.shape[:-2] for t in (send_rep, rec_rep, edge_rep)), key=len)
+        edge_b = edge_rep.expand(*lead, -1, -1) if edge_rep.shape[:-2] != lead else edge_rep
+        msgs, aggr = ChunkedMLPFunction.apply(geom, len(self.edge_mlp.mlps), *self.edge_mlp.flat_params(), edge_b, send_rep, rec_rep)
+        edge_out = None
+        if want_out:
+            edge_out = edge_rep + msgs if add_edge else msgs
+        return aggr, edge_out
+
     def _messages_generic(self, csr, send_rep, rec_rep, edge_rep, want_out, add_edge):
         # chunked edge MLPs (HiLAMParallel): per-chunk fused MLP kernels over an explicit
         # gathered concat; aggregation by the CSR segment-sum kernel.
@@ -312,6 +378,20 @@ class InteractionNet(nn.Module):
         return aggr, edge_out
 
     def _node_update(self, rec_rep, aggr):
+        if isinstance(self.aggr_mlp, SplitMLPs) and self.aggr_mlp.fully_fused and rec_rep.is_cuda:
+            # chunked node MLPs: per chunk one fused launch [rec | aggr] -> MLP -> LayerNorm -> + residual on its window of the nodes
+            gkey = ("chunked_node", str(rec_rep.device))
+            if gkey not in self._geom_cache:
+                bounds, total = self._chunk_bounds(self.aggr_mlp.chunk_sizes)
+                flags = L.F_ADD_SRC1 if self.residual_on_aggregate else L.F_ADD_SRC0
+                self._geom_cache[gkey] = ChunkedGeometry(nsrc=2, chunks=bounds, rows=total, src_mode=["slice", "slice"], src_idx=[None, None],
+                                                         flags_fwd=flags, flags_bwd=flags)
+            geom = self._geom_cache[gkey]
+            if geom.rows == rec_rep.shape[-2]:
+                lead = max((rec_rep.shape[:-2], aggr.shape[:-2]), key=len)
+                rec_b = rec_rep.expand(*lead, -1, -1) if rec_rep.shape[:-2] != lead else rec_rep
+                out, _ = ChunkedMLPFunction.apply(geom, len(self.aggr_mlp.mlps), *self.aggr_mlp.flat_params(), rec_b, aggr)
+                return out
         if isinstance(self.aggr_mlp, SplitMLPs) or not self.aggr_mlp.fully_fused:
             rec_diff = self.aggr_mlp(torch.cat((rec_rep, aggr), dim=-1))
             return self.node_residual_target(rec_rep, aggr) + rec_diff

@@ -639,6 +639,303 @@ class FusedMLPFunction(torch.autograd.Function):
         return (None, dW1, db1, dW2, db2, dg, dbt, *grads_src)
 
 
+@dataclass
+class ChunkedGeometry:
+    """Static description of a CHUNKED fused-MLP call site (``SplitMLPs``, gnn_layers.py:274-324: rows [r0, r1) of the
+    input go through the chunk's own MLP).  Rows are in their original order; per source either the chunk's rows are
+    a slice of the source tensor ("slice") or are gathered through an index ("gather")."""
+
+    nsrc: int
+    chunks: list                      # [(r0, r1), ...] covering 0 .. rows
+    rows: int
+    src_mode: list                    # "slice" | "gather" per source
+    src_idx: list                     # gather: int32 (rows,) device tensor of source rows; slice: None
+    flags_fwd: int = 0
+    flags_bwd: int = 0
+    # optional aggregation of the output rows onto receivers (CSR over all rows)
+    rowptr: torch.Tensor | None = None
+    perm: torch.Tensor | None = None
+    inv_deg: torch.Tensor | None = None
+    seg_of_row: torch.Tensor | None = None
+    num_rec: int = 0
+    mean: bool = False
+    # per gathered source: (ptr, order, nseg) of the segment sum that turns per-row gradients into per-source-row ones
+    scatter: list = field(default_factory=lambda: [None, None, None])
+
+
+def _row_window(x: torch.Tensor):
+    """(..., N, w) -> (tensor to keep alive, B, batch stride in floats): no copy for contiguous tensors and stride-0 batches."""
+    t, B, bstride, _ = as_batched(x)
+    return t, B, bstride
+
+
+class ChunkedMLPFunction(torch.autograd.Function):
+    """``SplitMLPs`` (gnn_layers.py:274-324) inside an InteractionNet, natively: every chunk is one launch of the fused
+    kernels on its row window of shared input / output buffers (no torch.split / cat copies, no index_select), the
+    aggregation is one CSR segment sum, and in backward the gradients of gathered sources are finished by one
+    segment sum per source over all chunks -- fixed summation orders throughout (the reference trains with
+    ``deterministic=True``, train_model.py:566).
+
+    forward(geom, nchunks, [W1, b1, W2, b2, ln_w, ln_b] * nchunks, *sources) -> (out (B, rows, dout), aggr | None)
+    """
+
+    @staticmethod
+    def forward(ctx, geom: ChunkedGeometry, nchunks: int, *flat):
+        lib = L.load()
+        params = [flat[6 * c : 6 * c + 6] for c in range(nchunks)]
+        srcs = flat[6 * nchunks :]
+        assert len(srcs) == geom.nsrc and len(geom.chunks) == nchunks
+        mm_flags = _mm_flags()
+        srcs = tuple(s if s.dtype == torch.float32 else s.float() for s in srcs)
+        _require_gpu(*[q for pr in params for q in pr], *srcs)
+        win = [_row_window(s) for s in srcs]
+        B = max(w[1] for w in win)
+        widths = [s.shape[-1] for s in srcs]
+        nrows_src = [s.shape[-2] for s in srcs]
+        hid, kin = params[0][0].shape
+        dout = params[0][2].shape[0]
+        if sum(widths) != kin:
+            raise RuntimeError(f"source widths {widths} do not add up to the first Linear's in_features {kin}")
+        dev = srcs[0].device
+        R = geom.rows
+        need_grad = any(ctx.needs_input_grad[2:])
+        has_ln = params[0][4] is not None
+        out = torch.empty((B, R, dout), device=dev, dtype=torch.float32)
+        saved = []
+        keep = []
+        for c, (r0, r1) in enumerate(geom.chunks):
+            W1, b1, W2, b2, ln_w, ln_b = params[c]
+            rows = r1 - r0
+            if rows == 0:
+                saved.append((None, None, None))
+                continue
+            p = L.MlpFwd()
+            for k in range(geom.nsrc):
+                t, b_, bstride = win[k]
+                bs = bstride if (b_ == B or B == 1) else 0
+                if geom.src_mode[k] == "slice":
+                    _fill_src(p.src[k], None, bs, widths[k], None)
+                    p.src[k].ptr = t.data_ptr() + 4 * r0 * widths[k]
+                else:
+                    _fill_src(p.src[k], t, bs, widths[k], None)
+                    p.src[k].idx = geom.src_idx[k].data_ptr() + 4 * r0
+            p.nsrc, p.batch, p.rows, p.ntiles = geom.nsrc, B, rows, (rows + 31) // 32
+            W1c, b1c, W2c, b2c = W1.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous()
+            keep.extend((W1c, b1c, W2c, b2c))
+            p.W1, p.b1, p.W2, p.b2, p.ln_w, p.ln_b = _ptr(W1c), _ptr(b1c), _ptr(W2c), _ptr(b2c), _ptr(ln_w), _ptr(ln_b)
+            p.eps, p.hid, p.dout, p.flags = 1e-5, hid, dout, geom.flags_fwd | mm_flags
+            p.out, p.out_bstride = out.data_ptr() + 4 * r0 * dout, R * dout
+            z1 = xhat = rstd = None
+            if need_grad:
+                z1 = torch.empty((B, rows, hid), device=dev, dtype=torch.float32)
+                p.z1 = _ptr(z1)
+                if has_ln:
+                    xhat = torch.empty((B, rows, dout), device=dev, dtype=torch.float32)
+                    rstd = torch.empty((B, rows), device=dev, dtype=torch.float32)
+                    p.xhat, p.rstd = _ptr(xhat), _ptr(rstd)
+            nwp = lib.nlam_mlp_fwd_wpack_floats(C.byref(p))
+            if nwp > 0:
+                wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+                p.wpack, p.wpack_floats = _ptr(wpack), nwp
+            L.check(lib.nlam_mlp_fwd(C.byref(p), _stream()), "nlam_mlp_fwd (chunk)")
+            saved.append((z1, xhat, rstd))
+        aggr = None
+        if geom.rowptr is not None:
+            aggr = segment_sum(out, R * dout, geom.rowptr, geom.perm, geom.inv_deg if geom.mean else None, geom.num_rec, dout, B)
+        if need_grad:
+            ctx.geom, ctx.B, ctx.nchunks, ctx.mm_flags, ctx.has_ln = geom, B, nchunks, mm_flags, has_ln
+            ctx.win_meta = [(w[1], w[2]) for w in win]
+            ctx.src_shapes = [tuple(s.shape) for s in srcs]
+            ctx.params = params
+            ctx.saved_acts = saved
+            ctx.bases = [w[0] for w in win]
+            ctx.set_materialize_grads(False)
+            if GRAD_LISTENER is not None:
+                GRAD_LISTENER.note_use([q for pr in params for q in pr if q is not None and q.requires_grad])
+        lead = max((tuple(s.shape[:-2]) for s in srcs), key=len)
+        if len(lead) != 1:
+            out = out.reshape(*lead, R, dout)
+            aggr = aggr.reshape(*lead, geom.num_rec, dout) if aggr is not None else None
+        return out, aggr
+
+    @staticmethod
+    def backward(ctx, g_out, g_aggr):
+        lib = L.load()
+        geom: ChunkedGeometry = ctx.geom
+        B, nchunks = ctx.B, ctx.nchunks
+        nsrc = geom.nsrc
+        n_fixed = 2 + 6 * nchunks
+        if g_out is None and g_aggr is None:
+            return (None,) * (n_fixed + nsrc)
+        params = ctx.params
+        hid, kin = params[0][0].shape
+        dout = params[0][2].shape[0]
+        widths = [s[-1] for s in ctx.src_shapes]
+        nrows_src = [s[-2] for s in ctx.src_shapes]
+        dev = params[0][0].device
+        R = geom.rows
+        if g_out is not None:
+            g_out = g_out.reshape(B, R, dout).contiguous()
+        if g_aggr is not None:
+            g_aggr = g_aggr.reshape(B, geom.num_rec, dout).contiguous()
+        need_src = [ctx.needs_input_grad[n_fixed + k] for k in range(nsrc)]
+        # gradient buffers: sliced sources get their rows written in place; gathered ones a (B, R, w) row-order buffer
+        dbuf = [None] * nsrc
+        for k in range(nsrc):
+            if need_src[k]:
+                nr = nrows_src[k] if geom.src_mode[k] == "slice" else R
+                dbuf[k] = torch.empty((B, nr, widths[k]), device=dev, dtype=torch.float32)
+        tmp_chunks = [[] for _ in range(nsrc)]   # B > 1: per-chunk (B, rows_c, w) buffers of gathered sources
+        grads_params = []
+        for c, (r0, r1) in enumerate(geom.chunks):
+            W1, b1, W2, b2, ln_w, ln_b = params[c]
+            rows = r1 - r0
+            needs = [ctx.needs_input_grad[2 + 6 * c + q] for q in range(6)]
+            if rows == 0:
+                grads_params.extend([torch.zeros_like(q) if (q is not None and nd) else None for q, nd in zip(params[c], needs)])
+                continue
+            z1, xhat, rstd = ctx.saved_acts[c]
+            W1c, W2c = W1.contiguous(), W2.contiguous()
+            p = L.MlpBwd()
+            for k in range(nsrc):
+                b_, bstride = ctx.win_meta[k]
+                bs = bstride if (b_ == B or B == 1) else 0
+                t = ctx.bases[k]
+                if geom.src_mode[k] == "slice":
+                    _fill_src(p.src[k], None, bs, widths[k], None)
+                    p.src[k].ptr = t.data_ptr() + 4 * r0 * widths[k]
+                else:
+                    _fill_src(p.src[k], t, bs, widths[k], None)
+                    p.src[k].idx = geom.src_idx[k].data_ptr() + 4 * r0
+            p.nsrc, p.batch, p.rows, p.ntiles = nsrc, B, rows, (rows + 31) // 32
+            p.W1, p.W2, p.ln_w = _ptr(W1c), _ptr(W2c), _ptr(ln_w) if ctx.has_ln else None
+            p.hid, p.dout, p.flags, p.nseg_total = hid, dout, geom.flags_bwd | ctx.mm_flags, geom.num_rec
+            if g_out is not None:
+                p.g_out, p.out_bstride = g_out.data_ptr() + 4 * r0 * dout, R * dout
+            if g_aggr is not None:
+                p.g_aggr, p.seg_of_row = _ptr(g_aggr), geom.seg_of_row.data_ptr() + 4 * r0
+                p.inv_deg = _ptr(geom.inv_deg)
+            p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
+            dz1 = torch.empty((B * rows, hid), device=dev, dtype=torch.float32)
+            dz2 = torch.empty((B * rows, dout), device=dev, dtype=torch.float32)
+            p.dz1, p.dz2 = _ptr(dz1), _ptr(dz2)
+            for k in range(nsrc):
+                if not need_src[k]:
+                    p.dmode[k] = 0
+                elif geom.src_mode[k] == "slice":
+                    p.dmode[k] = 1
+                    p.dsrc[k], p.dsrc_bstride[k] = dbuf[k].data_ptr() + 4 * r0 * widths[k], nrows_src[k] * widths[k]
+                else:
+                    p.dmode[k] = 2
+                    if B == 1:
+                        p.dsrc[k], p.dsrc_bstride[k] = dbuf[k].data_ptr() + 4 * r0 * widths[k], rows * widths[k]
+                    else:
+                        tc = torch.empty((B, rows, widths[k]), device=dev, dtype=torch.float32)
+                        tmp_chunks[k].append(tc)
+                        p.dsrc[k], p.dsrc_bstride[k] = _ptr(tc), rows * widths[k]
+            nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
+            if nwp > 0:
+                wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+                p.wpack, p.wpack_floats = _ptr(wpack), nwp
+            nblk = lib.nlam_mlp_bwd_blocks(C.byref(p))
+            vs = _vec_stride(hid, dout)
+            vecp = torch.empty((nblk, 4, vs), device=dev, dtype=torch.float32)
+            p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(vecp), nblk, vs
+            L.check(lib.nlam_mlp_bwd(C.byref(p), _stream()), "nlam_mlp_bwd (chunk)")
+
+            # ---- weight gradients of this chunk's MLP (deterministic two-stage reduction) ----
+            src_list = []
+            for k in range(nsrc):
+                b_, bstride = ctx.win_meta[k]
+                bs = bstride if (b_ == B or B == 1) else 0
+                t = ctx.bases[k]
+                if geom.src_mode[k] == "slice":
+                    src_list.append((t.data_ptr() + 4 * r0 * widths[k], bs, widths[k], None))
+                else:
+                    src_list.append((t.data_ptr(), bs, widths[k], geom.src_idx[k].data_ptr() + 4 * r0))
+            grads_params.extend(_chunk_weight_grads(lib, B, rows, hid, dout, kin, ctx.mm_flags, dz1, dz2, z1, vecp, nblk, vs,
+                                                    src_list, params[c], needs, ctx.has_ln))
+        # ---- finish the gathered sources: one segment sum over all chunks' rows ----
+        grads_src = []
+        for k in range(nsrc):
+            g = None
+            if need_src[k]:
+                if geom.src_mode[k] == "slice":
+                    g = dbuf[k]
+                else:
+                    rowbuf = dbuf[k] if B == 1 else torch.cat(tmp_chunks[k], dim=1)
+                    ptr, order, nseg = geom.scatter[k]
+                    g = segment_sum(rowbuf, R * widths[k], ptr, order, None, nseg, widths[k], B)
+                shape = ctx.src_shapes[k]
+                lead_numel = 1
+                for s_ in shape[:-2]:
+                    lead_numel *= s_
+                if lead_numel != B:
+                    g = g.sum(0) if B > 1 else g[0]
+                g = g.reshape(shape)
+            grads_src.append(g)
+        return (None, None, *grads_params, *grads_src)
+
+
+def _chunk_weight_grads(lib, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, vecp, nblk, vs, src_list, params, needs, has_ln):
+    """dW1, db1, dW2, db2, dgamma, dbeta of one fused MLP from the saved row gradients: two TN GEMMs (nlam_wgrad) + one
+    reduction launch; with a trainer's direct-gradient mode the sums land in the flat gradient views (returns None)."""
+    dev = dz1.device
+
+    def is_direct(param, shape):
+        return (DIRECT_PARAM_GRADS and param is not None and param.grad is not None and param.grad.is_contiguous()
+                and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32)
+
+    def wgrad(A, m, slist, n, flags):
+        q = L.Wgrad()
+        q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(slist), flags | mm_flags, n
+        for k, (ptr, bstride, w, idx) in enumerate(slist):
+            q.src[k].ptr, q.src[k].idx, q.src[k].bstride, q.src[k].width = ptr, idx, bstride, w
+        nparts = lib.nlam_wgrad_nparts(C.byref(q))
+        partials = torch.empty((nparts, m, n), device=dev, dtype=torch.float32)
+        q.partials, q.nparts = _ptr(partials), nparts
+        L.check(lib.nlam_wgrad(C.byref(q), _stream()), "nlam_wgrad (chunk)")
+        return partials
+
+    part1 = wgrad(dz1, hid, src_list, kin, 0) if needs[0] else None
+    part2 = wgrad(dz2, dout, [(z1.data_ptr(), rows * hid, hid, None)], hid, L.F_SILU_B) if needs[2] else None
+    results = [None] * 6
+    jobs = L.ReduceJobs()
+    keep = []
+
+    def add_job(slot, partials_ptr, nparts, stride, shape, param):
+        n = 1
+        for d_ in shape:
+            n *= d_
+        direct = is_direct(param, shape)
+        out = param.grad if direct else torch.empty(shape, device=dev, dtype=torch.float32)
+        if not direct:
+            results[slot] = out
+        keep.append(out)
+        j = jobs.job[jobs.njobs]
+        j.partials, j.out, j.stride, j.nparts, j.n, j.accumulate = partials_ptr, _ptr(out), stride, nparts, n, 1 if direct else 0
+        jobs.njobs += 1
+
+    vbase = vecp.data_ptr()
+    if part1 is not None:
+        add_job(0, _ptr(part1), part1.shape[0], hid * kin, (hid, kin), params[0])
+    if needs[1]:
+        add_job(1, vbase + 0 * vs * 4, nblk, 4 * vs, (hid,), params[1])
+    if part2 is not None:
+        add_job(2, _ptr(part2), part2.shape[0], dout * hid, (dout, hid), params[2])
+    if needs[3]:
+        add_job(3, vbase + 1 * vs * 4, nblk, 4 * vs, (dout,), params[3])
+    if has_ln and needs[4]:
+        add_job(4, vbase + 2 * vs * 4, nblk, 4 * vs, (dout,), params[4])
+    if has_ln and needs[5]:
+        add_job(5, vbase + 3 * vs * 4, nblk, 4 * vs, (dout,), params[5])
+    if jobs.njobs > 0:
+        L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
+    if GRAD_LISTENER is not None:
+        GRAD_LISTENER.note_done([q for q, nd in zip(params, needs) if nd and q is not None and is_direct(q, q.shape)])
+    return results
+
+
 def _linear_launch(x2d, W, ldn, ldk, k, n, out=None, accumulate=False, mm_flags=None):
     """out (rows, n) (+)= x2d (rows, k) . A^T with A[h][c] = W[h * ldn + c * ldk] (nlam_linear)."""
     lib = L.load()
