@@ -67,8 +67,12 @@ class FlatParams:
 class GradBuckets:
     """Contiguous slices of the flat gradient buffer, all-reduced as they complete."""
 
-    def __init__(self, fp: FlatParams, bucket_bytes: int = 32 << 20, group=None):
+    def __init__(self, fp: FlatParams, bucket_bytes: int = 32 << 20, group=None, comm_dtype=None):
         self.fp, self.group = fp, group
+        # gradient exchange precision: None = the fp32 buffer in place; torch.bfloat16 halves the bytes on the xGMI links
+        # (the "bf16 grads option" of SURVEY.md section 8(f)3): each bucket is cast, summed in bf16 and written back
+        self.comm_dtype = comm_dtype
+        self._comm_tmp = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bounds = []  # (start, end, [param indices])
         cur_start, cur_members, cur_bytes = 0, [], 0
@@ -95,6 +99,30 @@ class GradBuckets:
             for i, p in enumerate(fp.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
+    def _reduce_slice(self, s, e):
+        """Launch the all-reduce of grad[s:e]; in a reduced communication dtype the sum happens on a cast copy that
+        ``finish_step`` writes back."""
+        view = self.fp.grad[s:e]
+        if self.comm_dtype is None or self.comm_dtype == view.dtype:
+            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        low = view.to(self.comm_dtype)
+        self.handles.append(dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._comm_tmp.append((view, low))
+
+    def all_reduce_whole(self):
+        """One collective over the whole flat gradient buffer (the HIP-graph step)."""
+        self._reduce_slice(0, self.fp.numel)
+        self._wait_all()
+
+    def _wait_all(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        for view, low in self._comm_tmp:
+            view.copy_(low)
+        self._comm_tmp = []
+
     def _param_done(self, i):
         if i in self.done:
             return
@@ -105,7 +133,7 @@ class GradBuckets:
             s, e, _ = self.bounds[b]
             self.join_streams()   # the bucket's gradients were written from several streams
             self.launched.append(b)
-            self.handles.append(dist.all_reduce(self.fp.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._reduce_slice(s, e)
 
     def _make_hook(self, i):
         def hook(_param):   # autograd accumulated this parameter's (complete) gradient
@@ -150,11 +178,9 @@ class GradBuckets:
             if left > 0:
                 s, e, _ = self.bounds[b]
                 self.launched.append(b)
-                self.handles.append(dist.all_reduce(self.fp.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._reduce_slice(s, e)
                 self.pending[b] = 0
-        for h in self.handles:
-            h.wait()
-        self.handles = []
+        self._wait_all()
 
 
 class Trainer:
@@ -167,7 +193,7 @@ class Trainer:
 
     def __init__(self, module: nn.Module, lr=1e-3, betas=(0.9, 0.95), weight_decay=1e-2, eps=1e-8,
                  bucket_bytes: int = 32 << 20, optimizer_factory=None, group=None, use_graph: bool = False,
-                 overlap_wgrad: bool = True, early_leaf_backward: bool | None = None):
+                 overlap_wgrad: bool = True, early_leaf_backward: bool | None = None, grad_comm_dtype=None):
         self.module = module
         self.use_graph = use_graph
         self.overlap_wgrad = overlap_wgrad
@@ -181,7 +207,7 @@ class Trainer:
         self._static_sig = None
         self._static_loss = None
         self.fp = FlatParams(module)
-        self.buckets = GradBuckets(self.fp, bucket_bytes, group)
+        self.buckets = GradBuckets(self.fp, bucket_bytes, group, comm_dtype=grad_comm_dtype)
         self.buckets.join_streams = self._join_producers
         self.world = self.buckets.world
         if optimizer_factory is None:
@@ -285,8 +311,8 @@ class Trainer:
                 self.use_graph = True
         torch._foreach_copy_(self._static_in, list(batch))   # one multi-tensor launch instead of one copy per input
         self._graph.replay()
-        if self.world > 1:   # one flat buffer: a single collective (0.86 MB at cfg2, 20.6 MB at cfg3)
-            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM, group=self.buckets.group)
+        if self.world > 1:   # one flat buffer: a single collective (0.86 MB at cfg2, 20.6 MB at cfg3; half of that with bf16 exchange)
+            self.buckets.all_reduce_whole()
         self.opt.step(1.0 / self.world)
         return self._static_loss.clone()   # the static tensor is overwritten by the next replay
 

@@ -6,7 +6,7 @@ Run in the build container only (needs /root/reference):
 
 Every tensor stored under key "ref_*" was computed by the reference's files
 (gnn_layers.py, utils/networks.py, utils/graph.py, create_graph.py,
-models/step_predictors/**, models/forecasters/autoregressive.py, metrics.py)
+models/step_predictors/**, models/forecasters/autoregressive.py, models/latent/*.py, metrics.py)
 imported unmodified through tests/golden/ref_harness.py.  The only non-reference
 code in the loop is the torch_geometric stand-in of ref_harness.py (PyG 2.3.1 is
 not installed and there is no network) and the duck-typed SyntheticDatastore.
@@ -200,8 +200,59 @@ DS_SMALL = dict(nx=30, ny=27, num_state=5, num_forcing=2, num_static=1, boundary
                              "state_diff_std_standardized": [0.5, 0.8, 1.0, 1.2, 0.9]})
 
 
+def latent_case(ref, name, d, latent_dim, m2m_layers, B, seed, output_dist="diagonal", g2m_gnn_type="InteractionNet",
+                m2g_gnn_type="InteractionNet"):
+    """Graph-EFM latent encoder + decoder (reference files models/latent/{base,graph}_{encoder,decoder}.py,
+    imported unmodified) on a small flat graph: distribution parameters, decoder outputs, all gradients."""
+    import importlib
+
+    latent = importlib.import_module("neural_lam.models.latent")
+    xy = G.regular_grid_xy(30, 27)
+    raw = G.create_regular_grid_graph(xy, n_max_levels=None, hierarchical=False)
+    g2m, m2g, m2m = raw["g2m_edge_index"], raw["m2g_edge_index"], raw["m2m_edge_index"][0]
+    n_grid, n_mesh = 30 * 27, int(raw["mesh_features"][0].shape[0])
+    num_state = 5
+    torch.manual_seed(seed)
+    enc = latent.GraphLatentEncoder(latent_dim, g2m, m2m, d, m2m_layers, hidden_layers=1, g2m_gnn_type=g2m_gnn_type,
+                                    output_dist=output_dist)
+    dec = latent.GraphLatentDecoder(g2m, m2m, m2g, d, latent_dim, num_state, m2m_layers, hidden_layers=1,
+                                    g2m_gnn_type=g2m_gnn_type, m2g_gnn_type=m2g_gnn_type, output_std=True)
+    gen = torch.Generator().manual_seed(seed + 1)
+    t = lambda *shape: torch.randn(*shape, generator=gen)  # noqa: E731
+    inputs = {"grid_rep": t(B, n_grid, d), "mesh": t(B, n_mesh, d), "g2m": t(B, g2m.shape[1], d), "m2m": t(B, m2m.shape[1], d),
+              "m2g": t(B, m2g.shape[1], d), "eps": t(B, n_mesh, latent_dim)}
+    leaves = {k: v.clone().requires_grad_() for k, v in inputs.items() if k != "eps"}
+    emb = {k: leaves[k] for k in ("mesh", "g2m", "m2m", "m2g")}
+    dist = enc(leaves["grid_rep"], graph_emb=emb)
+    z = dist.mean + dist.stddev * inputs["eps"]   # reparameterised sample (rsample with a stored noise)
+    mean_delta, pred_std = dec(leaves["grid_rep"], z, emb)
+    cot = {"mean": t(*dist.mean.shape), "std": t(*dist.stddev.shape), "delta": t(*mean_delta.shape), "pstd": t(*pred_std.shape)}
+    loss = (dist.mean * cot["mean"]).sum() + (dist.stddev * cot["std"]).sum() + (mean_delta * cot["delta"]).sum() + (pred_std * cot["pstd"]).sum()
+    loss.backward()
+    case = {
+        "note": NOTE, "d": d, "latent_dim": latent_dim, "m2m_layers": m2m_layers, "num_state": num_state, "output_dist": output_dist,
+        "g2m_gnn_type": g2m_gnn_type, "m2g_gnn_type": m2g_gnn_type,
+        "g2m_edge_index": g2m, "m2m_edge_index": m2m, "m2g_edge_index": m2g,
+        "inputs": inputs, "cotangents": cot,
+        "enc_state_dict": {k: v.clone() for k, v in enc.state_dict().items()},
+        "dec_state_dict": {k: v.clone() for k, v in dec.state_dict().items()},
+        "ref_latent_mean": dist.mean.detach().clone(), "ref_latent_std": dist.stddev.detach().clone(),
+        "ref_mean_delta": mean_delta.detach().clone(), "ref_pred_std": pred_std.detach().clone(),
+        "ref_grad_inputs": {k: v.grad.clone() for k, v in leaves.items()},
+        "ref_grad_enc": {k: p.grad.clone() for k, p in enc.named_parameters()},
+        "ref_grad_dec": {k: p.grad.clone() for k, p in dec.named_parameters()},
+    }
+    torch.save(case, HERE / f"{name}.pt")
+    print(f"  latent case {name}: loss={float(loss):.6f}")
+
+
 def main():
     ref = rh.load_reference()
+    if "--latent-only" in sys.argv:
+        latent_case(ref, "latent_flat_d64", 64, 16, 2, 2, 50)
+        latent_case(ref, "latent_flat_d16_prop", 16, 8, 1, 1, 51, output_dist="isotropic", g2m_gnn_type="PropagationNet",
+                    m2g_gnn_type="PropagationNet")
+        return
     if "--wide-only" in sys.argv:
         make_layers_wide(ref)
         model_case(ref, "graphlam_30x27_d128", "GraphLAM", DS_SMALL, dict(n_max_levels=None, hierarchical=False),
@@ -209,6 +260,9 @@ def main():
         return
     make_layers(ref)
     make_layers_wide(ref)
+    latent_case(ref, "latent_flat_d64", 64, 16, 2, 2, 50)
+    latent_case(ref, "latent_flat_d16_prop", 16, 8, 1, 1, 51, output_dist="isotropic", g2m_gnn_type="PropagationNet",
+                m2g_gnn_type="PropagationNet")
     ds_small = DS_SMALL
     model_case(ref, "graphlam_30x27", "GraphLAM", ds_small, dict(n_max_levels=None, hierarchical=False),
                dict(hidden_dim=16, hidden_layers=1, processor_layers=2), B=2, T=2, seed=42)
