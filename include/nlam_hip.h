@@ -318,6 +318,39 @@ typedef struct {
 } nlam_std_jobs_t;
 int32_t nlam_standardize(const nlam_std_jobs_t* jobs, void* hip_stream);
 
+/* The elementwise tail of ONE autoregressive step in one pass (forward) and one pass (backward):
+ *   new   = prev + delta * dstd[f] + dmean[f]          step_predictors/graph/base.py:331-343 (no clamping configured)
+ *   pred  = bmask[n] * truth + (1 - bmask[n]) * new     forecasters/autoregressive.py:128-131
+ *   loss += scale * row_weight[n] * inv_var[f] * (pred - target)^2    metrics.py:37-137 + module.py:463-510
+ * rows = batch * nodes rows of `width` state variables; dstd / dmean may be NULL (1 / 0).  The forward writes one loss
+ * partial per block (`nparts` blocks; finish with nlam_reduce_partials).  The backward takes the gradient of `pred` that
+ * later AR steps produced (g_pred, NULL for the last step) and the scalar gradient of the loss from device memory:
+ *   G = g_pred + 2 * scale * gloss * row_weight[n] * inv_var[f] * (pred - target)
+ *   d_delta = (1 - bmask[n]) * dstd[f] * G ,   d_prev = (1 - bmask[n]) * G   (either output may be NULL). */
+int32_t nlam_step_tail_fwd(const float* delta, const float* prev, const float* truth, const float* target, const float* dstd,
+                           const float* dmean, const float* bmask, const float* inv_var, const float* row_weight, float scale,
+                           float* pred, float* partials, int32_t nparts, int64_t rows, int32_t nodes, int32_t width,
+                           void* hip_stream);
+int32_t nlam_step_tail_bwd(const float* g_pred, const float* gloss, const float* pred, const float* target, const float* dstd,
+                           const float* bmask, const float* inv_var, const float* row_weight, float scale, float* d_delta,
+                           float* d_prev, int64_t rows, int32_t nodes, int32_t width, void* hip_stream);
+
+/* Row-wise concatenation of up to NLAM_MAX_CAT sources into out (rows, sum of widths): the torch.cat of the grid input
+ * features (prev_state, prev_prev_state, forcing, static features; step_predictors/graph/base.py:275-283).  A source
+ * with bstride 0 is shared by all batch items (expand_to_batch, step_predictors/base.py:122-139). */
+#define NLAM_MAX_CAT 6
+typedef struct {
+    const float* ptr[NLAM_MAX_CAT];
+    int64_t bstride[NLAM_MAX_CAT];   /* floats between batch items of the source; 0 = shared */
+    int32_t width[NLAM_MAX_CAT];
+    int32_t nsrc;
+    int32_t batch;
+    int32_t nodes;                   /* rows per batch item */
+    int32_t _pad;
+    float* out;                      /* (batch, nodes, sum of widths) */
+} nlam_cat_t;
+int32_t nlam_concat(const nlam_cat_t* p, void* hip_stream);
+
 /* decoupled-weight-decay Adam on flat buffers; step_count is the 1-based step */
 int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step_count,

@@ -43,6 +43,9 @@ EXPORTS = [
     "nlam_adamw_step",
     "nlam_standardize",
     "nlam_linear",
+    "nlam_step_tail_fwd",
+    "nlam_step_tail_bwd",
+    "nlam_concat",
 ]
 
 
@@ -178,6 +181,19 @@ class Linear(C.Structure):
     ]
 
 
+class Cat(C.Structure):
+    _fields_ = [
+        ("ptr", C.c_void_p * 6),
+        ("bstride", C.c_int64 * 6),
+        ("width", C.c_int32 * 6),
+        ("nsrc", C.c_int32),
+        ("batch", C.c_int32),
+        ("nodes", C.c_int32),
+        ("_pad", C.c_int32),
+        ("out", C.c_void_p),
+    ]
+
+
 class StdJob(C.Structure):
     _fields_ = [
         ("x", C.c_void_p),
@@ -257,6 +273,12 @@ def load():
     lib.nlam_wmse_bwd.restype = i32
     lib.nlam_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
     lib.nlam_adamw_step.restype = i32
+    lib.nlam_step_tail_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i64, i32, i32, vp]
+    lib.nlam_step_tail_fwd.restype = i32
+    lib.nlam_step_tail_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i64, i32, i32, vp]
+    lib.nlam_step_tail_bwd.restype = i32
+    lib.nlam_concat.argtypes = [C.POINTER(Cat), vp]
+    lib.nlam_concat.restype = i32
     lib.nlam_linear.argtypes = [C.POINTER(Linear), vp]
     lib.nlam_linear.restype = i32
     lib.nlam_standardize.argtypes = [C.POINTER(StdJobs), vp]

@@ -2454,6 +2454,76 @@ __global__ void standardize_kernel(const nlam_std_jobs_t jobs) {
     }
 }
 
+// one AR step's elementwise tail (nlam_step_tail_fwd / _bwd): state update, boundary overwrite and the masked weighted
+// MSE partial sums in one pass over the (rows, width) state; the backward in one more
+__global__ __launch_bounds__(256) void step_tail_fwd_kernel(const float* __restrict__ delta, const float* __restrict__ prev,
+                                                            const float* __restrict__ truth, const float* __restrict__ target,
+                                                            const float* __restrict__ dstd, const float* __restrict__ dmean,
+                                                            const float* __restrict__ bmask, const float* __restrict__ inv_var,
+                                                            const float* __restrict__ row_weight, float scale, float* __restrict__ pred,
+                                                            float* __restrict__ partials, long total, int nodes, int width) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / width;
+        const int f = (int)(e - r * width);
+        const int n = (int)(r % nodes);
+        float nw = prev[e] + (dstd != nullptr ? delta[e] * dstd[f] : delta[e]);
+        if (dmean != nullptr) nw += dmean[f];
+        const float bm = bmask[n];
+        const float pv = bm * truth[e] + (1.f - bm) * nw;
+        pred[e] = pv;
+        const float w = row_weight[n];
+        if (w != 0.f) {
+            const float d = pv - target[e];
+            s += w * inv_var[f] * d * d;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+}
+
+__global__ void step_tail_bwd_kernel(const float* __restrict__ g_pred, const float* __restrict__ gloss, const float* __restrict__ pred,
+                                     const float* __restrict__ target, const float* __restrict__ dstd, const float* __restrict__ bmask,
+                                     const float* __restrict__ inv_var, const float* __restrict__ row_weight, float scale,
+                                     float* __restrict__ d_delta, float* __restrict__ d_prev, long total, int nodes, int width) {
+    const float g2 = 2.f * scale * gloss[0];
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / width;
+        const int f = (int)(e - r * width);
+        const int n = (int)(r % nodes);
+        const float w = row_weight[n];
+        float G = g_pred != nullptr ? g_pred[e] : 0.f;
+        if (w != 0.f) G += g2 * w * inv_var[f] * (pred[e] - target[e]);
+        G *= 1.f - bmask[n];
+        if (d_prev != nullptr) d_prev[e] = G;
+        if (d_delta != nullptr) d_delta[e] = dstd != nullptr ? G * dstd[f] : G;
+    }
+}
+
+// row-wise concatenation (nlam_concat): thread -> one output element; consecutive threads walk along a row
+__global__ void concat_kernel(const nlam_cat_t p, int wtot) {
+    const long total = (long)p.batch * p.nodes * wtot;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / wtot;
+        int c = (int)(e - r * wtot);
+        const int b = (int)(r / p.nodes);
+        const int n = (int)(r - (long)b * p.nodes);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < NLAM_MAX_CAT; ++k) {
+            if (k < p.nsrc) {
+                if (c >= 0 && c < p.width[k]) v = p.ptr[k][(long)b * p.bstride[k] + (long)n * p.width[k] + c];
+                c -= p.width[k];
+            }
+        }
+        p.out[e] = v;
+    }
+}
+
 __global__ void wmse_bwd_kernel(const float* pred, const float* target, const float* inv_var, const float* row_weight,
                                 const float* gscalar, long total, int nodes, int nvars, float scale, float* dpred) {
     const float g = 2.f * scale * gscalar[0];
@@ -3434,6 +3504,48 @@ int32_t nlam_affine_mix(const float* x, const float* a, const float* y, const fl
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(affine_mix_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, x, a, y, c, z, s, m, out, total,
                        nodes, width);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_step_tail_fwd(const float* delta, const float* prev, const float* truth, const float* target, const float* dstd,
+                           const float* dmean, const float* bmask, const float* inv_var, const float* row_weight, float scale,
+                           float* pred, float* partials, int32_t nparts, int64_t rows, int32_t nodes, int32_t width,
+                           void* hip_stream) {
+    if (delta == nullptr || prev == nullptr || truth == nullptr || target == nullptr || bmask == nullptr || inv_var == nullptr ||
+        row_weight == nullptr || pred == nullptr || partials == nullptr)
+        return NLAM_EINVAL;
+    if (rows < 1 || nodes < 1 || width < 1 || nparts < 1) return NLAM_EINVAL;
+    hipLaunchKernelGGL(step_tail_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)hip_stream, delta, prev, truth, target, dstd,
+                       dmean, bmask, inv_var, row_weight, scale, pred, partials, (long)rows * width, nodes, width);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_step_tail_bwd(const float* g_pred, const float* gloss, const float* pred, const float* target, const float* dstd,
+                           const float* bmask, const float* inv_var, const float* row_weight, float scale, float* d_delta,
+                           float* d_prev, int64_t rows, int32_t nodes, int32_t width, void* hip_stream) {
+    if (gloss == nullptr || pred == nullptr || target == nullptr || bmask == nullptr || inv_var == nullptr || row_weight == nullptr)
+        return NLAM_EINVAL;
+    if ((d_delta == nullptr && d_prev == nullptr) || rows < 1 || nodes < 1 || width < 1) return NLAM_EINVAL;
+    const long total = (long)rows * width;
+    long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(step_tail_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, g_pred, gloss, pred, target,
+                       dstd, bmask, inv_var, row_weight, scale, d_delta, d_prev, total, nodes, width);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_concat(const nlam_cat_t* p, void* hip_stream) {
+    if (p == nullptr || p->out == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_CAT || p->batch < 1 || p->nodes < 0) return NLAM_EINVAL;
+    int wtot = 0;
+    for (int k = 0; k < p->nsrc; ++k) {
+        if (p->ptr[k] == nullptr || p->width[k] < 0 || p->bstride[k] < 0) return NLAM_EINVAL;
+        wtot += p->width[k];
+    }
+    if (p->nodes == 0 || wtot == 0) return 0;
+    const long total = (long)p->batch * p->nodes * wtot;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(concat_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, *p, wtot);
     return (int32_t)hipGetLastError();
 }
 

@@ -247,11 +247,21 @@ class BaseGraphModel(StepPredictor):
         finally:
             self._static = None
 
-    def forward(self, prev_state, prev_prev_state, forcing):
+    def can_return_raw_delta(self) -> bool:
+        """True when the step's tail is the plain ``prev + delta * diff_std + diff_mean`` (no clamping, no predicted std):
+        the forecaster may then fuse it with the boundary overwrite and the loss (ops.StepTailFunction)."""
+        no_clamp = self.clamp_lower_upper_idx.numel() + self.clamp_lower_idx.numel() + self.clamp_upper_idx.numel() == 0
+        return no_clamp and not self.output_std and self.diff_std.dim() == 1
+
+    def forward(self, prev_state, prev_prev_state, forcing, raw_delta: bool = False):
         B = prev_state.shape[0]
-        grid_features = torch.cat(
-            (prev_state, prev_prev_state, forcing, self.expand_to_batch(self.grid_static_features, B)), dim=-1
-        )
+        feats = (prev_state, prev_prev_state, forcing, self.expand_to_batch(self.grid_static_features, B))
+        if FUSED_STATE_UPDATE and prev_state.is_cuda and all(t.dtype == torch.float32 and t.dim() == 3 for t in feats):
+            from .ops import ConcatFunction
+
+            grid_features = ConcatFunction.apply(*feats)   # graph/base.py:275-283 in one launch; the static features are read un-expanded
+        else:
+            grid_features = torch.cat(feats, dim=-1)
         st = self._static if self._static is not None else self.compute_static_embeddings()
         grid_emb = self.grid_embedder(grid_features)  # (B, N_grid, d)
         mesh_rep = self.g2m_gnn(
@@ -266,6 +276,8 @@ class BaseGraphModel(StepPredictor):
         mesh_rep = self.process_step(mesh_rep, st)
         grid_rep = self.m2g_gnn(mesh_rep, grid_rep, self.expand_to_batch(st["m2g"], B))
         net_output = self.output_map(grid_rep)
+        if raw_delta:
+            return net_output, None
         if self.output_std:
             pred_delta_mean, pred_std_raw = net_output.chunk(2, dim=-1)
             pred_std = torch.nn.functional.softplus(pred_std_raw)
@@ -487,12 +499,31 @@ class ARForecaster(nn.Module):
     def predicts_std(self):
         return self.predictor.predicts_std
 
-    def forward(self, init_states, forcing_features, boundary_states):
+    def forward(self, init_states, forcing_features, boundary_states, loss_spec=None):
+        """``loss_spec = (target_states, inv_var (F,), row_weight (N,), scale)``: also return the training loss
+        ``scale * sum_t sum_n,f row_weight * inv_var * (pred - target)^2`` as a third value, with each step's state
+        update + boundary overwrite + loss term fused into one pass (ops.StepTailFunction) when the predictor's tail is
+        the plain rescale (no clamping / predicted std)."""
         prev_prev_state, prev_state = init_states[:, 0], init_states[:, 1]
         preds, stds = [], []
         cache = self.predictor.static_cache() if hasattr(self.predictor, "static_cache") else contextlib.nullcontext()
+        fused_tail = (loss_spec is not None and FUSED_STATE_UPDATE and init_states.is_cuda and init_states.dtype == torch.float32
+                      and boundary_states.dtype == torch.float32 and getattr(self.predictor, "can_return_raw_delta", lambda: False)())
+        losses = []
         with cache:
             for i in range(forcing_features.shape[1]):
+                if fused_tail:
+                    from .ops import StepTailFunction
+
+                    target, inv_var, row_weight, scale = loss_spec
+                    delta, _ = self.predictor(prev_state, prev_prev_state, forcing_features[:, i], raw_delta=True)
+                    new_state, loss_t = StepTailFunction.apply(
+                        delta.float(), prev_state, boundary_states[:, i], target[:, i], self.predictor.diff_std, self.predictor.diff_mean,
+                        self.boundary_mask.reshape(-1), inv_var, row_weight, scale)
+                    preds.append(new_state)
+                    losses.append(loss_t)
+                    prev_prev_state, prev_state = prev_state, new_state
+                    continue
                 pred_state, pred_std = self.predictor(prev_state, prev_prev_state, forcing_features[:, i])
                 if (FUSED_STATE_UPDATE and pred_state.is_cuda and pred_state.dtype == torch.float32
                         and boundary_states.dtype == torch.float32):
@@ -510,6 +541,11 @@ class ARForecaster(nn.Module):
         def _stack(xs):   # a one-step rollout needs no copy
             return xs[0].unsqueeze(1) if len(xs) == 1 else torch.stack(xs, dim=1)
 
+        if loss_spec is not None:
+            loss = None
+            if fused_tail:
+                loss = losses[0] if len(losses) == 1 else torch.stack(losses).sum()
+            return _stack(preds), (_stack(stds) if stds else None), loss
         return _stack(preds), (_stack(stds) if stds else None)
 
 
@@ -596,7 +632,15 @@ class ForecasterStep(nn.Module):
             standardize = self.standardize_inputs
         if standardize:
             init_states, target_states, forcing = self.standardize(init_states, target_states, forcing)
-        prediction, pred_std = self.forecaster(init_states, forcing, target_states)
+        if (self.inv_var is not None and init_states.is_cuda and FUSED_STATE_UPDATE and isinstance(self.forecaster, ARForecaster)):
+            # rollout with every step's state update + boundary overwrite + loss term in one pass (one more in backward)
+            B, T = target_states.shape[0], target_states.shape[1]
+            prediction, pred_std, loss = self.forecaster(init_states, forcing, target_states,
+                                                         loss_spec=(target_states, self.inv_var, self.interior_weight, 1.0 / (B * T)))
+            if loss is not None:
+                return prediction, loss
+        else:
+            prediction, pred_std = self.forecaster(init_states, forcing, target_states)
         if pred_std is None and prediction.is_cuda:
             # fixed per-variable std: wmse + interior mask + the grid / batch / step means in one HBM-bound kernel pair
             from .ops import WmseLossFunction

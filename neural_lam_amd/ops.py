@@ -1114,6 +1114,101 @@ class AffineMixFunction(torch.autograd.Function):
         return None, None, gy, None, gz, None, None
 
 
+class StepTailFunction(torch.autograd.Function):
+    """The elementwise tail of one AR step in one pass each way (nlam_step_tail_fwd / _bwd):
+
+        new = prev + delta * diff_std + diff_mean ; pred = bmask * truth + (1 - bmask) * new ;
+        loss_t = scale * sum_n,f row_weight[n] * inv_var[f] * (pred - target)^2
+
+    i.e. ``step_predictors/graph/base.py:331-343`` + ``forecasters/autoregressive.py:128-131`` + this step's term of
+    ``metrics.wmse`` / ``module.py:463-510`` (three elementwise launches + the loss pass in the reference's formulation,
+    and as many again in backward).  forward(delta, prev, truth, target, dstd, dmean, bmask (N,), inv_var (F,),
+    row_weight (N,), scale) -> (pred (B, N, F), loss_t scalar)."""
+
+    NPARTS = 512
+
+    @staticmethod
+    def forward(ctx, delta, prev, truth, target, dstd, dmean, bmask, inv_var, row_weight, scale: float):
+        lib = L.load()
+        _require_gpu(delta, prev, truth, target, dstd, dmean, bmask, inv_var, row_weight)
+        B, N, F = delta.shape
+        cont = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        delta, prev, truth, target = map(cont, (delta, prev, truth, target))
+        dev = delta.device
+        pred = torch.empty((B, N, F), device=dev, dtype=torch.float32)
+        partials = torch.empty((StepTailFunction.NPARTS,), device=dev, dtype=torch.float32)
+        L.check(lib.nlam_step_tail_fwd(_ptr(delta), _ptr(prev), _ptr(truth), _ptr(target), _ptr(dstd), _ptr(dmean), _ptr(bmask),
+                                       _ptr(inv_var), _ptr(row_weight), scale, _ptr(pred), _ptr(partials), StepTailFunction.NPARTS,
+                                       B * N, N, F, _stream()), "nlam_step_tail_fwd")
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        L.check(lib.nlam_reduce_partials(_ptr(partials), StepTailFunction.NPARTS, 1, 1, _ptr(loss), 0, _stream()), "nlam_reduce_partials")
+        ctx.save_for_backward(pred, target, dstd, bmask, inv_var, row_weight)
+        ctx.scale = scale
+        ctx.set_materialize_grads(False)
+        return pred, loss
+
+    @staticmethod
+    def backward(ctx, g_pred, g_loss):
+        lib = L.load()
+        pred, target, dstd, bmask, inv_var, row_weight = ctx.saved_tensors
+        B, N, F = pred.shape
+        if g_pred is None and g_loss is None:
+            return (None,) * 10
+        dev = pred.device
+        gl = g_loss.contiguous().to(torch.float32) if g_loss is not None else torch.zeros((), device=dev, dtype=torch.float32)
+        gp = g_pred.contiguous() if g_pred is not None else None
+        d_delta = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        d_prev = torch.empty_like(pred) if ctx.needs_input_grad[1] else None
+        if d_delta is None and d_prev is None:
+            return (None,) * 10
+        L.check(lib.nlam_step_tail_bwd(_ptr(gp), _ptr(gl), _ptr(pred), _ptr(target), _ptr(dstd), _ptr(bmask), _ptr(inv_var),
+                                       _ptr(row_weight), ctx.scale, _ptr(d_delta), _ptr(d_prev), B * N, N, F, _stream()),
+                "nlam_step_tail_bwd")
+        return d_delta, d_prev, None, None, None, None, None, None, None, None
+
+
+class ConcatFunction(torch.autograd.Function):
+    """``torch.cat(sources, dim=-1)`` of (B, N, w_k) rows in one launch (nlam_concat); a stride-0 batch (expand_to_batch)
+    is read in place.  Backward: column slices of the incoming gradient (views)."""
+
+    @staticmethod
+    def forward(ctx, *srcs):
+        lib = L.load()
+        _require_gpu(*srcs)
+        assert 1 <= len(srcs) <= 6
+        p = L.Cat()
+        keep = []
+        B = max(s.shape[0] for s in srcs)
+        N = srcs[0].shape[-2]
+        widths = []
+        for k, s_ in enumerate(srcs):
+            t, b_, bstride, _ = as_batched(s_)
+            if b_ not in (1, B) or s_.shape[-2] != N:
+                raise RuntimeError("concat: inconsistent batch / row counts")
+            keep.append(t)
+            p.ptr[k], p.bstride[k], p.width[k] = t.data_ptr(), (bstride if b_ == B and B > 1 else 0), s_.shape[-1]
+            widths.append(s_.shape[-1])
+        out = torch.empty((B, N, sum(widths)), device=srcs[0].device, dtype=torch.float32)
+        p.nsrc, p.batch, p.nodes, p.out = len(srcs), B, N, _ptr(out)
+        L.check(lib.nlam_concat(C.byref(p), _stream()), "nlam_concat")
+        ctx.widths = widths
+        ctx.shapes = [tuple(s_.shape) for s_ in srcs]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        grads, off = [], 0
+        for k, w in enumerate(ctx.widths):
+            gk = None
+            if ctx.needs_input_grad[k]:
+                gk = g[..., off : off + w]
+                if gk.shape != ctx.shapes[k]:   # a broadcast source
+                    gk = gk.sum(0, keepdim=True).expand(ctx.shapes[k]) if len(ctx.shapes[k]) == g.dim() else gk.sum(0)
+            grads.append(gk)
+            off += w
+        return tuple(grads)
+
+
 def standardize(items):
     """``ForecasterModule.on_after_batch_transfer`` (models/module.py:326-367) for up to four tensors in one launch.
 

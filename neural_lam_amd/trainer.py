@@ -239,6 +239,7 @@ class Trainer:
                 cur.wait_stream(st)
 
     _main_stream = None
+    _unit = None
 
     def _fwd_bwd_on(self, batch):
         """forward + backward.  For their duration the fused-MLP backward owns the parameter gradients
@@ -259,7 +260,12 @@ class Trainer:
             if ov is not None:
                 ov.begin()
             try:
-                loss.backward()
+                if loss.dim() == 0 and loss.dtype == torch.float32:
+                    if self._unit is None or self._unit.device != loss.device:
+                        self._unit = torch.ones((), device=loss.device, dtype=torch.float32)
+                    loss.backward(gradient=self._unit)   # a resident seed: autograd's implicit ones_like is a fill launch per step
+                else:
+                    loss.backward()
             finally:
                 if ov is not None:
                     ov.end()
