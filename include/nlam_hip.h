@@ -273,8 +273,13 @@ typedef struct {
     int32_t n;
     int32_t accumulate;    /* != 0: out += */
     uint32_t flags;
+    const float* W2;       /* optional second product over the same x (widths above 64 only): out2 = x . A2^T, same shapes and */
+    float* out2;           /* strides (the sender- and the receiver-side product of a layer whose senders are its receivers)   */
 } nlam_linear_t;
 int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream);
+/* 1 when nlam_mlp_fwd / nlam_mlp_bwd / nlam_linear have a factorised (NLAM_F_PRE_ADD) kernel for this problem, else 0
+ * (only nsrc, the source widths, hid, dout, flags, ntiles and batch of *p are read) */
+int32_t nlam_pre_add_supported(const nlam_mlp_fwd_t* p);
 
 /* Training loss of ForecasterModule.training_step (models/module.py:463-510) with metrics.wmse /
  * mask_and_reduce_metric (metrics.py:37-137) for a per-variable std:

@@ -43,6 +43,7 @@ EXPORTS = [
     "nlam_adamw_step",
     "nlam_standardize",
     "nlam_linear",
+    "nlam_pre_add_supported",
     "nlam_step_tail_fwd",
     "nlam_step_tail_bwd",
     "nlam_concat",
@@ -178,6 +179,8 @@ class Linear(C.Structure):
         ("n", C.c_int32),
         ("accumulate", C.c_int32),
         ("flags", C.c_uint32),
+        ("W2", C.c_void_p),
+        ("out2", C.c_void_p),
     ]
 
 
@@ -279,6 +282,8 @@ def load():
     lib.nlam_step_tail_bwd.restype = i32
     lib.nlam_concat.argtypes = [C.POINTER(Cat), vp]
     lib.nlam_concat.restype = i32
+    lib.nlam_pre_add_supported.argtypes = [C.POINTER(MlpFwd)]
+    lib.nlam_pre_add_supported.restype = i32
     lib.nlam_linear.argtypes = [C.POINTER(Linear), vp]
     lib.nlam_linear.restype = i32
     lib.nlam_standardize.argtypes = [C.POINTER(StdJobs), vp]

@@ -2625,6 +2625,97 @@ __global__ __launch_bounds__(kFwdThreads) void linear_bf_kernel(const nlam_linea
     }
 }
 
+// Widths above 64 (k, n multiples of 64, up to 512): W no longer fits LDS as split fragments, so the product is walked
+// in 64 x 64 weight blocks.  blockIdx.y = pair of 32-column output blocks (with a second weight matrix / output, W2 and
+// out2, the pairs n/64 .. 2n/64 - 1 belong to it: both node-level products of a layer whose senders are its receivers
+// in one launch); the workgroup streams that pair's K dimension in 64-column chunks, the next chunk's weight block
+// staged (split) into the other LDS buffer while this one is multiplied.  One wave = one 32-row tile per round.
+template <int NS>
+__global__ __launch_bounds__(kFwdThreads) void linear_bfw_kernel(const nlam_linear_t p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int S = 4;                                           // K = 16 steps per 64-column chunk
+    constexpr size_t kWb = (size_t)NS * 2 * S * 64;                // u32x4 per weight buffer: [NS][2 blocks][S][64]
+    u32x4* Ws = reinterpret_cast<u32x4*>(smem);                    // two buffers
+    float* stg_all = reinterpret_cast<float*>(Ws + 2 * kWb);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    float* stg = stg_all + (size_t)wave * 32 * kStgStride;
+    const long ntiles = (p.rows + 31) / 32;
+    const int nwaves = blockDim.x >> 6;
+    const int NP = p.n / 64, KC = p.k / 64;
+    int np = blockIdx.y;
+    const float* Wm = p.W;
+    float* outm = p.out;
+    if (np >= NP) {
+        np -= NP;
+        Wm = p.W2;
+        outm = p.out2;
+    }
+    const float* Wp = Wm + (long)(64 * np) * p.ldn;
+    const long rounds = (ntiles + (long)gridDim.x * nwaves - 1) / ((long)gridDim.x * nwaves);
+    for (long rd = 0; rd < rounds; ++rd) {
+        const long t = (rd * nwaves + wave) * gridDim.x + blockIdx.x;
+        const bool live = t < ntiles;
+        const long r = live ? min(t * 32 + j, p.rows - 1) : 0;
+        const float* xrow = p.x + r * p.k + 8 * hi;
+        const int nrows = live ? (int)min((long)32, p.rows - t * 32) : 0;
+        float* obase = outm + t * 32 * p.n + 64 * np;
+        f32x4 xu[2][4];
+        auto load_x = [&](int kc) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float* xc = xrow + 64 * kc + 32 * u;
+                xu[u][0] = *reinterpret_cast<const f32x4*>(xc);
+                xu[u][1] = *reinterpret_cast<const f32x4*>(xc + 4);
+                xu[u][2] = *reinterpret_cast<const f32x4*>(xc + 16);
+                xu[u][3] = *reinterpret_cast<const f32x4*>(xc + 20);
+            }
+        };
+        load_x(0);
+        stage_split<NS>(Ws, S, 0, Wp, p.ldn, 64, 2, 64, false, p.ldk);
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][q] = 0.f;
+        for (int kc = 0; kc < KC; ++kc) {
+            if (kc + 1 < KC) stage_split<NS>(Ws + (size_t)((kc + 1) & 1) * kWb, S, 0, Wp + (long)(64 * (kc + 1)) * p.ldk, p.ldn, 64, 2, 64, false, p.ldk);
+            const u32x4* Wb = Ws + (size_t)(kc & 1) * kWb;
+            BfFrag<NS> B[4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float xs8[8] = {xu[u][2 * h][0], xu[u][2 * h][1], xu[u][2 * h][2], xu[u][2 * h][3],
+                                          xu[u][2 * h + 1][0], xu[u][2 * h + 1][1], xu[u][2 * h + 1][2], xu[u][2 * h + 1][3]};
+                    B[2 * u + h] = split8<NS>(xs8);
+                }
+            if (kc + 1 < KC) load_x(kc + 1);   // the next chunk's rows are in flight during this chunk's MFMAs
+#pragma unroll
+            for (int st = 0; st < 4; ++st) mma_split_lds<NS, 2>(acc, Wb, 2, S, st, lane, B[st]);
+            __syncthreads();   // the next block is staged; everyone is done with this one
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(acc[mb], tt);
+            wave_lds_sync();
+            for (int base = 0; base < nrows * 8; base += 64) {
+                const int item = base + lane;
+                if (item < nrows * 8) {
+                    const int rr = item >> 3, c4 = item & 7;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&stg[rr * kStgStride + 4 * c4]);
+                    float* d = obase + (size_t)rr * p.n + 32 * mb + 4 * c4;
+                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(d);
+                    *reinterpret_cast<f32x4*>(d) = v;
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
 #include "nlam_wide.inc"
 #include "nlam_wbf.inc"
 
@@ -2943,7 +3034,7 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
     if (p->rows == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
     if (fwd_is_wide(p)) {
-        if (p->flags & NLAM_F_PRE_ADD) return NLAM_EUNSUP;
+        if ((p->flags & NLAM_F_PRE_ADD) && fwd_wbf_ns(p) == 0) return NLAM_EUNSUP;   // the fp32 wide kernels have no factorised variant
         const WideCfg cfg = wide_cfg(p->hid > p->dout ? p->hid : p->dout);
         if (cfg.nwv == 0) return NLAM_EUNSUP;
         const int64_t need = nlam_mlp_fwd_wpack_floats(p);
@@ -2964,14 +3055,17 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
             const WbfPlan pl = fwd_wbf_choose(p, wns);
             const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
             const int TK1 = fwd_wbf_tk1(p, pl.kg);
+            const bool pre = (p->flags & NLAM_F_PRE_ADD) != 0;
+            const int ngemm = pre ? 1 : p->nsrc;
             int kin = 0;
-            for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
+            for (int s = 0; s < ngemm; ++s) kin += p->src[s].width;
+            if (pre && p->ldw1 > 0) kin = p->ldw1;   // floats between rows of W1
             u32x4* A1 = reinterpret_cast<u32x4*>(p->wpack);
             packbf_jobs_t jobs;
             jobs.njobs = 0;
             int off = 0, g0 = 0;
             long most = 0;
-            for (int s = 0; s < p->nsrc; ++s) {
+            for (int s = 0; s < ngemm; ++s) {
                 const int w = p->src[s].width;
                 const int ng = ((w + 16 * pl.kg - 1) / (16 * pl.kg)) * pl.kg;
                 jobs.job[jobs.njobs++] = {p->W1 + off, (long)kin, 1L, p->hid, HBT, w, TK1, g0, ng, 0, A1};
@@ -3112,7 +3206,7 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
     }
     if (p->rows == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
-    if (bwd_is_wide(p) && (p->flags & NLAM_F_PRE_ADD)) return NLAM_EUNSUP;
+    if (bwd_is_wide(p) && (p->flags & NLAM_F_PRE_ADD) && bwd_wbf_ns(p) == 0) return NLAM_EUNSUP;
     if (bwd_is_wide(p)) {
         const WideCfg cfg = wide_cfg(bwd_wide_maxw(p));
         if (cfg.nwv == 0) return NLAM_EUNSUP;
@@ -3130,8 +3224,10 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
 #if NLAM_IN_TU(4)
 int32_t nlam_detail::bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream) {
     const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
+    const bool pre = (p->flags & NLAM_F_PRE_ADD) != 0;
     int kin = 0;
-    for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
+    for (int s = 0; s < (pre ? 1 : p->nsrc); ++s) kin += p->src[s].width;
+    if (pre && p->ldw1 > 0) kin = p->ldw1;
     const int wns = bwd_wbf_ns(p);
     {
             const WbfBwdPlan pl = wbf_bwd_plan(bwd_wide_maxw(p));
@@ -3146,7 +3242,7 @@ int32_t nlam_detail::bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream) {
             int off = 0;
             for (int s = 0; s < p->nsrc; ++s) {
                 const int w = p->src[s].width;
-                if (p->dmode[s] != 0) {
+                if (p->dmode[s] != 0 && (s == 0 || !pre)) {
                     const int SB = (w + 31) / 32;
                     // A[m = source column][k = hidden] = W1[k][off + m]
                     jobs.job[jobs.njobs++] = {p->W1 + off, 1L, (long)kin, w, SB, p->hid, TKB, 0, TKB, 1, base + woff};
@@ -3388,12 +3484,36 @@ int32_t nlam_detail::wgrad_narrow(const nlam_wgrad_t* p, hipStream_t stream) {
 #if NLAM_IN_TU(5)
 extern "C" {
 
+int32_t nlam_pre_add_supported(const nlam_mlp_fwd_t* p) {
+    /* would nlam_mlp_fwd (and the matching nlam_mlp_bwd) run this NLAM_F_PRE_ADD problem on a factorised kernel?
+       Only shapes, flags, ntiles and batch are read. */
+    if (p == nullptr || (p->flags & NLAM_F_PRE_ADD) == 0 || p->nsrc < 2 || (p->flags & NLAM_F_ADD_SRC1)) return 0;
+    const int ns = (int)((p->flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
+    if (ns == 0 || p->hid % 32 != 0 || p->dout % 32 != 0 || p->src[0].width % 32 != 0) return 0;
+    for (int s = 1; s < p->nsrc; ++s)
+        if (p->src[s].width != p->hid) return 0;
+    if (!fwd_is_wide(p)) return p->hid == p->dout && (p->src[0].width == 32 || p->src[0].width == 64) ? 1 : 0;
+    if (fwd_wbf_ns(p) == 0) return 0;
+    nlam_mlp_bwd_t q = {};
+    q.nsrc = p->nsrc;
+    for (int s = 0; s < p->nsrc; ++s) {
+        q.src[s] = p->src[s];
+        q.dmode[s] = s == 0 ? 1 : (s == 1 ? 0 : 3);
+    }
+    q.batch = p->batch, q.rows = p->rows, q.ntiles = p->ntiles, q.hid = p->hid, q.dout = p->dout, q.flags = p->flags;
+    if (bwd_wbf_ns(&q) == 0) return 0;
+    const int k = p->src[0].width;   // node-level products: k = input width, n = hid (nlam_linear)
+    return (k % 64 == 0 && p->hid % 64 == 0) ? 1 : 0;
+}
+
 int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream) {
     if (p == nullptr || p->x == nullptr || p->W == nullptr || p->out == nullptr || p->rows < 0 || p->k < 1 || p->n < 1) return NLAM_EINVAL;
     if (p->rows == 0) return 0;
     const int ns = (int)((p->flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
     if (ns == 0 || p->k % 32 != 0 || p->n % 32 != 0) return NLAM_EUNSUP;
     if (((reinterpret_cast<uintptr_t>(p->x) | reinterpret_cast<uintptr_t>(p->out)) & 15) != 0) return NLAM_EINVAL;
+    if ((p->W2 == nullptr) != (p->out2 == nullptr)) return NLAM_EINVAL;
+    if (p->W2 != nullptr && (p->k <= 64 && p->n <= 64)) return NLAM_EUNSUP;   // the dual form exists for the wide kernel only
     const int KB = p->k / 32, MB = p->n / 32;
     const long ntiles = (p->rows + 31) / 32;
     const int blocks = (int)(ntiles < kMaxGridBlocks ? ntiles : kMaxGridBlocks);
@@ -3415,7 +3535,23 @@ int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream) {
     else if (KB == 2 && MB == 1) NLAM_LAUNCH_LIN(2, 1);
     else if (KB == 1 && MB == 2) NLAM_LAUNCH_LIN(1, 2);
     else if (KB == 2 && MB == 2) NLAM_LAUNCH_LIN(2, 2);
-    else return NLAM_EUNSUP;
+    else if (p->k % 64 == 0 && p->n % 64 == 0 && p->k <= kMaxWide && p->n <= kMaxWide) {
+        // 64 x 64 weight blocks streamed through two LDS buffers (linear_bfw_kernel)
+        const size_t wlds = (size_t)2 * ns * 2 * 4 * 64 * 16 + (size_t)kFwdWaves * 32 * kStgStride * sizeof(float);
+        const int wby = (p->n / 64) * (p->W2 != nullptr ? 2 : 1);
+        long wbx = (ntiles + kFwdWaves - 1) / kFwdWaves;   // eight tiles (one per wave) share each staged weight block
+        if (wbx * wby > 4 * kNumCUs) wbx = (4 * kNumCUs + wby - 1) / wby;
+        if (wbx < 1) wbx = 1;
+#define NLAM_LAUNCH_LINW(NS_)                                                                              \
+    do {                                                                                                   \
+        int rc = set_lds(linear_bfw_kernel<NS_>, wlds);                                                    \
+        if (rc != 0) return rc;                                                                            \
+        hipLaunchKernelGGL((linear_bfw_kernel<NS_>), dim3(wbx, wby), dim3(kFwdThreads), wlds, stream, *p); \
+    } while (0)
+        if (ns == 3) NLAM_LAUNCH_LINW(3);
+        else if (ns == 2) NLAM_LAUNCH_LINW(2);
+        else NLAM_LAUNCH_LINW(1);
+    } else return NLAM_EUNSUP;
     return (int32_t)hipGetLastError();
 }
 

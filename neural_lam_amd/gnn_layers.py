@@ -25,7 +25,8 @@ from .graph import EdgeCSR, build_edge_csr, build_tile_schedule
 import os
 
 from . import ops
-from .ops import ChunkedGeometry, ChunkedMLPFunction, FusedMLPFunction, MlpGeometry, NodeLinearFunction, as_batched, segment_sum
+from .ops import (ChunkedGeometry, ChunkedMLPFunction, FusedMLPFunction, MlpGeometry, NodeLinearFunction, NodeLinearPairFunction,
+                  as_batched, segment_sum)
 
 # Edge sets with at least this many edges (per batch item) run the FACTORISED edge MLP:
 #   W1 [e | x_j | x_i] = W1_e e + (W1_j x)[sender] + (W1_i x)[receiver]
@@ -35,6 +36,13 @@ from .ops import ChunkedGeometry, ChunkedMLPFunction, FusedMLPFunction, MlpGeome
 # Below the threshold the two extra node-level launches cost more than they save (the mesh-level layers of cfg2 are
 # latency-bound single-tile-per-wave launches).
 FACTORISE_MIN_EDGES = int(os.environ.get("NLAM_FACTORISE_MIN_EDGES", str(1 << 30)))
+# Widths above 64 (cfg3 / cfg4 / cfg5) are bound by the matrix cores, where dropping two thirds of the first GEMM pays
+# (m2g at d = 256: forward 854 -> 581 us, backward 1029 -> 694 us, dW1 643 -> 239 us; cfg3 step 54.6 -> 49.1 ms) as soon
+# as the edge set is large enough to amortise the node-level launches: edges x width >= FACTORISE_MIN_WORK_WIDE
+# (the 57 616-edge mesh layers at d = 256 gain, the Hi-LAM level layers at d = 128 lose: cfg4 12.5 -> 13.4 ms when
+# everything is factorised), on the edge sets the split-bf16 super-tile kernels take (nlam_pre_add_supported).
+FACTORISE_MIN_EDGES_WIDE = int(os.environ.get("NLAM_FACTORISE_MIN_EDGES_WIDE", "0"))
+FACTORISE_MIN_WORK_WIDE = int(os.environ.get("NLAM_FACTORISE_MIN_WORK_WIDE", "14000000"))
 
 
 class FusedMLP(nn.Sequential):
@@ -301,8 +309,11 @@ class InteractionNet(nn.Module):
         if self._factorise(csr, send_rep, rec_rep, edge_rep):
             W1 = self.edge_mlp[0].weight
             d = edge_rep.shape[-1]
-            p_send = NodeLinearFunction.apply(send_rep, W1, d)                         # (W1_j x) per sender node
-            p_rec = NodeLinearFunction.apply(rec_rep, W1, d + send_rep.shape[-1])      # (W1_i x) per receiver node
+            if send_rep is rec_rep and d > 64:   # mesh <-> mesh: both products of the one node table in a single launch
+                p_send, p_rec = NodeLinearPairFunction.apply(send_rep, W1, d, 2 * d)
+            else:
+                p_send = NodeLinearFunction.apply(send_rep, W1, d)          # (W1_j x) per sender node
+                p_rec = NodeLinearFunction.apply(rec_rep, W1, 2 * d)        # (W1_i x) per receiver node
             geom = self._edge_geom(csr, want_out, add_edge, key, pre=True)
             edge_out, aggr = self.edge_mlp.forward_fused(geom, edge_rep, p_send, p_rec)
             return aggr, edge_out
@@ -313,14 +324,30 @@ class InteractionNet(nn.Module):
     def _factorise(self, csr, send_rep, rec_rep, edge_rep) -> bool:
         """Factorised edge MLP (see FACTORISE_MIN_EDGES): InteractionNet messages (no ``x_j +`` term), split-bf16 matrix
         modes, widths that the narrow kernels take as whole 32-column units."""
-        if self.propagates_sender or csr.num_edges < FACTORISE_MIN_EDGES:
-            return False
-        if (ops._mm_flags() >> 8) & 3 == 0:
-            return False
         d, hid = edge_rep.shape[-1], self.edge_mlp[0].out_features
         dout = self.edge_mlp[2].out_features
-        ok = lambda w: w in (32, 64)  # noqa: E731
-        return ok(d) and ok(hid) and hid == dout and send_rep.shape[-1] == d and rec_rep.shape[-1] == d
+        wide = max(d, hid, dout) > 64
+        if self.propagates_sender or csr.num_edges < (FACTORISE_MIN_EDGES_WIDE if wide else FACTORISE_MIN_EDGES):
+            return False
+        if wide and csr.num_edges * max(d, hid) < FACTORISE_MIN_WORK_WIDE:
+            return False
+        mm = ops._mm_flags()
+        if (mm >> 8) & 3 == 0 or send_rep.shape[-1] != d or rec_rep.shape[-1] != d:
+            return False
+        B = 1
+        for n in max((t.shape[:-2] for t in (send_rep, rec_rep, edge_rep)), key=len):
+            B *= n
+        key = ("pre_ok", d, hid, dout, mm, B)
+        if key not in self._geom_cache:   # ask the library whether this launch has a factorised kernel (shape-only query)
+            import ctypes as C
+
+            q = L.MlpFwd()
+            q.nsrc, q.batch, q.rows, q.ntiles = 3, B, csr.num_edges, int(csr.tiles.shape[0])
+            for k, w in enumerate((d, hid, hid)):
+                q.src[k].width = w
+            q.hid, q.dout, q.flags = hid, dout, L.F_PRE_ADD | mm
+            self._geom_cache[key] = bool(L.load().nlam_pre_add_supported(C.byref(q)))
+        return self._geom_cache[key]
 
     def _chunk_bounds(self, sizes):
         bounds, r = [], 0

@@ -936,8 +936,9 @@ def _chunk_weight_grads(lib, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, ve
     return results
 
 
-def _linear_launch(x2d, W, ldn, ldk, k, n, out=None, accumulate=False, mm_flags=None):
-    """out (rows, n) (+)= x2d (rows, k) . A^T with A[h][c] = W[h * ldn + c * ldk] (nlam_linear)."""
+def _linear_launch(x2d, W, ldn, ldk, k, n, out=None, accumulate=False, mm_flags=None, W2=None, out2=None):
+    """out (rows, n) (+)= x2d (rows, k) . A^T with A[h][c] = W[h * ldn + c * ldk] (nlam_linear); with W2 / out2 a second
+    product over the same rows in the same launch."""
     lib = L.load()
     rows = x2d.shape[0]
     if out is None:
@@ -945,9 +946,11 @@ def _linear_launch(x2d, W, ldn, ldk, k, n, out=None, accumulate=False, mm_flags=
     q = L.Linear()
     q.x, q.W, q.out, q.rows, q.ldn, q.ldk, q.k, q.n = _ptr(x2d), W, _ptr(out), rows, ldn, ldk, k, n
     q.accumulate, q.flags = 1 if accumulate else 0, mm_flags if mm_flags is not None else _mm_flags()
-    key = ("linear", rows, k, n)
+    if W2 is not None:
+        q.W2, q.out2 = W2, _ptr(out2)
+    key = ("linear", rows, k, n * (2 if W2 is not None else 1))
     L.check(PROFILE.launch(key, lambda: lib.nlam_linear(C.byref(q), _stream()),
-                           lambda: {"flops": 2.0 * rows * k * n, "bytes": 4.0 * rows * (k + n), "mm": _MM_NAMES[(q.flags >> 8) & 3],
+                           lambda: {"flops": 2.0 * rows * k * key[3], "bytes": 4.0 * rows * (k + key[3]), "mm": _MM_NAMES[(q.flags >> 8) & 3],
                                     "mfmas_per_block": ((q.flags >> 8) & 3) * (((q.flags >> 8) & 3) + 1) // 2,
                                     "what": "node-level product of the factorised edge MLP"}), "nlam_linear")
     return out
@@ -963,6 +966,8 @@ class NodeLinearFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W1, col0: int):
+        if x.dtype != torch.float32 and x.is_floating_point():
+            x = x.float()   # storage is fp32 throughout (autocast regions hand in low-precision activations)
         _require_gpu(x, W1)
         xb, B, bstride, lead = as_batched(x)
         N, k = xb.shape[-2], xb.shape[-1]
@@ -1000,41 +1005,105 @@ class NodeLinearFunction(torch.autograd.Function):
             dx = dx.reshape(N, k).expand(xshape) if shared else dx.reshape(xshape)
         dW = None
         if ctx.needs_input_grad[1]:
-            prm = ctx.param_ref
-            direct = (DIRECT_PARAM_GRADS and prm.grad is not None and prm.grad.is_contiguous()
-                      and tuple(prm.grad.shape) == (hid, kin) and prm.grad.dtype == torch.float32)
-            on_side = OVERLAP.active and direct
-            streams = contextlib.ExitStack()
-            if on_side:
-                side = OVERLAP.stream_for(prm)
-                side.wait_stream(torch.cuda.current_stream())
-                OVERLAP.hold(side, g2d, x2d)
-                streams.enter_context(torch.cuda.stream(side))
-            with streams:
-                q = L.Wgrad()
-                q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(g2d), hid, 1, rows, 1, mm, k
-                _fill_src(q.src[0], x2d, 0, k, None)
-                nparts = lib.nlam_wgrad_nparts(C.byref(q))
-                partials = torch.empty((nparts, hid, k), device=dev, dtype=torch.float32)
-                q.partials, q.nparts = _ptr(partials), nparts
-                key = ("wgrad", rows, hid, k)
-                L.check(PROFILE.launch(key, lambda: lib.nlam_wgrad(C.byref(q), _stream()),
-                                       lambda: {"flops": 2.0 * rows * hid * k, "bytes": 4.0 * (rows * (hid + k) + nparts * hid * k),
-                                                "mm": "f32", "mfmas_per_block": 0, "what": "node-level weight gradient of the factorised edge MLP"}),
-                        "nlam_wgrad")
-                out = prm.grad if direct else torch.zeros((hid, kin), device=dev, dtype=torch.float32)
-                jobs = L.ReduceJobs()
-                j = jobs.job[0]
-                j.partials, j.out, j.stride, j.nparts, j.accumulate = _ptr(partials), out.data_ptr() + 4 * col0, hid * k, nparts, 1 if direct else 0
-                j.n, j.ncols, j.ld = hid * k, k, kin
-                jobs.njobs = 1
-                L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
-                if on_side:
-                    OVERLAP.hold(side, partials)
-                if GRAD_LISTENER is not None and direct:
-                    GRAD_LISTENER.note_done([prm])
-            dW = None if direct else out
+            dW = _node_linear_wgrad(ctx.param_ref, [(g2d, col0)], x2d, mm)
         return dx, dW, None
+
+
+def _node_linear_wgrad(prm, g_cols, x2d, mm):
+    """dW1[:, col0 : col0 + k] (+)= g^T x for each (g (rows, hid), col0): nlam_wgrad + one strided reduction launch; on a
+    weight-gradient side stream and straight into the flat gradient view under the trainer (returns None then)."""
+    lib = L.load()
+    hid, kin = prm.shape
+    rows, k = x2d.shape
+    dev = x2d.device
+    direct = (DIRECT_PARAM_GRADS and prm.grad is not None and prm.grad.is_contiguous()
+              and tuple(prm.grad.shape) == (hid, kin) and prm.grad.dtype == torch.float32)
+    on_side = OVERLAP.active and direct
+    streams = contextlib.ExitStack()
+    if on_side:
+        side = OVERLAP.stream_for(prm)
+        side.wait_stream(torch.cuda.current_stream())
+        OVERLAP.hold(side, x2d, *[g for g, _ in g_cols])
+        streams.enter_context(torch.cuda.stream(side))
+    with streams:
+        out = prm.grad if direct else torch.zeros((hid, kin), device=dev, dtype=torch.float32)
+        jobs = L.ReduceJobs()
+        keep = []
+        for g2d, col0 in g_cols:
+            q = L.Wgrad()
+            q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(g2d), hid, 1, rows, 1, mm, k
+            _fill_src(q.src[0], x2d, 0, k, None)
+            nparts = lib.nlam_wgrad_nparts(C.byref(q))
+            partials = torch.empty((nparts, hid, k), device=dev, dtype=torch.float32)
+            q.partials, q.nparts = _ptr(partials), nparts
+            keep.append(partials)
+            key = ("wgrad", rows, hid, k)
+            L.check(PROFILE.launch(key, lambda: lib.nlam_wgrad(C.byref(q), _stream()),
+                                   lambda: {"flops": 2.0 * rows * hid * k, "bytes": 4.0 * (rows * (hid + k) + nparts * hid * k),
+                                            "mm": "f32" if max(hid, k) <= 64 else _MM_NAMES[(mm >> 8) & 3],
+                                            "mfmas_per_block": 0 if max(hid, k) <= 64 else ((mm >> 8) & 3) * (((mm >> 8) & 3) + 1) // 2,
+                                            "what": "node-level weight gradient of the factorised edge MLP"}), "nlam_wgrad")
+            j = jobs.job[jobs.njobs]
+            j.partials, j.out, j.stride, j.nparts, j.accumulate = _ptr(partials), out.data_ptr() + 4 * col0, hid * k, nparts, 1 if direct else 0
+            j.n, j.ncols, j.ld = hid * k, k, kin
+            jobs.njobs += 1
+        L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
+        if on_side:
+            OVERLAP.hold(side, *keep)
+        if GRAD_LISTENER is not None and direct:
+            GRAD_LISTENER.note_done([prm])
+    return None if direct else out
+
+
+class NodeLinearPairFunction(torch.autograd.Function):
+    """Both node-level products of a layer whose senders are its receivers (mesh <-> mesh), widths above 64:
+    ``(x @ W1[:, cj : cj + k].T, x @ W1[:, ci : ci + k].T)`` in ONE launch (nlam_linear with W2 / out2); backward: one
+    data-gradient launch pair accumulating into one dx, both column blocks of dW1 from one reduction launch."""
+
+    @staticmethod
+    def forward(ctx, x, W1, cj: int, ci: int):
+        if x.dtype != torch.float32 and x.is_floating_point():
+            x = x.float()
+        _require_gpu(x, W1)
+        xb, B, bstride, lead = as_batched(x)
+        N, k = xb.shape[-2], xb.shape[-1]
+        hid, kin = W1.shape
+        shared = bstride == 0 and B > 1
+        x2d = xb.reshape(-1, k)
+        W1c = W1.contiguous()
+        mm = _mm_flags()
+        pj = torch.empty((x2d.shape[0], hid), device=x.device, dtype=torch.float32)
+        pi = torch.empty_like(pj)
+        _linear_launch(x2d, W1c.data_ptr() + 4 * cj, kin, 1, k, hid, out=pj, mm_flags=mm, W2=W1c.data_ptr() + 4 * ci, out2=pi)
+        ctx.save_for_backward(x2d, W1c)
+        ctx.meta = (cj, ci, tuple(x.shape), B, N, shared, mm)
+        ctx.param_ref = W1
+        ctx.set_materialize_grads(False)
+        if GRAD_LISTENER is not None and W1.requires_grad:
+            GRAD_LISTENER.note_use([W1])
+        shape = lambda t: t.reshape(N, hid).expand(*lead, N, hid) if shared else t.reshape(*lead, N, hid)  # noqa: E731
+        return shape(pj), shape(pi)
+
+    @staticmethod
+    def backward(ctx, gj, gi):
+        if gj is None and gi is None:
+            return None, None, None, None
+        x2d, W1 = ctx.saved_tensors
+        cj, ci, xshape, B, N, shared, mm = ctx.meta
+        hid, kin = W1.shape
+        k = x2d.shape[1]
+        prep = lambda g: None if g is None else (g.reshape(B, N, hid).sum(0) if shared else g.reshape(-1, hid)).contiguous()  # noqa: E731
+        gj2, gi2 = prep(gj), prep(gi)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            for g2d, c0 in ((gj2, cj), (gi2, ci)):
+                if g2d is not None:
+                    dx = _linear_launch(g2d, W1.data_ptr() + 4 * c0, 1, kin, hid, k, out=dx, accumulate=dx is not None, mm_flags=mm)
+            dx = dx.reshape(N, k).expand(xshape) if shared else dx.reshape(xshape)
+        dW = None
+        if ctx.needs_input_grad[1]:
+            dW = _node_linear_wgrad(ctx.param_ref, [(g, c) for g, c in ((gj2, cj), (gi2, ci)) if g is not None], x2d, mm)
+        return dx, dW, None, None
 
 
 class WmseLossFunction(torch.autograd.Function):

@@ -59,6 +59,20 @@ def wide_family(request):
     assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
 
 
+@pytest.fixture(params=["factorised", "plain"])
+def wide_factorise(request):
+    """Widths above 64 run the factorised edge MLP (node-level products + gathered addends) wherever the split-bf16
+    super-tile kernels apply; "plain" switches it off so the un-factorised kernels stay covered at full size."""
+    from neural_lam_amd import gnn_layers as hl
+
+    old, old_w = hl.FACTORISE_MIN_EDGES_WIDE, hl.FACTORISE_MIN_WORK_WIDE
+    hl.FACTORISE_MIN_WORK_WIDE = 0
+    if request.param == "plain":
+        hl.FACTORISE_MIN_EDGES_WIDE = 1 << 30
+    yield request.param
+    hl.FACTORISE_MIN_EDGES_WIDE, hl.FACTORISE_MIN_WORK_WIDE = old, old_w
+
+
 LAYERS = [
     # (edge set, d, class, update_edges)
     ("m2g", 64, "InteractionNet", False),
@@ -75,9 +89,11 @@ LAYERS = [
 
 
 @pytest.mark.parametrize("which,d,cls_name,update_edges", LAYERS)
-def test_meps_layer_matches_oracle(dev, meps_raw, which, d, cls_name, update_edges, wide_family):
-    if d <= 64 and wide_family == "wbf":
+def test_meps_layer_matches_oracle(dev, meps_raw, which, d, cls_name, update_edges, wide_family, wide_factorise):
+    if d <= 64 and (wide_family == "wbf" or wide_factorise == "plain"):
         pytest.skip("one kernel family at d <= 64")
+    if wide_family == "wbf" and wide_factorise == "plain":
+        pytest.skip("covered by the auto family: both take the super-tile kernels at this size")
     from neural_lam_amd import gnn_layers as hl
     from oracle import gnn_layers as og
 

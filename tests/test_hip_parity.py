@@ -53,10 +53,13 @@ def factorise(request):
     from neural_lam_amd import gnn_layers as hl
 
     old = hl.FACTORISE_MIN_EDGES
+    old_w = hl.FACTORISE_MIN_WORK_WIDE
+    hl.FACTORISE_MIN_WORK_WIDE = 0   # widths above 64: factorised wherever the super-tile kernels apply (the "wbf" family at test sizes)
     if request.param == "factorised":
         hl.FACTORISE_MIN_EDGES = 0
     yield request.param
     hl.FACTORISE_MIN_EDGES = old
+    hl.FACTORISE_MIN_WORK_WIDE = old_w
 
 
 LAYER_CASES = [
@@ -771,7 +774,8 @@ def test_graph_step_falls_back_to_eager_for_another_batch_shape(dev, tmp_path):
     assert torch.equal(tg.fp.flat, te.fp.flat)
 
 
-@pytest.mark.parametrize("k,n,rows,batched", [(64, 64, 6561, False), (32, 64, 100, True), (64, 32, 33, False), (32, 32, 1, False)])
+@pytest.mark.parametrize("k,n,rows,batched", [(64, 64, 6561, False), (32, 64, 100, True), (64, 32, 33, False), (32, 32, 1, False),
+                                              (256, 256, 6561, False), (128, 128, 70, True), (512, 512, 300, False)])
 def test_node_linear_matches_torch(dev, k, n, rows, batched):
     """nlam_linear through NodeLinearFunction: x @ W1[:, col0:col0+k].T, its data gradient and the strided weight
     gradient (only the addressed column block of W1.grad is written)."""
@@ -792,6 +796,26 @@ def test_node_linear_matches_torch(dev, k, n, rows, batched):
     assert rel_err(x.grad.double().cpu(), xr.grad.cpu()) < 1e-5
     assert rel_err(W.grad.double().cpu(), Wr.grad.cpu()) < 1e-5
     assert float(W.grad[:, :col0].abs().max()) == 0.0 and float(W.grad[:, col0 + k :].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("d,rows", [(128, 6561), (256, 45)])
+def test_node_linear_pair_matches_torch(dev, d, rows):
+    """Both node-level products of a mesh <-> mesh layer in one launch (nlam_linear with W2 / out2)."""
+    from neural_lam_amd.ops import NodeLinearPairFunction
+
+    torch.manual_seed(4)
+    W = torch.randn(d, 3 * d, device=dev, requires_grad=True)
+    x = torch.randn(2, rows, d, device=dev, requires_grad=True)
+    pj, pi = NodeLinearPairFunction.apply(x, W, d, 2 * d)
+    cj, ci = torch.randn_like(pj), torch.randn_like(pi)
+    ((pj * cj).sum() + (pi * ci).sum()).backward()
+    xr, Wr = x.detach().double().requires_grad_(), W.detach().double().requires_grad_()
+    rj, ri = xr @ Wr[:, d : 2 * d].T, xr @ Wr[:, 2 * d :].T
+    ((rj * cj.double()).sum() + (ri * ci.double()).sum()).backward()
+    assert rel_err(pj.double().cpu(), rj.cpu()) < 1e-5 and rel_err(pi.double().cpu(), ri.cpu()) < 1e-5
+    assert rel_err(x.grad.double().cpu(), xr.grad.cpu()) < 1e-5
+    assert rel_err(W.grad.double().cpu(), Wr.grad.cpu()) < 1e-5
+    assert float(W.grad[:, :d].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("hidden_layers", [0, 2, 3])
