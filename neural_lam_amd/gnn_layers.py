@@ -43,6 +43,10 @@ FACTORISE_MIN_EDGES = int(os.environ.get("NLAM_FACTORISE_MIN_EDGES", str(1 << 30
 # everything is factorised), on the edge sets the split-bf16 super-tile kernels take (nlam_pre_add_supported).
 FACTORISE_MIN_EDGES_WIDE = int(os.environ.get("NLAM_FACTORISE_MIN_EDGES_WIDE", "0"))
 FACTORISE_MIN_WORK_WIDE = int(os.environ.get("NLAM_FACTORISE_MIN_WORK_WIDE", "14000000"))
+# d = 128 (cfg4, Hi-LAM): the one qualifying edge set (m2g) is faster in isolation (forward 328 -> 245 us, backward 401 ->
+# 297 us) but the captured step measured slower with it (12.3 -> 13.4 ms, reproducibly; equal under the profiler), so the
+# factorised path starts at d = 256
+FACTORISE_MIN_WIDTH_WIDE = int(os.environ.get("NLAM_FACTORISE_MIN_WIDTH_WIDE", "256"))
 
 
 class FusedMLP(nn.Sequential):
@@ -329,7 +333,7 @@ class InteractionNet(nn.Module):
         wide = max(d, hid, dout) > 64
         if self.propagates_sender or csr.num_edges < (FACTORISE_MIN_EDGES_WIDE if wide else FACTORISE_MIN_EDGES):
             return False
-        if wide and csr.num_edges * max(d, hid) < FACTORISE_MIN_WORK_WIDE:
+        if wide and (csr.num_edges * max(d, hid) < FACTORISE_MIN_WORK_WIDE or max(d, hid) < FACTORISE_MIN_WIDTH_WIDE):
             return False
         mm = ops._mm_flags()
         if (mm >> 8) & 3 == 0 or send_rep.shape[-1] != d or rec_rep.shape[-1] != d:

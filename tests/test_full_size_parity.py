@@ -67,10 +67,12 @@ def wide_factorise(request):
 
     old, old_w = hl.FACTORISE_MIN_EDGES_WIDE, hl.FACTORISE_MIN_WORK_WIDE
     hl.FACTORISE_MIN_WORK_WIDE = 0
+    hl.FACTORISE_MIN_WIDTH_WIDE = 0
     if request.param == "plain":
         hl.FACTORISE_MIN_EDGES_WIDE = 1 << 30
     yield request.param
     hl.FACTORISE_MIN_EDGES_WIDE, hl.FACTORISE_MIN_WORK_WIDE = old, old_w
+    hl.FACTORISE_MIN_WIDTH_WIDE = 256
 
 
 LAYERS = [

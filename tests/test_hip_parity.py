@@ -54,12 +54,14 @@ def factorise(request):
 
     old = hl.FACTORISE_MIN_EDGES
     old_w = hl.FACTORISE_MIN_WORK_WIDE
+    hl.FACTORISE_MIN_WIDTH_WIDE = 0
     hl.FACTORISE_MIN_WORK_WIDE = 0   # widths above 64: factorised wherever the super-tile kernels apply (the "wbf" family at test sizes)
     if request.param == "factorised":
         hl.FACTORISE_MIN_EDGES = 0
     yield request.param
     hl.FACTORISE_MIN_EDGES = old
     hl.FACTORISE_MIN_WORK_WIDE = old_w
+    hl.FACTORISE_MIN_WIDTH_WIDE = 256
 
 
 LAYER_CASES = [
