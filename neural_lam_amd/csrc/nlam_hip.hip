@@ -2344,15 +2344,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* parti
 
 // several partial-sum reductions in one launch (blockIdx.y = job): the weight and vector
 // gradients of one fused-MLP backward, optionally accumulated straight into the flat gradient buffer.
-// The partials of one step add up to several hundred MB at cfg2 (up to 512 x 48 KB per edge MLP): lanes read
-// 16 B each (a wave = 1 KiB of one partial per load), the block's 4 waves split the parts, fixed summation order.
-__global__ __launch_bounds__(256) void reduce_jobs_kernel(const nlam_reduce_jobs_t jobs) {
-    __shared__ f32x4 red[4][64];
+// The partials of one step add up to hundreds of MB at cfg2 (up to 512 x 48 KB per edge MLP) and every launch is a
+// latency chain of dependent loads: a workgroup is 16 waves, wave w sums its slice of the parts with up to eight 16-byte
+// loads per lane in flight, the slices are combined through LDS in wave order (fixed summation order: deterministic).
+constexpr int kRedWaves = 16;
+__global__ __launch_bounds__(kRedWaves * 64) void reduce_jobs_kernel(const nlam_reduce_jobs_t jobs) {
+    __shared__ f32x4 red[kRedWaves][64];
     if ((int)blockIdx.y >= jobs.njobs) return;
     const nlam_reduce_job_t jb = jobs.job[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = (jb.nparts + 3) / 4;
-    const int q0 = wave * per, q1 = min(jb.nparts, q0 + per);
+    const int per = (jb.nparts + kRedWaves - 1) / kRedWaves;
+    const int q0 = min(jb.nparts, wave * per), q1 = min(jb.nparts, q0 + per);
     const bool vec = ((jb.n | (int)(jb.stride & 3) | jb.ncols | jb.ld) & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(jb.partials) | reinterpret_cast<uintptr_t>(jb.out)) & 15) == 0;
     if (vec) {
@@ -2362,19 +2364,20 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(const nlam_reduce_jobs
             if (idx < jb.n) {
                 const float* pp = jb.partials + idx;
                 int q = q0;
-                for (; q + 4 <= q1; q += 4) {   // four independent loads in flight per lane
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(pp + (size_t)q * jb.stride);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(pp + (size_t)(q + 1) * jb.stride);
-                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(pp + (size_t)(q + 2) * jb.stride);
-                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(pp + (size_t)(q + 3) * jb.stride);
-                    s += (v0 + v1) + (v2 + v3);
+                for (; q + 8 <= q1; q += 8) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)(q + u) * jb.stride);
+                    s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                 }
                 for (; q < q1; ++q) s += *reinterpret_cast<const f32x4*>(pp + (size_t)q * jb.stride);
             }
             red[wave][lane] = s;
             __syncthreads();
             if (wave == 0 && idx < jb.n) {
-                f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+                f32x4 t = red[0][lane];
+#pragma unroll
+                for (int w = 1; w < kRedWaves; ++w) t += red[w][lane];
                 float* o = jb.out + (jb.ncols > 0 ? (size_t)(idx / jb.ncols) * jb.ld + idx % jb.ncols : (size_t)idx);   // ncols % 4 == 0 here
                 if (jb.accumulate) t += *reinterpret_cast<const f32x4*>(o);
                 *reinterpret_cast<f32x4*>(o) = t;
@@ -2394,7 +2397,9 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(const nlam_reduce_jobs
         redf[wave * 64 + lane] = s;
         __syncthreads();
         if (wave == 0 && idx < jb.n) {
-            const float t = (redf[lane] + redf[64 + lane]) + (redf[128 + lane] + redf[192 + lane]);
+            float t = redf[lane];
+#pragma unroll
+            for (int w = 1; w < kRedWaves; ++w) t += redf[w * 64 + lane];
             float* o = jb.out + (jb.ncols > 0 ? (size_t)(idx / jb.ncols) * jb.ld + idx % jb.ncols : (size_t)idx);
             *o = jb.accumulate ? *o + t : t;
         }
@@ -2464,19 +2469,23 @@ __global__ __launch_bounds__(256) void step_tail_fwd_kernel(const float* __restr
                                                             float* __restrict__ partials, long total, int nodes, int width) {
     __shared__ float red[4];
     float s = 0.f;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long r = e / width;
-        const int f = (int)(e - r * width);
-        const int n = (int)(r % nodes);
-        float nw = prev[e] + (dstd != nullptr ? delta[e] * dstd[f] : delta[e]);
-        if (dmean != nullptr) nw += dmean[f];
-        const float bm = bmask[n];
-        const float pv = bm * truth[e] + (1.f - bm) * nw;
-        pred[e] = pv;
-        const float w = row_weight[n];
-        if (w != 0.f) {
-            const float d = pv - target[e];
-            s += w * inv_var[f] * d * d;
+    // a block walks whole 256-element spans; (row, variable) of the first element by one division per span, then incrementally
+    for (long e0 = (long)blockIdx.x * blockDim.x; e0 < total; e0 += (long)gridDim.x * blockDim.x) {
+        const long e = e0 + threadIdx.x;
+        if (e < total) {
+            const long r = e / width;
+            const int f = (int)(e - r * width);
+            const int n = (int)(r % nodes);
+            float nw = prev[e] + (dstd != nullptr ? delta[e] * dstd[f] : delta[e]);
+            if (dmean != nullptr) nw += dmean[f];
+            const float bm = bmask[n];
+            const float pv = bm * truth[e] + (1.f - bm) * nw;
+            pred[e] = pv;
+            const float w = row_weight[n];
+            if (w != 0.f) {
+                const float d = pv - target[e];
+                s += w * inv_var[f] * d * d;
+            }
         }
     }
 #pragma unroll
@@ -2504,23 +2513,33 @@ __global__ void step_tail_bwd_kernel(const float* __restrict__ g_pred, const flo
     }
 }
 
-// row-wise concatenation (nlam_concat): thread -> one output element; consecutive threads walk along a row
-__global__ void concat_kernel(const nlam_cat_t p, int wtot) {
-    const long total = (long)p.batch * p.nodes * wtot;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long r = e / wtot;
-        int c = (int)(e - r * wtot);
-        const int b = (int)(r / p.nodes);
-        const int n = (int)(r - (long)b * p.nodes);
-        float v = 0.f;
+// row-wise concatenation (nlam_concat): a workgroup owns 64 consecutive rows; every source's 64 x w_k block is one
+// contiguous span in memory (read coalesced into the LDS row image), and so is the 64 x wtot output block
+constexpr int kCatRows = 64;
+__global__ __launch_bounds__(256) void concat_kernel(const nlam_cat_t p, int wtot) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const long ntile = ((long)p.nodes + kCatRows - 1) / kCatRows;
+    for (long tb = blockIdx.x; tb < ntile * p.batch; tb += gridDim.x) {
+        const int b = (int)(tb / ntile);
+        const long n0 = (tb % ntile) * kCatRows;
+        const int nr = (int)min((long)kCatRows, p.nodes - n0);
+        int off = 0;
 #pragma unroll
         for (int k = 0; k < NLAM_MAX_CAT; ++k) {
             if (k < p.nsrc) {
-                if (c >= 0 && c < p.width[k]) v = p.ptr[k][(long)b * p.bstride[k] + (long)n * p.width[k] + c];
-                c -= p.width[k];
+                const int w = p.width[k];
+                const float* src = p.ptr[k] + (long)b * p.bstride[k] + n0 * w;
+                for (int e = threadIdx.x; e < nr * w; e += blockDim.x) {
+                    const int r = e / w;
+                    smem[r * wtot + off + (e - r * w)] = src[e];
+                }
+                off += w;
             }
         }
-        p.out[e] = v;
+        __syncthreads();
+        float* dst = p.out + ((long)b * p.nodes + n0) * wtot;
+        for (int e = threadIdx.x; e < nr * wtot; e += blockDim.x) dst[e] = smem[e];
+        __syncthreads();
     }
 }
 
@@ -3604,7 +3623,7 @@ int32_t nlam_reduce_jobs(const nlam_reduce_jobs_t* jobs, void* hip_stream) {
     }
     int blocks = (nmax + 255) / 256;   // 256 elements per block and pass on the 16-B path (the scalar path strides by gridDim.x * 64)
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(reduce_jobs_kernel, dim3(blocks, jobs->njobs), dim3(256), 0, (hipStream_t)hip_stream, *jobs);
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3(blocks, jobs->njobs), dim3(kRedWaves * 64), 0, (hipStream_t)hip_stream, *jobs);
     return (int32_t)hipGetLastError();
 }
 
@@ -3678,10 +3697,10 @@ int32_t nlam_concat(const nlam_cat_t* p, void* hip_stream) {
         wtot += p->width[k];
     }
     if (p->nodes == 0 || wtot == 0) return 0;
-    const long total = (long)p->batch * p->nodes * wtot;
-    long blocks = (total + 255) / 256;
+    if ((size_t)kCatRows * wtot * sizeof(float) > 48 * 1024) return NLAM_EUNSUP;   // rows wider than 192 floats: not a grid feature concat
+    long blocks = (long)p->batch * (((long)p->nodes + kCatRows - 1) / kCatRows);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(concat_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, *p, wtot);
+    hipLaunchKernelGGL(concat_kernel, dim3((int)blocks), dim3(256), (size_t)kCatRows * wtot * sizeof(float), (hipStream_t)hip_stream, *p, wtot);
     return (int32_t)hipGetLastError();
 }
 
