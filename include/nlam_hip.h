@@ -218,6 +218,18 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p);
 
 int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream);
 int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream);
+
+/* GROUPED launches: n <= NLAM_MAX_GROUP independent fused MLPs of the same kernel shape in ONE grid (every workgroup is
+ * bound to one member, the 256 workgroups are dealt in proportion to the members' tile counts).  For the embedders of
+ * the static grid / mesh / edge features (utils.make_mlp blocks called back to back at graph/base.py:286-295,
+ * hierarchical.py:195-231): as separate launches each is a latency-bound chain link.  Covered: single-source members
+ * without residual / aggregation whose widths share the 32-column block counts, split-bf16 matrix modes, hid and dout
+ * <= 64 (NLAM_EUNSUP otherwise: launch the members one by one).  nlam_mlp_group_blocks gives the workgroups each
+ * member gets: member k of the backward writes blocks[k] rows of its vec_partials. */
+#define NLAM_MAX_GROUP 8
+int32_t nlam_mlp_group_blocks(const int64_t* tiles, int32_t n, int32_t* blocks);
+int32_t nlam_mlp_fwd_group(const nlam_mlp_fwd_t* ps, int32_t n, void* hip_stream);
+int32_t nlam_mlp_bwd_group(const nlam_mlp_bwd_t* ps, int32_t n, void* hip_stream);
 int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream);
 
 /* out[b, s, :] = scale(s) * sum_{q in [ptr[s], ptr[s+1])} in[b, order[q], :]   (order NULL = q) */

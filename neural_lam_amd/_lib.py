@@ -15,6 +15,7 @@ HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["NLAM_LIB"]) if os.environ.get("NLAM_LIB") else HERE / "libnlam_hip.so"
 
 NLAM_MAX_SRC = 3
+NLAM_MAX_GROUP = 8
 F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD = 1, 2, 4, 8, 16
 TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning keys (include/nlam_hip.h)
 TUNE_WGRAD_CHUNKS = 2
@@ -42,6 +43,9 @@ EXPORTS = [
     "nlam_wmse_bwd",
     "nlam_adamw_step",
     "nlam_standardize",
+    "nlam_mlp_group_blocks",
+    "nlam_mlp_fwd_group",
+    "nlam_mlp_bwd_group",
     "nlam_linear",
     "nlam_pre_add_supported",
     "nlam_step_tail_fwd",
@@ -282,6 +286,12 @@ def load():
     lib.nlam_step_tail_bwd.restype = i32
     lib.nlam_concat.argtypes = [C.POINTER(Cat), vp]
     lib.nlam_concat.restype = i32
+    lib.nlam_mlp_group_blocks.argtypes = [C.POINTER(C.c_int64), i32, C.POINTER(C.c_int32)]
+    lib.nlam_mlp_group_blocks.restype = i32
+    lib.nlam_mlp_fwd_group.argtypes = [C.POINTER(MlpFwd), i32, vp]
+    lib.nlam_mlp_fwd_group.restype = i32
+    lib.nlam_mlp_bwd_group.argtypes = [C.POINTER(MlpBwd), i32, vp]
+    lib.nlam_mlp_bwd_group.restype = i32
     lib.nlam_pre_add_supported.argtypes = [C.POINTER(MlpFwd)]
     lib.nlam_pre_add_supported.restype = i32
     lib.nlam_linear.argtypes = [C.POINTER(Linear), vp]

@@ -454,6 +454,9 @@ __device__ __forceinline__ void mma_split_lds(f32x16 (&acc)[NB], const u32x4* Wp
 template <int NS>
 __device__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2, long ldk = 1,
                             int Kpad = 0) {
+#ifdef NLAM_EXPERIMENT_NOSTAGE   // tools/ab experiments only: how much of a launch is weight staging (results are garbage)
+    return;
+#endif
     const int nst = (Kpad > 0 ? Kpad : K) >> 4;   // steps written (columns k >= K are zero)
     const int total = MB * nst * 64;
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
@@ -884,8 +887,11 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
 // would queue behind the tile's stores)
 // PRE (NLAM_F_PRE_ADD, the factorised edge MLP): only source 0 goes through GEMM1; sources 1.. are gathered
 // pre-activation addends of width hid, fetched in accumulator ("chunk") layout a tile ahead and added to GEMM1's result.
+// The kernel body takes its workgroup index and grid size as arguments: the plain launch passes blockIdx.x / gridDim.x,
+// the GROUPED launch (nlam_mlp_fwd_group: several independent same-shape MLPs in one grid, each workgroup bound to one
+// member -- the embedders of the static graph features) passes the member-local ones.
 template <int HB, int OB, int NS, bool RAG, bool RES, bool PRE = false>
-__global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_fwd_t p) {
+__device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const int wg_id, const int wg_count) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int DPH = HB * 32, OP = OB * 32;
     constexpr int S2 = DPH / 16;
@@ -943,8 +949,8 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
 
     const int nwaves = blockDim.x >> 6;
     const long total_tiles = (long)p.ntiles * p.batch;
-    const long stride = (long)gridDim.x * nwaves;
-    long gt = (long)wave * gridDim.x + blockIdx.x;   // workgroup index fastest (see mlp_fwd_kernel)
+    const long stride = (long)wg_count * nwaves;
+    long gt = (long)wave * wg_count + wg_id;   // workgroup index fastest (see mlp_fwd_kernel)
 
     auto tile_of = [&](long g, int& b_out) -> TileInfo {
         b_out = (int)(g / p.ntiles);
@@ -1257,6 +1263,26 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_
     NLAM_T_DRAIN
     NLAM_T_MARK(7)
     NLAM_T_FLUSH(t_ntiles_)
+}
+
+template <int HB, int OB, int NS, bool RAG, bool RES, bool PRE = false>
+__global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_fwd_t p) {
+    mlp_fwd_bf_body<HB, OB, NS, RAG, RES, PRE>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+struct fwd_group_t {
+    nlam_mlp_fwd_t g[NLAM_MAX_GROUP];
+    int n;
+    int first[NLAM_MAX_GROUP + 1];   // first workgroup of each member; first[n] = grid size
+};
+
+template <int HB, int OB, int NS>
+__global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_group_kernel(const fwd_group_t G) {
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < NLAM_MAX_GROUP; ++k)
+        if (k < G.n && (int)blockIdx.x >= G.first[k]) gi = k;
+    mlp_fwd_bf_body<HB, OB, NS, true, false, false>(G.g[gi], (int)blockIdx.x - G.first[gi], G.first[gi + 1] - G.first[gi]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1585,7 +1611,7 @@ __device__ __forceinline__ float block_colsum_half(const float* stg, int lane) {
 }
 
 template <int HB, int OB, int NS>
-__global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_mlp_bwd_t p) {
+__device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const int wg_id, const int wg_count) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int DPH = HB * 32, OP = OB * 32;
     constexpr int NSW = NS > 0 ? NS : 1;
@@ -1658,7 +1684,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
     for (int k = 0; k < 8; ++k) colacc[k * 64] = 0.f;
 
     const long total_tiles = (long)p.ntiles * p.batch;
-    for (long gt = (long)wave * gridDim.x + blockIdx.x; gt < total_tiles; gt += (long)gridDim.x * kWavesPerBlock) {
+    for (long gt = (long)wave * wg_count + wg_id; gt < total_tiles; gt += (long)wg_count * kWavesPerBlock) {
         const int b = (int)(gt / p.ntiles);
         const TileInfo tl = get_tile(p.tiles, (int)(gt % p.ntiles), p.rows);
         const bool valid = j < tl.nrows;
@@ -1938,9 +1964,29 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < kWavesPerBlock; ++w) s += red[(w * 4 + wave) * 64 + lane];
-            p.vec_partials[((size_t)blockIdx.x * 4 + wave) * p.vec_stride + lane] = s;
+            p.vec_partials[((size_t)wg_id * 4 + wave) * p.vec_stride + lane] = s;
         }
     }
+}
+
+template <int HB, int OB, int NS>
+__global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_mlp_bwd_t p) {
+    mlp_bwd_fast_body<HB, OB, NS>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+struct bwd_group_t {
+    nlam_mlp_bwd_t g[NLAM_MAX_GROUP];
+    int n;
+    int first[NLAM_MAX_GROUP + 1];
+};
+
+template <int HB, int OB, int NS>
+__global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_group_kernel(const bwd_group_t G) {
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < NLAM_MAX_GROUP; ++k)
+        if (k < G.n && (int)blockIdx.x >= G.first[k]) gi = k;
+    mlp_bwd_fast_body<HB, OB, NS>(G.g[gi], (int)blockIdx.x - G.first[gi], G.first[gi + 1] - G.first[gi]);
 }
 
 // ---------------------------------------------------------------------------
@@ -2906,6 +2952,20 @@ int wgrad_windows_of(const nlam_wgrad_t* p, int winm, int winn) {
 
 int wgrad_windows(const nlam_wgrad_t* p) { return wgrad_windows_of(p, kWWin, kWWin); }
 
+// workgroups of a grouped launch: kMaxGridBlocks dealt in proportion to the members' tiles, at least one each and never
+// more than a member has tiles
+void group_blocks(const long* tiles, int n, int* blocks) {
+    long tot = 0;
+    for (int k = 0; k < n; ++k) tot += tiles[k] < 1 ? 1 : tiles[k];
+    for (int k = 0; k < n; ++k) {
+        const long t = tiles[k] < 1 ? 1 : tiles[k];
+        long b = tot <= kMaxGridBlocks ? t : (t * kMaxGridBlocks) / tot;
+        if (b < 1) b = 1;
+        if (b > t) b = t;
+        blocks[k] = (int)b;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -3333,6 +3393,117 @@ int32_t nlam_detail::bwd_wide(const nlam_mlp_bwd_t* p, hipStream_t stream) {
         else NLAM_LAUNCH_BWD_WIDE(8, 2);
         return (int32_t)hipGetLastError();
     }
+}
+#endif
+
+#if NLAM_IN_TU(1)
+extern "C" {
+
+int32_t nlam_mlp_group_blocks(const int64_t* tiles, int32_t n, int32_t* blocks) {
+    if (tiles == nullptr || blocks == nullptr || n < 1 || n > NLAM_MAX_GROUP) return NLAM_EINVAL;
+    long t[NLAM_MAX_GROUP];
+    for (int k = 0; k < n; ++k) t[k] = (long)tiles[k];
+    group_blocks(t, n, blocks);
+    return 0;
+}
+
+int32_t nlam_mlp_fwd_group(const nlam_mlp_fwd_t* ps, int32_t n, void* hip_stream) {
+    if (ps == nullptr || n < 1 || n > NLAM_MAX_GROUP) return NLAM_EINVAL;
+    const int HB = (ps[0].hid + 31) / 32, OB = (ps[0].dout + 31) / 32;
+    const int ns = (int)((ps[0].flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
+    if (ns == 0 || HB != OB || HB > 2) return NLAM_EUNSUP;
+    fwd_group_t G;
+    long tiles[NLAM_MAX_GROUP];
+    size_t lds = 0;
+    for (int k = 0; k < n; ++k) {
+        const nlam_mlp_fwd_t& p = ps[k];
+        if (p.W1 == nullptr || p.W2 == nullptr || p.batch < 1 || p.rows < 1 || p.out == nullptr) return NLAM_EINVAL;
+        // same kernel instantiation for every member: one source of at most 64 columns, whole output blocks, no residual /
+        // aggregation / scatter, the same matrix mode
+        if (p.nsrc != 1 || fwd_is_wide(&p) || p.hid != ps[0].hid || p.dout != ps[0].dout || p.hid % 32 != 0 || p.dout % 32 != 0) return NLAM_EUNSUP;
+        if ((p.flags & ~NLAM_F_MM_MASK) != 0 || (p.flags & NLAM_F_MM_MASK) != (ps[0].flags & NLAM_F_MM_MASK)) return NLAM_EUNSUP;
+        if (p.aggr != nullptr || p.out_idx != nullptr || p.src[0].idx != nullptr || p.tiles != nullptr) return NLAM_EUNSUP;
+        if ((p.ln_w == nullptr) != (ps[0].ln_w == nullptr)) return NLAM_EUNSUP;
+        G.g[k] = p;
+        tiles[k] = (long)p.ntiles * p.batch;
+        const size_t l = fwd_lds_bytes(&p, HB, OB, ns);
+        if (l > lds) lds = l;
+    }
+    int blocks[NLAM_MAX_GROUP];
+    group_blocks(tiles, n, blocks);
+    G.n = n;
+    G.first[0] = 0;
+    for (int k = 0; k < n; ++k) G.first[k + 1] = G.first[k] + blocks[k];
+    for (int k = n + 1; k <= NLAM_MAX_GROUP; ++k) G.first[k] = G.first[n];
+    hipStream_t stream = (hipStream_t)hip_stream;
+#define NLAM_LAUNCH_FWDG(HB_, NS_)                                                                                         \
+    do {                                                                                                                   \
+        int rc = set_lds(mlp_fwd_bf_group_kernel<HB_, HB_, NS_>, lds);                                                     \
+        if (rc != 0) return rc;                                                                                            \
+        hipLaunchKernelGGL((mlp_fwd_bf_group_kernel<HB_, HB_, NS_>), dim3(G.first[n]), dim3(kFwdThreads), lds, stream, G); \
+    } while (0)
+    if (HB == 1) {
+        if (ns == 3) NLAM_LAUNCH_FWDG(1, 3);
+        else if (ns == 2) NLAM_LAUNCH_FWDG(1, 2);
+        else NLAM_LAUNCH_FWDG(1, 1);
+    } else {
+        if (ns == 3) NLAM_LAUNCH_FWDG(2, 3);
+        else if (ns == 2) NLAM_LAUNCH_FWDG(2, 2);
+        else NLAM_LAUNCH_FWDG(2, 1);
+    }
+    return (int32_t)hipGetLastError();
+}
+
+}  // extern "C"
+#endif
+
+#if NLAM_IN_TU(2)
+extern "C" int32_t nlam_mlp_bwd_group(const nlam_mlp_bwd_t* ps, int32_t n, void* hip_stream) {
+    if (ps == nullptr || n < 1 || n > NLAM_MAX_GROUP) return NLAM_EINVAL;
+    const int HB = (ps[0].hid + 31) / 32, OB = (ps[0].dout + 31) / 32;
+    const int ns = (int)((ps[0].flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
+    if (ns == 0 || HB != OB || HB > 2) return NLAM_EUNSUP;
+    bwd_group_t G;
+    long tiles[NLAM_MAX_GROUP];
+    size_t lds = 0;
+    int blocks[NLAM_MAX_GROUP];
+    for (int k = 0; k < n; ++k) {
+        const nlam_mlp_bwd_t& p = ps[k];
+        if (p.W1 == nullptr || p.W2 == nullptr || p.z1 == nullptr || p.batch < 1 || p.rows < 1 || p.g_out == nullptr) return NLAM_EINVAL;
+        if (p.nsrc != 1 || bwd_is_wide(&p) || p.hid != ps[0].hid || p.dout != ps[0].dout || p.hid % 32 != 0 || p.dout % 32 != 0) return NLAM_EUNSUP;
+        if ((p.flags & ~NLAM_F_MM_MASK) != 0 || (p.flags & NLAM_F_MM_MASK) != (ps[0].flags & NLAM_F_MM_MASK)) return NLAM_EUNSUP;
+        if (p.g_aggr != nullptr || p.out_idx != nullptr || p.tiles != nullptr || p.dmode[0] != 0) return NLAM_EUNSUP;   // leaf MLPs: no data gradient
+        if ((p.ln_w == nullptr) != (ps[0].ln_w == nullptr)) return NLAM_EUNSUP;
+        G.g[k] = p;
+        tiles[k] = (long)p.ntiles * p.batch;
+        const size_t l = bwd_fast_lds_bytes(&p, HB, OB, ns);
+        if (l > lds) lds = l;
+    }
+    group_blocks(tiles, n, blocks);
+    G.n = n;
+    G.first[0] = 0;
+    for (int k = 0; k < n; ++k) {
+        if (ps[k].vec_partials != nullptr && ps[k].vec_partials_rows < blocks[k]) return NLAM_EINVAL;
+        G.first[k + 1] = G.first[k] + blocks[k];
+    }
+    for (int k = n + 1; k <= NLAM_MAX_GROUP; ++k) G.first[k] = G.first[n];
+    hipStream_t stream = (hipStream_t)hip_stream;
+#define NLAM_LAUNCH_BWDG(HB_, NS_)                                                                                             \
+    do {                                                                                                                       \
+        int rc = set_lds(mlp_bwd_fast_group_kernel<HB_, HB_, NS_>, lds);                                                       \
+        if (rc != 0) return rc;                                                                                                \
+        hipLaunchKernelGGL((mlp_bwd_fast_group_kernel<HB_, HB_, NS_>), dim3(G.first[n]), dim3(kBlockThreads), lds, stream, G); \
+    } while (0)
+    if (HB == 1) {
+        if (ns == 3) NLAM_LAUNCH_BWDG(1, 3);
+        else if (ns == 2) NLAM_LAUNCH_BWDG(1, 2);
+        else NLAM_LAUNCH_BWDG(1, 1);
+    } else {
+        if (ns == 3) NLAM_LAUNCH_BWDG(2, 3);
+        else if (ns == 2) NLAM_LAUNCH_BWDG(2, 2);
+        else NLAM_LAUNCH_BWDG(2, 1);
+    }
+    return (int32_t)hipGetLastError();
 }
 #endif
 

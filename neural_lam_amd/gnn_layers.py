@@ -124,6 +124,33 @@ class FusedMLP(nn.Sequential):
         return FusedMLPFunction.apply(geom, *self.params(), *srcs)
 
 
+def grouped_mlp_forward(pairs):
+    """``[mlp(x) for mlp, x in pairs]`` for independent MLPs of data inputs (static feature embedders), as grouped launches of
+    up to 8 members (ops.GroupedMLPFunction) where the members are one-kernel MLPs of the same shape on GPU tensors."""
+    def ok(m, x):
+        return (isinstance(m, FusedMLP) and m.fully_fused and x.is_cuda and x.dim() == 2 and not x.requires_grad
+                and x.dtype == torch.float32)
+
+    outs = [None] * len(pairs)
+    classes = {}
+    for i, (m, x) in enumerate(pairs):
+        if ok(m, x):
+            classes.setdefault((m[0].out_features, m[2].out_features, m.has_layer_norm), []).append(i)
+        else:
+            outs[i] = m(x)
+    for idxs in classes.values():
+        for c0 in range(0, len(idxs), 8):
+            chunk = idxs[c0 : c0 + 8]
+            if len(chunk) == 1:
+                outs[chunk[0]] = pairs[chunk[0]][0](pairs[chunk[0]][1])
+                continue
+            flat = [q for i in chunk for q in pairs[i][0].params()]
+            res = ops.GroupedMLPFunction.apply(len(chunk), *flat, *[pairs[i][1] for i in chunk])
+            for i, r in zip(chunk, res):
+                outs[i] = r
+    return outs
+
+
 def make_mlp(blueprint, layer_norm: bool = True) -> FusedMLP:
     """utils/networks.py:8-40."""
     return FusedMLP(blueprint, layer_norm=layer_norm)

@@ -233,8 +233,39 @@ class BaseGraphModel(StepPredictor):
             ("m2g", lambda: self.m2g_embedder(self.m2g_features)),
         ]
 
+    def static_embedding_specs(self):
+        """(key, mlp | [mlps], features | [features]) in the order the step needs them: the embedders of the static
+        features are independent of each other and of the input, so they run as grouped launches."""
+        return [
+            ("mesh", *self.mesh_embedding_spec()),
+            ("g2m", self.g2m_embedder, self.g2m_features),
+            ("m2g", self.m2g_embedder, self.m2g_features),
+        ]
+
     def compute_static_embeddings(self) -> dict:
-        return {k: f() for k, f in self.static_embedding_items()}
+        from .gnn_layers import grouped_mlp_forward
+
+        specs = self.static_embedding_specs()
+        pairs, slots = [], []
+        for key, mlps, feats in specs:
+            if isinstance(mlps, (list, tuple, nn.ModuleList)):
+                for i, (m_, f_) in enumerate(zip(mlps, feats)):
+                    pairs.append((m_, f_))
+                    slots.append((key, i))
+            else:
+                pairs.append((mlps, feats))
+                slots.append((key, None))
+        outs = grouped_mlp_forward(pairs)
+        st = {}
+        for (key, i), o in zip(slots, outs):
+            if i is None:
+                st[key] = o
+            else:
+                st.setdefault(key, []).append(o)
+        for key, mlps, _ in specs:   # empty lists (a one-level hierarchy has no up / down embedders)
+            if isinstance(mlps, (list, tuple, nn.ModuleList)) and key not in st:
+                st[key] = []
+        return st
 
     @contextlib.contextmanager
     def static_cache(self):
@@ -318,9 +349,16 @@ class GraphLAM(BaseGraphModel):
     def embedd_mesh_nodes(self):
         return self.mesh_embedder(self.mesh_static_features)
 
+    def mesh_embedding_spec(self):
+        return self.mesh_embedder, self.mesh_static_features
+
     def static_embedding_items(self):
         items = super().static_embedding_items()
         return items[:2] + [("m2m", lambda: self.m2m_embedder(self.m2m_features))] + items[2:]
+
+    def static_embedding_specs(self):
+        specs = super().static_embedding_specs()
+        return specs[:2] + [("m2m", self.m2m_embedder, self.m2m_features)] + specs[2:]
 
     def process_step(self, mesh_rep, st=None):
         B = mesh_rep.shape[0]
@@ -364,6 +402,19 @@ class BaseHiGraphModel(BaseGraphModel):
 
     def embedd_mesh_nodes(self):
         return self.mesh_embedders[0](self.mesh_static_features[0])
+
+    def mesh_embedding_spec(self):
+        return self.mesh_embedders[0], self.mesh_static_features[0]
+
+    def static_embedding_specs(self):
+        specs = super().static_embedding_specs()
+        mine = [
+            ("levels", list(self.mesh_embedders)[1:], list(self.mesh_static_features[1:])),
+            ("up", list(self.mesh_up_embedders), list(self.mesh_up_features)),
+            ("same", list(self.mesh_same_embedders), list(self.m2m_features)),
+            ("down", list(self.mesh_down_embedders), list(self.mesh_down_features)),
+        ]
+        return specs[:2] + mine + specs[2:]
 
     def static_embedding_items(self):
         items = super().static_embedding_items()

@@ -936,6 +936,153 @@ def _chunk_weight_grads(lib, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, ve
     return results
 
 
+class GroupedMLPFunction(torch.autograd.Function):
+    """n <= 8 independent single-source fused MLPs of one shape -- the embedders of the static grid / mesh / edge features
+    (graph/base.py:286-295, hierarchical.py:195-231) -- in ONE launch each way (nlam_mlp_fwd_group / nlam_mlp_bwd_group):
+    as separate launches each is a latency-bound link of the step's critical chain (4 x 14-50 us forward and 4 x 21-86 us
+    at the very end of backward at cfg2).  Their inputs are data (no input gradients).  Shapes the grouped kernels do not
+    cover run as a loop of single launches inside the same Function.
+
+    forward(n, [W1, b1, W2, b2, ln_w, ln_b] * n, *xs) -> n outputs."""
+
+    @staticmethod
+    def forward(ctx, n: int, *flat):
+        lib = L.load()
+        params = [flat[6 * k : 6 * k + 6] for k in range(n)]
+        xs = flat[6 * n :]
+        assert len(xs) == n
+        mm_flags = _mm_flags()
+        xs = tuple(x if x.dtype == torch.float32 else x.float() for x in xs)
+        _require_gpu(*[q for pr in params for q in pr], *xs)
+        need_grad = any(ctx.needs_input_grad[1 : 1 + 6 * n])
+        dev = xs[0].device
+        arr = (L.MlpFwd * n)()
+        outs, saved, keep = [], [], []
+        for k in range(n):
+            W1, b1, W2, b2, ln_w, ln_b = params[k]
+            x = xs[k]
+            t, B, bstride, lead = as_batched(x)
+            rows, kin = x.shape[-2], x.shape[-1]
+            hid, dout = W1.shape[0], W2.shape[0]
+            if W1.shape[1] != kin:
+                raise RuntimeError(f"grouped MLP {k}: input width {kin} does not match the first Linear {tuple(W1.shape)}")
+            p = arr[k]
+            _fill_src(p.src[0], t, bstride, kin, None)
+            p.nsrc, p.batch, p.rows, p.ntiles = 1, B, rows, (rows + 31) // 32
+            W1c, b1c, W2c, b2c = W1.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous()
+            keep.extend((t, W1c, b1c, W2c, b2c))
+            p.W1, p.b1, p.W2, p.b2, p.ln_w, p.ln_b = _ptr(W1c), _ptr(b1c), _ptr(W2c), _ptr(b2c), _ptr(ln_w), _ptr(ln_b)
+            p.eps, p.hid, p.dout, p.flags = 1e-5, hid, dout, mm_flags
+            out = torch.empty((B, rows, dout), device=dev, dtype=torch.float32)
+            p.out, p.out_bstride = _ptr(out), rows * dout
+            z1 = xhat = rstd = None
+            if need_grad:
+                z1 = torch.empty((B, rows, hid), device=dev, dtype=torch.float32)
+                p.z1 = _ptr(z1)
+                if ln_w is not None:
+                    xhat = torch.empty((B, rows, dout), device=dev, dtype=torch.float32)
+                    rstd = torch.empty((B, rows), device=dev, dtype=torch.float32)
+                    p.xhat, p.rstd = _ptr(xhat), _ptr(rstd)
+            outs.append(out.reshape(*lead, rows, dout) if len(lead) != 1 else out)
+            saved.append((t, B, bstride, rows, W1c, W2c, z1, xhat, rstd))
+        rc = lib.nlam_mlp_fwd_group(arr, n, _stream()) if n > 1 else -2
+        if rc == -2:   # NLAM_EUNSUP: members of different kernel shapes -> one launch each
+            for k in range(n):
+                p = arr[k]
+                nwp = lib.nlam_mlp_fwd_wpack_floats(C.byref(p))
+                if nwp > 0:
+                    wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+                    keep.append(wpack)
+                    p.wpack, p.wpack_floats = _ptr(wpack), nwp
+                L.check(lib.nlam_mlp_fwd(C.byref(p), _stream()), "nlam_mlp_fwd (group member)")
+        else:
+            L.check(rc, "nlam_mlp_fwd_group")
+        if need_grad:
+            ctx.n, ctx.params, ctx.saved, ctx.mm_flags = n, params, saved, mm_flags
+            ctx.set_materialize_grads(False)
+            if GRAD_LISTENER is not None:
+                GRAD_LISTENER.note_use([q for pr in params for q in pr if q is not None and q.requires_grad])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        lib = L.load()
+        n, params = ctx.n, ctx.params
+        dev = params[0][0].device
+        live = [k for k in range(n) if g_outs[k] is not None]
+        grads = [None] * (6 * n)
+        if not live:
+            return (None, *grads, *([None] * n))
+        m = len(live)
+        arr = (L.MlpBwd * m)()
+        tiles = (C.c_int64 * m)()
+        work = []
+        for i, k in enumerate(live):
+            t, B, bstride, rows, W1c, W2c, z1, xhat, rstd = ctx.saved[k]
+            hid, kin = W1c.shape
+            dout = W2c.shape[0]
+            g = g_outs[k].reshape(B, rows, dout).contiguous()
+            p = arr[i]
+            _fill_src(p.src[0], t, bstride, kin, None)
+            p.nsrc, p.batch, p.rows, p.ntiles = 1, B, rows, (rows + 31) // 32
+            p.W1, p.W2, p.ln_w = _ptr(W1c), _ptr(W2c), _ptr(params[k][4])
+            p.hid, p.dout, p.flags = hid, dout, ctx.mm_flags
+            p.g_out, p.out_bstride = _ptr(g), rows * dout
+            p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
+            dz1 = torch.empty((B * rows, hid), device=dev, dtype=torch.float32)
+            dz2 = torch.empty((B * rows, dout), device=dev, dtype=torch.float32)
+            p.dz1, p.dz2 = _ptr(dz1), _ptr(dz2)
+            tiles[i] = p.ntiles * B
+            work.append([k, g, dz1, dz2, None, 0, None])
+        blocks = (C.c_int32 * m)()
+        L.check(lib.nlam_mlp_group_blocks(tiles, m, blocks), "nlam_mlp_group_blocks")
+        for i, k in enumerate(live):
+            p = arr[i]
+            hid, dout = p.hid, p.dout
+            nblk_single = lib.nlam_mlp_bwd_blocks(C.byref(p))
+            vs = _vec_stride(hid, dout)
+            rows_v = max(int(blocks[i]), int(nblk_single))
+            vecp = torch.empty((rows_v, 4, vs), device=dev, dtype=torch.float32)
+            p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(vecp), rows_v, vs
+            work[i][4], work[i][5] = vecp, int(blocks[i])
+        rc = lib.nlam_mlp_bwd_group(arr, m, _stream()) if m > 1 else -2
+        if rc == -2:
+            for i in range(m):
+                p = arr[i]
+                nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
+                if nwp > 0:
+                    wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+                    work[i][6] = wpack
+                    p.wpack, p.wpack_floats = _ptr(wpack), nwp
+                work[i][5] = lib.nlam_mlp_bwd_blocks(C.byref(p))
+                L.check(lib.nlam_mlp_bwd(C.byref(p), _stream()), "nlam_mlp_bwd (group member)")
+        else:
+            L.check(rc, "nlam_mlp_bwd_group")
+        # ---- weight gradients per member (side streams under the trainer) ----
+        for i, k in enumerate(live):
+            _, g, dz1, dz2, vecp, nblk, wpack = work[i]
+            t, B, bstride, rows, W1c, W2c, z1, xhat, rstd = ctx.saved[k]
+            hid, kin = W1c.shape
+            dout = W2c.shape[0]
+            prm = params[k]
+            needs = [ctx.needs_input_grad[1 + 6 * k + q] for q in range(6)]
+            has_ln = prm[4] is not None
+            direct_all = DIRECT_PARAM_GRADS and all(q is None or not nd or (q.grad is not None and q.grad.is_contiguous()) for q, nd in zip(prm, needs))
+            on_side = OVERLAP.active and direct_all
+            streams = contextlib.ExitStack()
+            if on_side:
+                side = OVERLAP.stream_for(prm[0])
+                side.wait_stream(torch.cuda.current_stream())
+                OVERLAP.hold(side, g, dz1, dz2, vecp, z1, t, wpack)
+                streams.enter_context(torch.cuda.stream(side))
+            with streams:
+                src_list = [(t.data_ptr(), bstride, kin, None)]
+                res = _chunk_weight_grads(lib, B, rows, hid, dout, kin, ctx.mm_flags, dz1, dz2, z1, vecp, nblk, _vec_stride(hid, dout),
+                                          src_list, prm, needs, has_ln)
+            grads[6 * k : 6 * k + 6] = res
+        return (None, *grads, *([None] * n))
+
+
 def _linear_launch(x2d, W, ldn, ldk, k, n, out=None, accumulate=False, mm_flags=None, W2=None, out2=None):
     """out (rows, n) (+)= x2d (rows, k) . A^T with A[h][c] = W[h * ldn + c * ldk] (nlam_linear); with W2 / out2 a second
     product over the same rows in the same launch."""

@@ -1,0 +1,34 @@
+"""profiles/round2/pmc_traffic.json from the per-kernel PMC averages of tools/pmc_collect.py.
+
+    python tools/pmc_collect.py m2g_edge fetch write wave insts -- python tools/kernel_bench.py m2g 3 64 edge
+    python tools/pmc_collect.py m2m_edge fetch write wave insts -- python tools/kernel_bench.py m2m 3 64 edge
+    python tools/make_pmc_traffic.py gpurun_out/pmc_m2g_edge.json:255136 gpurun_out/pmc_m2m_edge.json:57616 > profiles/round2/pmc_traffic.json
+
+HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB): on gfx950 rocprofv3's FETCH_SIZE tallies 128-byte read requests
+at 64 bytes (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is taken as reported (uncalibrated).  Keys are the launch keys
+of bench.py's roofline rows (kind:rows:k:n)."""
+import json
+import sys
+
+d = 64
+NAMES = {   # kernel name prefix -> (kind, k, n) of the launch key at hidden_dim 64
+    "mlp_fwd_bf_kernel<2, 2, 3, false, false, false>": ("mlp_fwd", 3 * d, d),
+    "mlp_fwd_bf_kernel<2, 2, 3, false, true, false>": ("mlp_fwd", 3 * d, d),
+    "mlp_bwd_fast_kernel<2, 2, 3>": ("mlp_bwd", 3 * d, d),
+    "wgrad_dma_kernel<3, false>": ("wgrad", d, 3 * d),
+    "wgrad_dma_kernel<1, true>": ("wgrad", d, d),
+}
+out = {"note": "HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE KiB (gfx950 FETCH_SIZE correction); separate --pmc passes, "
+               "kernel trace only; one InteractionNet edge stage (forward in training mode, backward, both weight gradients)",
+       "bytes_per_launch": {}, "counters": {}, "commands": []}
+for arg in sys.argv[1:]:
+    path, rows = arg.split(":")
+    js = json.load(open(path))
+    out["commands"].append(js["command"])
+    for name, c in js["kernels"].items():
+        for prefix, (kind, k, n) in NAMES.items():
+            if name.startswith(prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                key = f"{kind}:{rows}:{k}:{n}"
+                out["bytes_per_launch"][key] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+                out["counters"][key] = {"kernel": name, **{kk: vv for kk, vv in c.items() if kk != "grid"}}
+print(json.dumps(out, indent=1))

@@ -67,6 +67,17 @@ def main():
         lines.append("")
     text = "\n".join(lines)
     (root / "gpurun_out" / f"pmc_{tag}.md").write_text(text)
+    import json
+
+    js = {}
+    for key in stats:
+        if not key[0].startswith(("mlp_", "wgrad", "segment", "reduce", "pack", "adamw", "linear")):
+            continue
+        c = stats[key]
+        dd = [v for kk, v in dur.items() if kk[0] == key[0]]
+        dmean = sum(sum(v) for v in dd) / max(1, sum(len(v) for v in dd)) if dd else None
+        js[key[0]] = {"grid": key[1], "mean_duration_us": dmean, **{cn: sum(v) / len(v) for cn, v in c.items()}}
+    (root / "gpurun_out" / f"pmc_{tag}.json").write_text(json.dumps({"command": " ".join(cmd), "kernels": js}, indent=1))
     print(text)
 
 
