@@ -985,7 +985,16 @@ class GroupedMLPFunction(torch.autograd.Function):
                     p.xhat, p.rstd = _ptr(xhat), _ptr(rstd)
             outs.append(out.reshape(*lead, rows, dout) if len(lead) != 1 else out)
             saved.append((t, B, bstride, rows, W1c, W2c, z1, xhat, rstd))
-        rc = lib.nlam_mlp_fwd_group(arr, n, _stream()) if n > 1 else -2
+        rows_all = sum(int(arr[k].rows) * int(arr[k].batch) for k in range(n))
+
+        def grp_meta():
+            fl = sum(2.0 * arr[k].rows * arr[k].batch * (xs[k].shape[-1] * arr[k].hid + arr[k].hid * arr[k].dout) for k in range(n))
+            by = sum(4.0 * arr[k].rows * arr[k].batch * (xs[k].shape[-1] + arr[k].dout + (arr[k].hid + arr[k].dout + 1 if need_grad else 0)) for k in range(n))
+            name, mf = _mm_executed(mm_flags, arr[0].hid, arr[0].dout, [32])
+            return {"flops": fl, "bytes": by, "mm": name, "mfmas_per_block": mf, "what": f"{n} static-feature embedders in one grouped launch"}
+
+        rc = PROFILE.launch(("mlp_fwd_group", rows_all, n, int(arr[0].hid), int(arr[0].dout)),
+                            lambda: lib.nlam_mlp_fwd_group(arr, n, _stream()), grp_meta) if n > 1 else -2
         if rc == -2:   # NLAM_EUNSUP: members of different kernel shapes -> one launch each
             for k in range(n):
                 p = arr[k]
@@ -1045,7 +1054,17 @@ class GroupedMLPFunction(torch.autograd.Function):
             vecp = torch.empty((rows_v, 4, vs), device=dev, dtype=torch.float32)
             p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(vecp), rows_v, vs
             work[i][4], work[i][5] = vecp, int(blocks[i])
-        rc = lib.nlam_mlp_bwd_group(arr, m, _stream()) if m > 1 else -2
+        rows_all = sum(int(arr[i].rows) * int(arr[i].batch) for i in range(m))
+
+        def grp_meta():
+            fl = sum(2.0 * arr[i].rows * arr[i].batch * arr[i].hid * arr[i].dout for i in range(m))
+            by = sum(4.0 * arr[i].rows * arr[i].batch * (3 * arr[i].dout + 2 * arr[i].hid + 1) for i in range(m))
+            name, mf = _mm_executed(ctx.mm_flags, arr[0].hid, arr[0].dout, [32])
+            return {"flops": fl, "bytes": by, "mm": name, "mfmas_per_block": mf,
+                    "what": f"backward of {m} static-feature embedders in one grouped launch (no data gradients; writes dz1, dz2)"}
+
+        rc = PROFILE.launch(("mlp_bwd_group", rows_all, m, int(arr[0].hid), int(arr[0].dout)),
+                            lambda: lib.nlam_mlp_bwd_group(arr, m, _stream()), grp_meta) if m > 1 else -2
         if rc == -2:
             for i in range(m):
                 p = arr[i]
