@@ -73,6 +73,10 @@ extern "C" {
  * nlam_segment_sum over the dz1 rows gives the gradient of a sender-gathered addend).  Split-bf16 matrix modes,
  * widths that are multiples of 32 and <= 64 (NLAM_EUNSUP otherwise); not combined with NLAM_F_ADD_SRC1. */
 #define NLAM_F_PRE_ADD   16u
+/* nlam_mlp_bwd_group only: a leaf MLP (no data gradients) of <= 4 input columns accumulates its weight gradients in the
+ * backward kernel itself -- dz1 / dz2 are never written: `dz2` receives the (workgroups, dout, hid) partial sums of dW2,
+ * `dz1` is unused, `vec_partials` has SEVEN rows per workgroup: db1, db2, dgamma, dbeta, dW1[:, 0], dW1[:, 1], dW1[:, 2]. */
+#define NLAM_F_LEAF_WGRAD 32u
 /* matrix path of the GEMMs (bits 8-9): 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains);
  * n = 1..3: operands split into n bf16 terms on the bf16 matrix cores, fp32 accumulate
  * (1 = plain bf16 operands, 2 = ~2^-16 product error, 3 = fp32-class ~2^-24).  Shapes the
@@ -250,7 +254,7 @@ int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stri
 /* Up to NLAM_MAX_REDUCE_JOBS reductions of the nlam_reduce_partials kind in ONE launch: the dW1, dW2,
  * db1, db2, dgamma, dbeta of one fused-MLP backward (autograd's AccumulateGrad `grad += new`, folded in
  * when accumulate != 0 and out points into the gradient buffer). */
-#define NLAM_MAX_REDUCE_JOBS 6
+#define NLAM_MAX_REDUCE_JOBS 8
 typedef struct {
     const float* partials;
     float* out;

@@ -16,7 +16,7 @@ LIB_PATH = Path(os.environ["NLAM_LIB"]) if os.environ.get("NLAM_LIB") else HERE 
 
 NLAM_MAX_SRC = 3
 NLAM_MAX_GROUP = 8
-F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD = 1, 2, 4, 8, 16
+F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD, F_LEAF_WGRAD = 1, 2, 4, 8, 16, 32
 TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning keys (include/nlam_hip.h)
 TUNE_WGRAD_CHUNKS = 2
 TILE_SPLIT = 1 << 30
@@ -168,7 +168,7 @@ class ReduceJob(C.Structure):
 
 
 class ReduceJobs(C.Structure):
-    _fields_ = [("job", ReduceJob * 6), ("njobs", C.c_int32), ("_pad", C.c_int32)]
+    _fields_ = [("job", ReduceJob * 8), ("njobs", C.c_int32), ("_pad", C.c_int32)]
 
 
 class Linear(C.Structure):

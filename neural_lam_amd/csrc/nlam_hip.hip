@@ -1610,7 +1610,12 @@ __device__ __forceinline__ float block_colsum_half(const float* stg, int lane) {
     return s;
 }
 
-template <int HB, int OB, int NS>
+// LW (NLAM_F_LEAF_WGRAD): a leaf MLP of <= 4 input columns (the embedders of the static features) accumulates its own
+// weight gradients: dW2 = dz2^T silu(z1) as a transposed MFMA product of the blocks the kernel stages anyway (rows are
+// the K dimension: lane (i, hi) reads rows 8 hi .. 8 hi + 7 of column i of the row-major staged block), dW1[:, k] as
+// column sums of dz1 weighted with input column k.  dz1 / dz2 never leave the chip; p.dz2 receives the workgroup's
+// (dout x hid) partial, vec_partials has 7 rows per workgroup (db1, db2, dgamma, dbeta, dW1[:, 0..2]).
+template <int HB, int OB, int NS, bool LW = false, int NWV = kWavesPerBlock>
 __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const int wg_id, const int wg_count) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int DPH = HB * 32, OP = OB * 32;
@@ -1642,8 +1647,9 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         if (gemm_src(s)) w1_floats += NS > 0 ? (size_t)NS * p.src[s].width * DPH / 2 : (size_t)p.src[s].width * DPH;
     }
     float* gml = W1t + w1_floats;                         // OP
-    float* stg_all = gml + OP;                            // kWavesPerBlock x 32 x kStgStride
-    float* colacc_all = stg_all + (size_t)kWavesPerBlock * 32 * kStgStride;   // kWavesPerBlock x 8 x 64 column accumulators
+    float* stg_all = gml + OP;                            // NWV x 32 x kStgStride
+    float* colacc_all = stg_all + (size_t)NWV * 32 * kStgStride;   // NWV x 8 x 64 column accumulators
+    float* xs_all = colacc_all + (size_t)NWV * 8 * 64;             // LW: NWV x [32][4] input rows of the tile
     if constexpr (NS > 0) {
         // A[m = hidden][k = out (slot-permuted)] = W2[k][m]
         stage_split<NSW>(reinterpret_cast<u32x4*>(W2t), S2, 0, p.W2, 1, p.hid, HB, p.dout, true, p.hid);
@@ -1682,9 +1688,22 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
     enum { kDb1 = 0, kDb2 = 2, kDg = 4, kDbt = 6 };
 #pragma unroll
     for (int k = 0; k < 8; ++k) colacc[k * 64] = 0.f;
+    float* xs = xs_all + (size_t)wave * 32 * 4;
+    f32x16 dw2[LW ? OB : 1][LW ? HB : 1];   // LW: this wave's share of dW2 (block (ob, hb): rows = output features, lane & 31 = hidden feature)
+    float dw1c[LW ? HB : 1][3];             // LW: this lane's share of dW1[32 hb + (lane & 31)][k]
+    if constexpr (LW) {
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dw2[ob][hb][r] = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) dw1c[hb][0] = dw1c[hb][1] = dw1c[hb][2] = 0.f;
+    }
 
     const long total_tiles = (long)p.ntiles * p.batch;
-    for (long gt = (long)wave * wg_count + wg_id; gt < total_tiles; gt += (long)wg_count * kWavesPerBlock) {
+    for (long gt = (long)wave * wg_count + wg_id; gt < total_tiles; gt += (long)wg_count * NWV) {
         const int b = (int)(gt / p.ntiles);
         const TileInfo tl = get_tile(p.tiles, (int)(gt % p.ntiles), p.rows);
         const bool valid = j < tl.nrows;
@@ -1716,16 +1735,26 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         const float* garow = p.g_aggr != nullptr ? p.g_aggr + ((size_t)b * p.nseg_total + sg) * p.dout : nullptr;
         const float* xrow = has_ln ? p.xhat + srow_c * p.dout : nullptr;
         const float* zrow = p.z1 + srow_c * p.hid;
+        if constexpr (LW) {   // the tile's input rows (<= 4 columns), zero past the width and past the tile's rows
+            if (hi == 0) {
+                const int kw = p.src[0].width;
+                const float* xr = p.src[0].ptr + (long)b * p.src[0].bstride + (long)prow_c * kw;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xs[j * 4 + k] = (valid && k < kw) ? xr[k] : 0.f;
+            }
+        }
 
         NLAM_T_MARK(1)
         // ---- dmsg (C-layout chunks), LayerNorm backward ----
         f32x16 dz2[OB];
         {
             float m1 = 0.f, m2 = 0.f;
-            f32x4 xhs[OB][4];   // xhat stays in registers between its two uses (the big edge sets are HBM-bound: one read)
+            // xhat stays in registers between its two uses (the big edge sets are HBM-bound: one read); the fused-weight-gradient
+            // variant carries 64 accumulator registers through the tile loop and re-reads it (an L2 hit) instead
+            f32x4 xhs[LW ? 1 : OB][4];
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob) {
-                f32x4(&xh)[4] = xhs[ob];
+                f32x4(&xh)[4] = xhs[LW ? 0 : ob];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
@@ -1770,7 +1799,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
                 for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
-                        const f32x4 xh = xhs[ob][tt];
+                        const f32x4 xh = LW ? *reinterpret_cast<const f32x4*>(xrow + 8 * (ob * 4 + tt) + 4 * hi) : xhs[LW ? 0 : ob][tt];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const float v = rstd * (dz2[ob][4 * tt + c] - m1 - xh[c] * m2);
@@ -1787,7 +1816,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
             for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt);
             wave_lds_sync();
             colacc[(kDb2 + ob) * 64] += block_colsum_half(stg, lane);
-            if (p.dz2 != nullptr) {
+            if (!LW && p.dz2 != nullptr) {
                 float* dbase = p.dz2 + tile_row0 * p.dout + 32 * ob;
                 block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return dbase + (size_t)r * p.dout; });
             }
@@ -1818,8 +1847,29 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) mma_chunk<HB>(dz1, W2t, T2, ob * 4 + tt, acc_chunk(dz2[ob], tt), lane);
         }
+        // LW: dz2^T fragments (A operand of dW2: feature lane & 31, rows 16 s + 8 hi .. + 7), made AFTER the dh GEMM so that
+        // they are not live across it (the blocks are re-staged from the registers the GEMM has just read)
+        BfFrag<NSW> a2[LW ? OB : 1][2];
+        if constexpr (LW) {
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt);
+                wave_lds_sync();
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float a8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a8[q] = stg[(16 * s2 + 8 * hi + q) * kStgStride + j];
+                    a2[ob][s2] = split8<NSW>(a8);
+                    __builtin_amdgcn_sched_barrier(0);   // one fragment at a time (the scheduler otherwise interleaves the conversions: VGPRs)
+                }
+                wave_lds_sync();
+            }
+        }
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb) {
+            f32x4 hh[LW ? 4 : 1];   // LW: silu(z1) of this block, the B operand of dW2
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const f32x4 z = *reinterpret_cast<const f32x4*>(zrow + 8 * (hb * 4 + tt) + 4 * hi);
@@ -1828,12 +1878,55 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
                 for (int c = 0; c < 4; ++c) {
                     v[c] = valid ? dz1[hb][4 * tt + c] * silu_grad_f(z[c]) : 0.f;
                     dz1[hb][4 * tt + c] = v[c];
+                    if constexpr (LW) hh[tt][c] = valid ? silu_f(z[c]) : 0.f;
                 }
                 *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = v;
             }
             wave_lds_sync();
             colacc[(kDb1 + hb) * 64] += block_colsum_half(stg, lane);
-            if (p.dz1 != nullptr) {
+            if constexpr (LW) {
+                __builtin_amdgcn_sched_barrier(0);
+                // dW1[:, k] += sum_rows dz1[row][:] * x[row][k]: the column sums of db1 with the input column as weight
+                const int c_ = lane & 31, r0_ = (lane >> 5) * 16;
+                float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float dv = stg[(r0_ + q) * kStgStride + c_];
+                    const f32x4 xr = *reinterpret_cast<const f32x4*>(&xs[(r0_ + q) * 4]);
+                    w0 += dv * xr[0];
+                    w1 += dv * xr[1];
+                    w2 += dv * xr[2];
+                }
+                dw1c[hb][0] += w0;
+                dw1c[hb][1] += w1;
+                dw1c[hb][2] += w2;
+                wave_lds_sync();
+                // dW2[ob][hb] += dz2_ob^T . silu(z1)_hb  (K = the tile's 32 rows = two K steps)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = hh[tt];
+                wave_lds_sync();
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float b8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) b8[q] = stg[(16 * s2 + 8 * hi + q) * kStgStride + j];
+                    const BfFrag<NSW> bh = split8<NSW>(b8);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ord = NSW - 1; ord >= 0; --ord)
+#pragma unroll
+                        for (int pa = 0; pa <= ord; ++pa)
+#pragma unroll
+                            for (int ob = 0; ob < OB; ++ob) {   // accumulators alternate (OB = 2) or are fenced (see mma_split_lds)
+                                dw2[ob][hb] = MFMA_BF16(a2[ob][s2].t[pa], bh.t[ord - pa], dw2[ob][hb]);
+                                if (OB == 1) {
+                                    asm volatile("s_nop 15");
+                                    asm volatile("s_nop 15");
+                                }
+                            }
+                }
+            }
+            if (!LW && p.dz1 != nullptr) {
                 float* dbase = p.dz1 + tile_row0 * p.hid + 32 * hb;
                 block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return dbase + (size_t)r * p.hid; });
             }
@@ -1847,6 +1940,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         }
 
         NLAM_T_MARK(4)
+        if constexpr (!LW) {   // a leaf MLP has no data gradients: the whole stage is compiled out of the fused-weight-gradient variant
         // ---- dx_s = W1_s^T dz1 per source ----
         // split-bf16: the B fragments of dz1 are the same for every source -- convert once
         BfFrag<NSW> bz[NS > 0 ? HB * 2 : 1];
@@ -1933,16 +2027,38 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
                 wave_lds_sync();
             }
         }
+        }
         NLAM_T_MARK(5)
     }
 
     NLAM_T_DRAIN
     NLAM_T_MARK(6)
     NLAM_T_FLUSH(t_ntiles_)
+    if constexpr (LW) {
+        // ---- the workgroup's dW2 partial: the eight waves' 32 x 32 blocks summed through the staging blocks ----
+        float* P2 = p.dz2 + (size_t)wg_id * p.dout * p.hid;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                __syncthreads();
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)   // stg[n = hidden feature][m = output feature]
+                    *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dw2[ob][hb], tt);
+                __syncthreads();
+                for (int e = threadIdx.x; e < 1024; e += (NWV * 64)) {
+                    const int n = e & 31, m = e >> 5;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NWV; ++w) sum += stg_all[(size_t)w * 32 * kStgStride + n * kStgStride + m];
+                    if (32 * ob + m < p.dout && 32 * hb + n < p.hid) P2[(size_t)(32 * ob + m) * p.hid + 32 * hb + n] = sum;
+                }
+            }
+    }
     // ---- combine the waves' column partials through LDS; one row per workgroup ----
     if (p.vec_partials != nullptr) {
         __syncthreads();
-        float* red = stg_all;   // kWavesPerBlock x 4 x 64 floats (fits: 8 x 32 x 36 staging)
+        float* red = stg_all;   // NWV x 4 x 64 floats (fits: 8 x 32 x 36 staging)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float v1 = k < HB ? colacc[(kDb1 + k) * 64] : 0.f;
@@ -1960,11 +2076,31 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
             }
         }
         __syncthreads();
+        constexpr int kVecRows = LW ? 7 : 4;
         if (wave < 4) {
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < kWavesPerBlock; ++w) s += red[(w * 4 + wave) * 64 + lane];
-            p.vec_partials[((size_t)wg_id * 4 + wave) * p.vec_stride + lane] = s;
+            for (int w = 0; w < NWV; ++w) s += red[(w * 4 + wave) * 64 + lane];
+            p.vec_partials[((size_t)wg_id * kVecRows + wave) * p.vec_stride + lane] = s;
+        }
+        if constexpr (LW) {   // dW1[:, 0..2]: the same reduction with the weighted column sums
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    const float v = k < HB ? dw1c[k < HB ? k : 0][c3] : 0.f;
+                    const float sv = v + __shfl_xor(v, 32, 64);
+                    if (lane < 32) red[(wave * 4 + c3) * 64 + 32 * k + lane] = sv;
+                }
+            }
+            __syncthreads();
+            if (wave < 3) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) s += red[(w * 4 + wave) * 64 + lane];
+                p.vec_partials[((size_t)wg_id * kVecRows + 4 + wave) * p.vec_stride + lane] = s;
+            }
         }
     }
 }
@@ -1980,13 +2116,17 @@ struct bwd_group_t {
     int first[NLAM_MAX_GROUP + 1];
 };
 
-template <int HB, int OB, int NS>
-__global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_group_kernel(const bwd_group_t G) {
+// The fused-weight-gradient variant carries 64 + accumulator registers through the tile loop: with two waves per SIMD (256
+// registers each) it spilled 428 bytes per lane and ran 217 us against 129 us for the plain grouped kernel; its per-tile work
+// is VALU-bound (LayerNorm backward + operand splits), so it runs ONE wave per SIMD (4-wave workgroups, up to 512 registers).
+constexpr int kLeafWaves = 4;
+template <int HB, int OB, int NS, bool LW>
+__global__ __launch_bounds__(LW ? kLeafWaves * 64 : kBlockThreads) void mlp_bwd_fast_group_kernel(const bwd_group_t G) {
     int gi = 0;
 #pragma unroll
     for (int k = 1; k < NLAM_MAX_GROUP; ++k)
         if (k < G.n && (int)blockIdx.x >= G.first[k]) gi = k;
-    mlp_bwd_fast_body<HB, OB, NS>(G.g[gi], (int)blockIdx.x - G.first[gi], G.first[gi + 1] - G.first[gi]);
+    mlp_bwd_fast_body<HB, OB, NS, LW, LW ? kLeafWaves : kWavesPerBlock>(G.g[gi], (int)blockIdx.x - G.first[gi], G.first[gi + 1] - G.first[gi]);
 }
 
 // ---------------------------------------------------------------------------
@@ -2819,7 +2959,9 @@ size_t bwd_fast_lds_bytes(const nlam_mlp_bwd_t* p, int HB, int OB, int NS) {
     for (int s = 0; s < p->nsrc; ++s)
         if (p->dmode[s] != 0 && (!pre || s == 0)) wf += (size_t)p->src[s].width * DPH;
     if (NS > 0) wf = wf * NS / 2;
-    return (wf + OP + (size_t)kWavesPerBlock * 32 * kStgStride + (size_t)kWavesPerBlock * 8 * 64) * sizeof(float);
+    const size_t nw = (p->flags & NLAM_F_LEAF_WGRAD) ? kLeafWaves : kWavesPerBlock;
+    const size_t xs = (p->flags & NLAM_F_LEAF_WGRAD) ? nw * 32 * 4 : 0;   // the tile's input rows (fused leaf weight gradients)
+    return (wf + OP + nw * 32 * kStgStride + nw * 8 * 64 + xs) * sizeof(float);
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
@@ -3471,7 +3613,10 @@ extern "C" int32_t nlam_mlp_bwd_group(const nlam_mlp_bwd_t* ps, int32_t n, void*
         const nlam_mlp_bwd_t& p = ps[k];
         if (p.W1 == nullptr || p.W2 == nullptr || p.z1 == nullptr || p.batch < 1 || p.rows < 1 || p.g_out == nullptr) return NLAM_EINVAL;
         if (p.nsrc != 1 || bwd_is_wide(&p) || p.hid != ps[0].hid || p.dout != ps[0].dout || p.hid % 32 != 0 || p.dout % 32 != 0) return NLAM_EUNSUP;
-        if ((p.flags & ~NLAM_F_MM_MASK) != 0 || (p.flags & NLAM_F_MM_MASK) != (ps[0].flags & NLAM_F_MM_MASK)) return NLAM_EUNSUP;
+        if ((p.flags & ~(NLAM_F_MM_MASK | NLAM_F_LEAF_WGRAD)) != 0 || (p.flags & (NLAM_F_MM_MASK | NLAM_F_LEAF_WGRAD)) != (ps[0].flags & (NLAM_F_MM_MASK | NLAM_F_LEAF_WGRAD)))
+            return NLAM_EUNSUP;
+        if ((p.flags & NLAM_F_LEAF_WGRAD) && (p.src[0].width > 4 || p.src[0].ptr == nullptr || p.src[0].idx != nullptr || p.dz2 == nullptr || p.vec_partials == nullptr))
+            return NLAM_EUNSUP;   // fused weight gradients: <= 4 input columns, p.dz2 = (blocks, dout, hid) partials, 7 vector rows
         if (p.g_aggr != nullptr || p.out_idx != nullptr || p.tiles != nullptr || p.dmode[0] != 0) return NLAM_EUNSUP;   // leaf MLPs: no data gradient
         if ((p.ln_w == nullptr) != (ps[0].ln_w == nullptr)) return NLAM_EUNSUP;
         G.g[k] = p;
@@ -3488,11 +3633,16 @@ extern "C" int32_t nlam_mlp_bwd_group(const nlam_mlp_bwd_t* ps, int32_t n, void*
     }
     for (int k = n + 1; k <= NLAM_MAX_GROUP; ++k) G.first[k] = G.first[n];
     hipStream_t stream = (hipStream_t)hip_stream;
-#define NLAM_LAUNCH_BWDG(HB_, NS_)                                                                                             \
-    do {                                                                                                                       \
-        int rc = set_lds(mlp_bwd_fast_group_kernel<HB_, HB_, NS_>, lds);                                                       \
-        if (rc != 0) return rc;                                                                                                \
-        hipLaunchKernelGGL((mlp_bwd_fast_group_kernel<HB_, HB_, NS_>), dim3(G.first[n]), dim3(kBlockThreads), lds, stream, G); \
+#define NLAM_LAUNCH_BWDG1(HB_, NS_, LW_)                                                                                            \
+    do {                                                                                                                            \
+        int rc = set_lds(mlp_bwd_fast_group_kernel<HB_, HB_, NS_, LW_>, lds);                                                       \
+        if (rc != 0) return rc;                                                                                                     \
+        hipLaunchKernelGGL((mlp_bwd_fast_group_kernel<HB_, HB_, NS_, LW_>), dim3(G.first[n]), dim3(LW_ ? kLeafWaves * 64 : kBlockThreads), lds, stream, G); \
+    } while (0)
+#define NLAM_LAUNCH_BWDG(HB_, NS_)                            \
+    do {                                                      \
+        if (ps[0].flags & NLAM_F_LEAF_WGRAD) NLAM_LAUNCH_BWDG1(HB_, NS_, true); \
+        else NLAM_LAUNCH_BWDG1(HB_, NS_, false);              \
     } while (0)
     if (HB == 1) {
         if (ns == 3) NLAM_LAUNCH_BWDG(1, 3);

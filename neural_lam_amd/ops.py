@@ -936,6 +936,10 @@ def _chunk_weight_grads(lib, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, ve
     return results
 
 
+# Leaf MLPs of <= 3 input columns accumulate their weight gradients inside the grouped backward kernel (NLAM_F_LEAF_WGRAD)
+FUSED_LEAF_WGRAD = os.environ.get("NLAM_FUSED_LEAF_WGRAD", "1") == "1"
+
+
 class GroupedMLPFunction(torch.autograd.Function):
     """n <= 8 independent single-source fused MLPs of one shape -- the embedders of the static grid / mesh / edge features
     (graph/base.py:286-295, hierarchical.py:195-231) -- in ONE launch each way (nlam_mlp_fwd_group / nlam_mlp_bwd_group):
@@ -1023,6 +1027,11 @@ class GroupedMLPFunction(torch.autograd.Function):
         if not live:
             return (None, *grads, *([None] * n))
         m = len(live)
+        if m > 1 and FUSED_LEAF_WGRAD and (ctx.mm_flags >> 8) & 3 and all(ctx.saved[k][4].shape[1] <= 3 and ctx.saved[k][4].shape[0] <= 64 and
+                                                                             ctx.saved[k][5].shape[0] <= 64 for k in live):
+            done = _grouped_backward_fused(ctx, g_outs, live, grads)
+            if done:
+                return (None, *grads, *([None] * n))
         arr = (L.MlpBwd * m)()
         tiles = (C.c_int64 * m)()
         work = []
@@ -1100,6 +1109,108 @@ class GroupedMLPFunction(torch.autograd.Function):
                                           src_list, prm, needs, has_ln)
             grads[6 * k : 6 * k + 6] = res
         return (None, *grads, *([None] * n))
+
+
+def _grouped_backward_fused(ctx, g_outs, live, grads):
+    """Grouped backward with the weight gradients accumulated in the kernel (NLAM_F_LEAF_WGRAD): one launch produces, per
+    member and workgroup, the partial sums of dW2 and seven vector rows (db1, db2, dgamma, dbeta, dW1[:, 0..2]); one
+    reduction launch per member finishes them (straight into the flat gradient views under the trainer).  No dz1 / dz2
+    round trip, no weight-gradient launches behind the kernel.  Returns False when the library has no such kernel."""
+    lib = L.load()
+    params = ctx.params
+    dev = params[0][0].device
+    m = len(live)
+    arr = (L.MlpBwd * m)()
+    tiles = (C.c_int64 * m)()
+    for i, k in enumerate(live):
+        t, B, bstride, rows, W1c, W2c, z1, xhat, rstd = ctx.saved[k]
+        tiles[i] = ((rows + 31) // 32) * B
+    blocks = (C.c_int32 * m)()
+    L.check(lib.nlam_mlp_group_blocks(tiles, m, blocks), "nlam_mlp_group_blocks")
+    work = []
+    for i, k in enumerate(live):
+        t, B, bstride, rows, W1c, W2c, z1, xhat, rstd = ctx.saved[k]
+        hid, kin = W1c.shape
+        dout = W2c.shape[0]
+        g = g_outs[k].reshape(B, rows, dout).contiguous()
+        p = arr[i]
+        _fill_src(p.src[0], t, bstride, kin, None)
+        p.nsrc, p.batch, p.rows, p.ntiles = 1, B, rows, (rows + 31) // 32
+        p.W1, p.W2, p.ln_w = _ptr(W1c), _ptr(W2c), _ptr(params[k][4])
+        p.hid, p.dout, p.flags = hid, dout, ctx.mm_flags | L.F_LEAF_WGRAD
+        p.g_out, p.out_bstride = _ptr(g), rows * dout
+        p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
+        nblk = int(blocks[i])
+        vs = _vec_stride(hid, dout)
+        dw2p = torch.empty((nblk, dout, hid), device=dev, dtype=torch.float32)
+        vecp = torch.empty((nblk, 7, vs), device=dev, dtype=torch.float32)
+        p.dz2, p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(dw2p), _ptr(vecp), nblk, vs
+        work.append((k, g, dw2p, vecp, nblk, vs))
+    rows_all = sum(int(arr[i].rows) * int(arr[i].batch) for i in range(m))
+
+    def meta():
+        fl = sum(4.0 * arr[i].rows * arr[i].batch * arr[i].hid * arr[i].dout for i in range(m))
+        by = sum(4.0 * arr[i].rows * arr[i].batch * (2 * arr[i].dout + arr[i].hid + 1) for i in range(m))
+        name, mf = _mm_executed(ctx.mm_flags, arr[0].hid, arr[0].dout, [32])
+        return {"flops": fl, "bytes": by, "mm": name, "mfmas_per_block": mf,
+                "what": f"backward of {m} static-feature embedders in one grouped launch, weight gradients accumulated in the kernel"}
+
+    rc = PROFILE.launch(("mlp_bwd_group_lw", rows_all, m, int(arr[0].hid), int(arr[0].dout)), lambda: lib.nlam_mlp_bwd_group(arr, m, _stream()), meta)
+    if rc == -2:
+        return False
+    L.check(rc, "nlam_mlp_bwd_group (fused weight gradients)")
+
+    def is_direct(param, shape):
+        return (DIRECT_PARAM_GRADS and param is not None and param.grad is not None and param.grad.is_contiguous()
+                and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32)
+
+    keep = []
+    for (k, g, dw2p, vecp, nblk, vs) in work:
+        prm = params[k]
+        hid, kin = prm[0].shape
+        dout = prm[2].shape[0]
+        needs = [ctx.needs_input_grad[1 + 6 * k + q] for q in range(6)]
+        has_ln = prm[4] is not None
+        jobs = L.ReduceJobs()
+        res = [None] * 6
+        vbase = vecp.data_ptr()
+
+        def add(slot, ptr, stride, shape, param, ncols=0, ld=0, out_off=0, out=None):
+            n = 1
+            for d_ in shape:
+                n *= d_
+            direct = is_direct(param, param.shape)
+            if out is None:
+                out = param.grad if direct else (torch.zeros if ncols else torch.empty)(tuple(param.shape), device=dev, dtype=torch.float32)
+                if not direct:
+                    res[slot] = out
+            keep.append(out)
+            j = jobs.job[jobs.njobs]
+            j.partials, j.out, j.stride, j.nparts, j.accumulate = ptr, out.data_ptr() + 4 * out_off, stride, nblk, 1 if direct else 0
+            j.n, j.ncols, j.ld = n, ncols, ld
+            jobs.njobs += 1
+            return out
+
+        if needs[0]:   # dW1[:, c] = vector row 4 + c, scattered into column c of the (hid, kin) matrix
+            out = None
+            for c in range(kin):
+                out = add(0, vbase + (4 + c) * vs * 4, 7 * vs, (hid,), prm[0], ncols=1, ld=kin, out_off=c, out=out)
+        if needs[1]:
+            add(1, vbase + 0 * vs * 4, 7 * vs, (hid,), prm[1])
+        if needs[2]:
+            add(2, _ptr(dw2p), dout * hid, (dout, hid), prm[2])
+        if needs[3]:
+            add(3, vbase + 1 * vs * 4, 7 * vs, (dout,), prm[3])
+        if has_ln and needs[4]:
+            add(4, vbase + 2 * vs * 4, 7 * vs, (dout,), prm[4])
+        if has_ln and needs[5]:
+            add(5, vbase + 3 * vs * 4, 7 * vs, (dout,), prm[5])
+        if jobs.njobs > 0:
+            L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
+        if GRAD_LISTENER is not None:
+            GRAD_LISTENER.note_done([q for q, nd in zip(prm, needs) if nd and q is not None and is_direct(q, q.shape)])
+        grads[6 * k : 6 * k + 6] = res
+    return True
 
 
 def _linear_launch(x2d, W, ldn, ldk, k, n, out=None, accumulate=False, mm_flags=None, W2=None, out2=None):
