@@ -75,7 +75,8 @@ extern "C" {
 #define NLAM_F_PRE_ADD   16u
 /* nlam_mlp_bwd_group only: a leaf MLP (no data gradients) of <= 4 input columns accumulates its weight gradients in the
  * backward kernel itself -- dz1 / dz2 are never written: `dz2` receives the (workgroups, dout, hid) partial sums of dW2,
- * `dz1` is unused, `vec_partials` has SEVEN rows per workgroup: db1, db2, dgamma, dbeta, dW1[:, 0], dW1[:, 1], dW1[:, 2]. */
+ * `dz1` is unused, `vec_partials` has SEVEN rows per workgroup: db1, db2, dgamma, dbeta, dW1[:, 0], dW1[:, 1], dW1[:, 2].
+ * z1 may be NULL (then `b1` is required): the forward of such an MLP need not save its pre-activation. */
 #define NLAM_F_LEAF_WGRAD 32u
 /* matrix path of the GEMMs (bits 8-9): 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains);
  * n = 1..3: operands split into n bf16 terms on the bf16 matrix cores, fp32 accumulate
@@ -176,6 +177,8 @@ typedef struct {
     int32_t vec_stride;    /* row stride of vec_partials: multiple of 64, >= max(hid, dout) */
     float* wpack;          /* >= nlam_mlp_bwd_wpack_floats(p) floats, or NULL when that is 0 */
     int64_t wpack_floats;
+    const float* b1;       /* NLAM_F_LEAF_WGRAD only: first-layer bias; with z1 == NULL the kernel recomputes the pre-activation
+                              z1 = W1 x + b1 from the (<= 4-column) input instead of reading a saved copy */
 } nlam_mlp_bwd_t;
 
 typedef struct {

@@ -134,6 +134,7 @@ class MlpBwd(C.Structure):
         ("vec_stride", C.c_int32),
         ("wpack", C.c_void_p),
         ("wpack_floats", C.c_int64),
+        ("b1", C.c_void_p),
     ]
 
 

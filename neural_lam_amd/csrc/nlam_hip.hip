@@ -1650,6 +1650,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
     float* stg_all = gml + OP;                            // NWV x 32 x kStgStride
     float* colacc_all = stg_all + (size_t)NWV * 32 * kStgStride;   // NWV x 8 x 64 column accumulators
     float* xs_all = colacc_all + (size_t)NWV * 8 * 64;             // LW: NWV x [32][4] input rows of the tile
+    float* w1l = xs_all + (size_t)NWV * 32 * 4;                    // LW with z1 == NULL: W1 rows padded to 4 columns [DPH][4], then b1 [DPH]
     if constexpr (NS > 0) {
         // A[m = hidden][k = out (slot-permuted)] = W2[k][m]
         stage_split<NSW>(reinterpret_cast<u32x4*>(W2t), S2, 0, p.W2, 1, p.hid, HB, p.dout, true, p.hid);
@@ -1670,6 +1671,15 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         }
     }
     stage_vec(gml, p.ln_w, p.dout, OP, 1.f);
+    const bool recompute_z = LW && p.z1 == nullptr;
+    if (LW && recompute_z) {
+        const int kw = p.src[0].width;
+        for (int e = threadIdx.x; e < DPH * 4; e += blockDim.x) {
+            const int f_ = e >> 2, k_ = e & 3;
+            w1l[e] = (f_ < p.hid && k_ < kw) ? p.W1[(long)f_ * kw + k_] : 0.f;
+        }
+        for (int e = threadIdx.x; e < DPH; e += blockDim.x) w1l[DPH * 4 + e] = e < p.hid ? p.b1[e] : 0.f;
+    }
     __syncthreads();
     NLAM_T_MARK(0)
 
@@ -1734,7 +1744,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         const float* grow = p.g_out != nullptr ? p.g_out + (long)b * p.out_bstride + (long)oidx * p.dout : nullptr;
         const float* garow = p.g_aggr != nullptr ? p.g_aggr + ((size_t)b * p.nseg_total + sg) * p.dout : nullptr;
         const float* xrow = has_ln ? p.xhat + srow_c * p.dout : nullptr;
-        const float* zrow = p.z1 + srow_c * p.hid;
+        const float* zrow = p.z1 != nullptr ? p.z1 + srow_c * p.hid : nullptr;
         if constexpr (LW) {   // the tile's input rows (<= 4 columns), zero past the width and past the tile's rows
             if (hi == 0) {
                 const int kw = p.src[0].width;
@@ -1742,6 +1752,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
 #pragma unroll
                 for (int k = 0; k < 4; ++k) xs[j * 4 + k] = (valid && k < kw) ? xr[k] : 0.f;
             }
+            wave_lds_sync();
         }
 
         NLAM_T_MARK(1)
@@ -1872,13 +1883,30 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
             f32x4 hh[LW ? 4 : 1];   // LW: silu(z1) of this block, the B operand of dW2
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-                const f32x4 z = *reinterpret_cast<const f32x4*>(zrow + 8 * (hb * 4 + tt) + 4 * hi);
+                f32x4 z;
+                if (LW && recompute_z) {   // z1 = W1 x + b1 from the tile's input row (three FMAs per element) instead of a saved copy
+                    const int f0 = 8 * (hb * 4 + tt) + 4 * hi;
+                    const f32x4 xr = *reinterpret_cast<const f32x4*>(&xs[j * 4]);
+                    z = *reinterpret_cast<const f32x4*>(&w1l[DPH * 4 + f0]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x4 wr = *reinterpret_cast<const f32x4*>(&w1l[(f0 + c) * 4]);
+                        z[c] += wr[0] * xr[0] + wr[1] * xr[1] + wr[2] * xr[2] + wr[3] * xr[3];
+                    }
+                } else {
+                    z = *reinterpret_cast<const f32x4*>(zrow + 8 * (hb * 4 + tt) + 4 * hi);
+                }
                 f32x4 v;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    v[c] = valid ? dz1[hb][4 * tt + c] * silu_grad_f(z[c]) : 0.f;
+                    if constexpr (LW) {   // one sigmoid for silu and its derivative
+                        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-z[c]));
+                        v[c] = valid ? dz1[hb][4 * tt + c] * (sg * (1.f + z[c] * (1.f - sg))) : 0.f;
+                        hh[tt][c] = valid ? z[c] * sg : 0.f;
+                    } else {
+                        v[c] = valid ? dz1[hb][4 * tt + c] * silu_grad_f(z[c]) : 0.f;
+                    }
                     dz1[hb][4 * tt + c] = v[c];
-                    if constexpr (LW) hh[tt][c] = valid ? silu_f(z[c]) : 0.f;
                 }
                 *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = v;
             }
@@ -2960,7 +2988,7 @@ size_t bwd_fast_lds_bytes(const nlam_mlp_bwd_t* p, int HB, int OB, int NS) {
         if (p->dmode[s] != 0 && (!pre || s == 0)) wf += (size_t)p->src[s].width * DPH;
     if (NS > 0) wf = wf * NS / 2;
     const size_t nw = (p->flags & NLAM_F_LEAF_WGRAD) ? kLeafWaves : kWavesPerBlock;
-    const size_t xs = (p->flags & NLAM_F_LEAF_WGRAD) ? nw * 32 * 4 : 0;   // the tile's input rows (fused leaf weight gradients)
+    const size_t xs = (p->flags & NLAM_F_LEAF_WGRAD) ? nw * 32 * 4 + (size_t)DPH * 5 : 0;   // the tile's input rows + W1 / b1 (fused leaf weight gradients)
     return (wf + OP + nw * 32 * kStgStride + nw * 8 * 64 + xs) * sizeof(float);
 }
 
@@ -3611,7 +3639,8 @@ extern "C" int32_t nlam_mlp_bwd_group(const nlam_mlp_bwd_t* ps, int32_t n, void*
     int blocks[NLAM_MAX_GROUP];
     for (int k = 0; k < n; ++k) {
         const nlam_mlp_bwd_t& p = ps[k];
-        if (p.W1 == nullptr || p.W2 == nullptr || p.z1 == nullptr || p.batch < 1 || p.rows < 1 || p.g_out == nullptr) return NLAM_EINVAL;
+        if (p.W1 == nullptr || p.W2 == nullptr || p.batch < 1 || p.rows < 1 || p.g_out == nullptr) return NLAM_EINVAL;
+        if (p.z1 == nullptr && ((p.flags & NLAM_F_LEAF_WGRAD) == 0 || p.b1 == nullptr)) return NLAM_EINVAL;
         if (p.nsrc != 1 || bwd_is_wide(&p) || p.hid != ps[0].hid || p.dout != ps[0].dout || p.hid % 32 != 0 || p.dout % 32 != 0) return NLAM_EUNSUP;
         if ((p.flags & ~(NLAM_F_MM_MASK | NLAM_F_LEAF_WGRAD)) != 0 || (p.flags & (NLAM_F_MM_MASK | NLAM_F_LEAF_WGRAD)) != (ps[0].flags & (NLAM_F_MM_MASK | NLAM_F_LEAF_WGRAD)))
             return NLAM_EUNSUP;

@@ -962,6 +962,11 @@ class GroupedMLPFunction(torch.autograd.Function):
         dev = xs[0].device
         arr = (L.MlpFwd * n)()
         outs, saved, keep = [], [], []
+        # leaf MLPs of <= 3 input columns: the grouped backward accumulates the weight gradients itself and recomputes the
+        # pre-activation from the input (three FMAs per element), so the forward does not save z1 (a third of its bytes)
+        lw = (n > 1 and FUSED_LEAF_WGRAD and (mm_flags >> 8) & 3 != 0
+              and all(pr[0].shape[1] <= 3 and pr[0].shape[0] in (32, 64) and pr[2].shape[0] == pr[0].shape[0] for pr in params)
+              and len({(pr[0].shape[0], pr[4] is None) for pr in params}) == 1 and all(x.dim() == 2 for x in xs))
         for k in range(n):
             W1, b1, W2, b2, ln_w, ln_b = params[k]
             x = xs[k]
@@ -981,8 +986,9 @@ class GroupedMLPFunction(torch.autograd.Function):
             p.out, p.out_bstride = _ptr(out), rows * dout
             z1 = xhat = rstd = None
             if need_grad:
-                z1 = torch.empty((B, rows, hid), device=dev, dtype=torch.float32)
-                p.z1 = _ptr(z1)
+                if not lw:
+                    z1 = torch.empty((B, rows, hid), device=dev, dtype=torch.float32)
+                    p.z1 = _ptr(z1)
                 if ln_w is not None:
                     xhat = torch.empty((B, rows, dout), device=dev, dtype=torch.float32)
                     rstd = torch.empty((B, rows), device=dev, dtype=torch.float32)
@@ -1011,6 +1017,7 @@ class GroupedMLPFunction(torch.autograd.Function):
         else:
             L.check(rc, "nlam_mlp_fwd_group")
         if need_grad:
+            ctx.lw = lw
             ctx.n, ctx.params, ctx.saved, ctx.mm_flags = n, params, saved, mm_flags
             ctx.set_materialize_grads(False)
             if GRAD_LISTENER is not None:
@@ -1027,11 +1034,10 @@ class GroupedMLPFunction(torch.autograd.Function):
         if not live:
             return (None, *grads, *([None] * n))
         m = len(live)
-        if m > 1 and FUSED_LEAF_WGRAD and (ctx.mm_flags >> 8) & 3 and all(ctx.saved[k][4].shape[1] <= 3 and ctx.saved[k][4].shape[0] <= 64 and
-                                                                             ctx.saved[k][5].shape[0] <= 64 for k in live):
-            done = _grouped_backward_fused(ctx, g_outs, live, grads)
-            if done:
-                return (None, *grads, *([None] * n))
+        if ctx.lw:   # decided in forward (which did not save z1): the fused-weight-gradient kernel, for one or several live members
+            if not _grouped_backward_fused(ctx, g_outs, live, grads):
+                raise RuntimeError("nlam_mlp_bwd_group has no fused-weight-gradient kernel for a shape the forward planned it for")
+            return (None, *grads, *([None] * n))
         arr = (L.MlpBwd * m)()
         tiles = (C.c_int64 * m)()
         work = []
@@ -1140,12 +1146,14 @@ def _grouped_backward_fused(ctx, g_outs, live, grads):
         p.hid, p.dout, p.flags = hid, dout, ctx.mm_flags | L.F_LEAF_WGRAD
         p.g_out, p.out_bstride = _ptr(g), rows * dout
         p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
+        b1c = params[k][1].contiguous()
+        p.b1 = _ptr(b1c)
         nblk = int(blocks[i])
         vs = _vec_stride(hid, dout)
         dw2p = torch.empty((nblk, dout, hid), device=dev, dtype=torch.float32)
         vecp = torch.empty((nblk, 7, vs), device=dev, dtype=torch.float32)
         p.dz2, p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(dw2p), _ptr(vecp), nblk, vs
-        work.append((k, g, dw2p, vecp, nblk, vs))
+        work.append((k, g, dw2p, vecp, nblk, vs, b1c))
     rows_all = sum(int(arr[i].rows) * int(arr[i].batch) for i in range(m))
 
     def meta():
@@ -1165,7 +1173,7 @@ def _grouped_backward_fused(ctx, g_outs, live, grads):
                 and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32)
 
     keep = []
-    for (k, g, dw2p, vecp, nblk, vs) in work:
+    for (k, g, dw2p, vecp, nblk, vs, _b1c) in work:
         prm = params[k]
         hid, kin = prm[0].shape
         dout = prm[2].shape[0]
