@@ -275,6 +275,21 @@ class Trainer:
         return self._fwd_bwd_on(self._static_in)
 
     def _capture(self, *batch):
+        # No cyclic garbage collection between here and the end of the capture: on ROCm the destructor of a torch CUDAGraph
+        # synchronises the device, which is an error inside a stream capture and, thrown from a destructor, aborts the
+        # process -- an older Trainer that the collector happens to free from the autograd thread mid-capture did that.
+        import gc
+
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_locked(*batch)
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _capture_locked(self, *batch):
         self._static_in = [b.clone() for b in batch]
         self._static_sig = [(tuple(b.shape), b.dtype) for b in batch]
         self.buckets.enabled = False
