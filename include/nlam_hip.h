@@ -375,6 +375,39 @@ typedef struct {
 } nlam_cat_t;
 int32_t nlam_concat(const nlam_cat_t* p, void* hip_stream);
 
+/* The data path: WeatherDataset.__getitem__ (weather_dataset.py:467-533) for a BATCH of sample indices, cut straight out
+ * of analysis time series that are resident in HBM -- _slice_state_time (:199-262, analysis branch :255-261),
+ * _slice_forcing_time (:264-361, analysis branch :330-359), the feature-major / window-minor stacking of the forcing
+ * window (:443-445) -- optionally followed, in the same pass, by ForecasterModule.on_after_batch_transfer
+ * (models/module.py:326-367: (x - mean) / std, forcing statistics tiled over the window, IEEE sub + div).
+ *   sample i = sample_idx[b]:  state rows  [i + max(0, past - 2), i + max(2, past) + ar_steps)  -> 2 init + ar_steps target
+ *                              forcing of step t, window slot w:  time  i + max(2, past) + t - past + w
+ *                              forcing_windowed[b][t][n][f * window + w],  window = past + future + 1
+ * Sample indices are read on the device (a resident permutation drives an epoch without host traffic); they must lie
+ * in [0, nlam_window_len): the kernel clamps the time index instead of faulting, the Python wrapper validates host
+ * indices (IndexError as weather_dataset.py:497-503).  HBM-bound: every output float is read once and written once. */
+typedef struct {
+    const float* state;          /* (n_times, nodes, d_state) */
+    const float* forcing;        /* (n_times, nodes, d_forcing) or NULL when d_forcing == 0 */
+    const int64_t* times;        /* (n_times) time stamps (ns) or NULL */
+    const int64_t* sample_idx;   /* device, (batch) */
+    float* init_states;          /* (batch, 2, nodes, d_state) */
+    float* target_states;        /* (batch, ar_steps, nodes, d_state) */
+    float* forcing_windowed;     /* (batch, ar_steps, nodes, d_forcing * window) or NULL when d_forcing == 0 */
+    int64_t* target_times;       /* (batch, ar_steps) or NULL */
+    const float* state_mean;     /* (d_state)   all four NULL: raw values, as the reference's dataset returns them */
+    const float* state_std;      /* (d_state) */
+    const float* forcing_mean;   /* (d_forcing) */
+    const float* forcing_std;    /* (d_forcing) */
+    int64_t n_times;
+    int32_t nodes, d_state, d_forcing, batch;
+    int32_t ar_steps, num_past_forcing_steps, num_future_forcing_steps, _pad;
+} nlam_window_t;
+/* len(WeatherDataset) for analysis data (weather_dataset.py:179-194); n_forcing_times < 0: no forcing */
+int64_t nlam_window_len(int64_t n_state_times, int64_t n_forcing_times, int32_t ar_steps, int32_t num_past_forcing_steps,
+                        int32_t num_future_forcing_steps);
+int32_t nlam_window_batch(const nlam_window_t* p, void* hip_stream);
+
 /* decoupled-weight-decay Adam on flat buffers; step_count is the 1-based step */
 int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step_count,

@@ -51,6 +51,8 @@ EXPORTS = [
     "nlam_step_tail_fwd",
     "nlam_step_tail_bwd",
     "nlam_concat",
+    "nlam_window_len",
+    "nlam_window_batch",
 ]
 
 
@@ -202,6 +204,32 @@ class Cat(C.Structure):
     ]
 
 
+class Window(C.Structure):
+    _fields_ = [
+        ("state", C.c_void_p),
+        ("forcing", C.c_void_p),
+        ("times", C.c_void_p),
+        ("sample_idx", C.c_void_p),
+        ("init_states", C.c_void_p),
+        ("target_states", C.c_void_p),
+        ("forcing_windowed", C.c_void_p),
+        ("target_times", C.c_void_p),
+        ("state_mean", C.c_void_p),
+        ("state_std", C.c_void_p),
+        ("forcing_mean", C.c_void_p),
+        ("forcing_std", C.c_void_p),
+        ("n_times", C.c_int64),
+        ("nodes", C.c_int32),
+        ("d_state", C.c_int32),
+        ("d_forcing", C.c_int32),
+        ("batch", C.c_int32),
+        ("ar_steps", C.c_int32),
+        ("num_past_forcing_steps", C.c_int32),
+        ("num_future_forcing_steps", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
 class StdJob(C.Structure):
     _fields_ = [
         ("x", C.c_void_p),
@@ -287,6 +315,10 @@ def load():
     lib.nlam_step_tail_bwd.restype = i32
     lib.nlam_concat.argtypes = [C.POINTER(Cat), vp]
     lib.nlam_concat.restype = i32
+    lib.nlam_window_len.argtypes = [i64, i64, i32, i32, i32]
+    lib.nlam_window_len.restype = i64
+    lib.nlam_window_batch.argtypes = [C.POINTER(Window), vp]
+    lib.nlam_window_batch.restype = i32
     lib.nlam_mlp_group_blocks.argtypes = [C.POINTER(C.c_int64), i32, C.POINTER(C.c_int32)]
     lib.nlam_mlp_group_blocks.restype = i32
     lib.nlam_mlp_fwd_group.argtypes = [C.POINTER(MlpFwd), i32, vp]

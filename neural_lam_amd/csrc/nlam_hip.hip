@@ -2730,6 +2730,56 @@ __global__ void step_tail_bwd_kernel(const float* __restrict__ g_pred, const flo
 // row-wise concatenation (nlam_concat): a workgroup owns 64 consecutive rows; every source's 64 x w_k block is one
 // contiguous span in memory (read coalesced into the LDS row image), and so is the 64 x wtot output block
 constexpr int kCatRows = 64;
+// nlam_window_batch: blockIdx.z = sample of the batch, blockIdx.y = 0 -> the 2 + ar_steps state rows (contiguous
+// (nodes x d_state) blocks of the series), 1 -> the windowed forcing (a (window x d_forcing) -> (d_forcing x window)
+// transpose per node: consecutive lanes write consecutive floats; their reads walk `window` contiguous streams)
+__global__ __launch_bounds__(256) void window_batch_kernel(const nlam_window_t p) {
+    const int b = blockIdx.z;
+    const long i = p.sample_idx[b];
+    const int past = p.num_past_forcing_steps, fut = p.num_future_forcing_steps;
+    const long last = p.n_times - 1;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long)gridDim.x * blockDim.x;
+    if (blockIdx.y == 0) {
+        const long per = (long)p.nodes * p.d_state;
+        const long t0 = i + max(0, past - 2);
+        const long total = (long)(2 + p.ar_steps) * per;
+        const bool stdz = p.state_mean != nullptr;
+        for (long e = tid; e < total; e += nthr) {
+            const long r = e / per, rem = e - r * per;
+            const long t = min(max(t0 + r, 0L), last);
+            float v = p.state[t * per + rem];
+            if (stdz) {
+                const int f = (int)(rem % p.d_state);
+                v = __fdiv_rn(__fsub_rn(v, p.state_mean[f]), p.state_std[f]);
+            }
+            if (r < 2) p.init_states[((long)b * 2 + r) * per + rem] = v;
+            else p.target_states[((long)b * p.ar_steps + (r - 2)) * per + rem] = v;
+        }
+        if (p.target_times != nullptr && p.times != nullptr && blockIdx.x == 0 && threadIdx.x < p.ar_steps) {
+            const long t = min(max(i + max(2, past) + (long)threadIdx.x, 0L), last);
+            p.target_times[(long)b * p.ar_steps + threadIdx.x] = p.times[t];
+        }
+    } else {
+        if (p.d_forcing == 0) return;
+        const int W = past + fut + 1;
+        const int fw = p.d_forcing * W;
+        const long per_in = (long)p.nodes * p.d_forcing, per_out = (long)p.nodes * fw;
+        const long off = i + max(2, past);
+        const long total = (long)p.ar_steps * per_out;
+        const bool stdz = p.forcing_mean != nullptr;
+        for (long e = tid; e < total; e += nthr) {
+            const long step = e / per_out, rem = e - step * per_out;
+            const long n = rem / fw;
+            const int j = (int)(rem - n * fw);
+            const int f = j / W, w = j - f * W;
+            const long t = min(max(off + step - past + w, 0L), last);
+            float v = p.forcing[t * per_in + n * p.d_forcing + f];
+            if (stdz) v = __fdiv_rn(__fsub_rn(v, p.forcing_mean[f]), p.forcing_std[f]);
+            p.forcing_windowed[((long)b * p.ar_steps + step) * per_out + rem] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void concat_kernel(const nlam_cat_t p, int wtot) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const long ntile = ((long)p.nodes + kCatRows - 1) / kCatRows;
@@ -3852,6 +3902,36 @@ int32_t nlam_detail::wgrad_narrow(const nlam_wgrad_t* p, hipStream_t stream) {
 
 #if NLAM_IN_TU(5)
 extern "C" {
+
+int64_t nlam_window_len(int64_t n_state_times, int64_t n_forcing_times, int32_t ar_steps, int32_t past, int32_t future) {
+    const int64_t window = (int64_t)(past > 2 ? past : 2) + ar_steps + future;
+    int64_t n = n_state_times - window + 1;
+    if (n_forcing_times >= 0 && n_forcing_times - window + 1 < n) n = n_forcing_times - window + 1;
+    return n > 0 ? n : 0;
+}
+
+int32_t nlam_window_batch(const nlam_window_t* p, void* hip_stream) {
+    if (p == nullptr || p->state == nullptr || p->sample_idx == nullptr || p->init_states == nullptr || p->target_states == nullptr)
+        return NLAM_EINVAL;
+    if (p->batch < 0 || p->nodes < 0 || p->d_state < 1 || p->d_forcing < 0 || p->ar_steps < 1 || p->ar_steps > 256 ||
+        p->num_past_forcing_steps < 0 || p->num_future_forcing_steps < 0 || p->n_times < 1)
+        return NLAM_EINVAL;
+    if (p->d_forcing > 0 && (p->forcing == nullptr || p->forcing_windowed == nullptr)) return NLAM_EINVAL;
+    if ((p->state_mean == nullptr) != (p->state_std == nullptr) || (p->forcing_mean == nullptr) != (p->forcing_std == nullptr)) return NLAM_EINVAL;
+    if (p->state_mean != nullptr && p->d_forcing > 0 && p->forcing_mean == nullptr) return NLAM_EINVAL;   // all or nothing, as the reference's hook
+    if (nlam_window_len(p->n_times, p->d_forcing > 0 ? p->n_times : -1, p->ar_steps, p->num_past_forcing_steps, p->num_future_forcing_steps) < 1)
+        return NLAM_EINVAL;   // the series is shorter than one sample
+    if (p->batch == 0 || p->nodes == 0) return 0;
+    const long window = p->num_past_forcing_steps + p->num_future_forcing_steps + 1;
+    const long e_state = (long)(2 + p->ar_steps) * p->nodes * p->d_state;
+    const long e_forc = (long)p->ar_steps * p->nodes * p->d_forcing * window;
+    long blocks = ((e_state > e_forc ? e_state : e_forc) + 1023) / 1024;   // four elements per thread
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    if (p->batch > 65535) return NLAM_EUNSUP;
+    hipLaunchKernelGGL(window_batch_kernel, dim3((int)blocks, p->d_forcing > 0 ? 2 : 1, p->batch), dim3(256), 0, (hipStream_t)hip_stream, *p);
+    return (int32_t)hipGetLastError();
+}
 
 int32_t nlam_pre_add_supported(const nlam_mlp_fwd_t* p) {
     /* would nlam_mlp_fwd (and the matching nlam_mlp_bwd) run this NLAM_F_PRE_ADD problem on a factorised kernel?

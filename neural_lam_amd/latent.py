@@ -12,10 +12,11 @@ Reference -> here:
   GraphLatentEncoder       models/latent/graph_encoder.py:11-105
   BaseGraphLatentDecoder   models/latent/base_decoder.py:9-171
   GraphLatentDecoder       models/latent/graph_decoder.py:11-134
+  HiGraphLatentEncoder     models/latent/hi_graph_encoder.py:14-175
+  HiGraphLatentDecoder     models/latent/hi_graph_decoder.py:17-270
 
-The hierarchical variants (``hi_graph_encoder.py``, ``hi_graph_decoder.py``) and the ``GraphEFM`` step predictor that
-drives them (``step_predictors/graph/graph_efm.py``: ELBO terms, prior / variational sampling) are out of scope of the
-hot path; they compose the same layer classes and would run on them unchanged.
+The ``GraphEFM`` step predictor that drives them (``step_predictors/graph/graph_efm.py``: ELBO terms, prior /
+variational sampling) is out of scope of the hot path; it composes these classes unchanged.
 """
 from __future__ import annotations
 
@@ -24,7 +25,7 @@ from torch import distributions as tdists
 from torch import nn
 
 from . import _lib as L
-from .gnn_layers import get_gnn_class, make_gnn_seq, make_mlp
+from .gnn_layers import InteractionNet, PropagationNet, get_gnn_class, make_gnn_seq, make_mlp
 from .ops import MlpGeometry
 
 
@@ -128,3 +129,79 @@ class GraphLatentDecoder(BaseGraphLatentDecoder):
         if self.m2m_gnns is not None:
             mesh_rep, _ = self.m2m_gnns(mesh_rep, graph_emb["m2m"], need_last_edges=False)
         return self.m2g_gnn(mesh_rep, residual_grid_rep, graph_emb["m2g"])
+
+
+def _need_levels(name, flat_name, m2m_edge_index):
+    if len(m2m_edge_index) < 2:   # hi_graph_encoder.py:69-74 / hi_graph_decoder.py:88-93
+        raise ValueError(f"{name} requires at least 2 mesh levels (got {len(m2m_edge_index)}). Use {flat_name} for flat graphs.")
+
+
+class HiGraphLatentEncoder(BaseLatentEncoder):
+    """hi_graph_encoder.py:14-175: grid -> bottom mesh level (g2m), then up the hierarchy through PropagationNets with
+    optional intra-level stacks; the latent parameters are read out on the top level."""
+
+    def __init__(self, latent_dim, g2m_edge_index, m2m_edge_index, mesh_up_edge_index, hidden_dim, intra_level_layers,
+                 hidden_layers=1, g2m_gnn_type="InteractionNet", output_dist="isotropic"):
+        super().__init__(latent_dim, output_dist)
+        _need_levels("HiGraphLatentEncoder", "GraphLatentEncoder", m2m_edge_index)
+        self.g2m_gnn = get_gnn_class(g2m_gnn_type)(g2m_edge_index, hidden_dim, hidden_layers=hidden_layers, update_edges=False)
+        # always PropagationNets: an upward step must push information into nodes that start from their static embedding (:83-97)
+        self.mesh_up_gnns = nn.ModuleList(
+            [PropagationNet(ei, hidden_dim, hidden_layers=hidden_layers, update_edges=False) for ei in mesh_up_edge_index])
+        self.intra_level_gnns = (
+            nn.ModuleList([make_gnn_seq(ei, intra_level_layers, hidden_layers, hidden_dim) for ei in m2m_edge_index])
+            if intra_level_layers > 0 else None)
+        self.latent_param_map = make_mlp([hidden_dim] * (hidden_layers + 1) + [self.output_dim], layer_norm=False)
+
+    def compute_dist_params(self, grid_rep, graph_emb, **kwargs):
+        cur = self.g2m_gnn(grid_rep, graph_emb["mesh"][0], graph_emb["g2m"])
+        if self.intra_level_gnns is not None:
+            cur, _ = self.intra_level_gnns[0](cur, graph_emb["m2m"][0], need_last_edges=False)   # edge outputs are discarded (:151-153)
+        for level, (up_gnn, up_rep, mesh_rep) in enumerate(zip(self.mesh_up_gnns, graph_emb["mesh_up"], graph_emb["mesh"][1:]), start=1):
+            cur = up_gnn(cur, mesh_rep, up_rep)
+            if self.intra_level_gnns is not None:
+                cur, _ = self.intra_level_gnns[level](cur, graph_emb["m2m"][level], need_last_edges=False)
+        return self.latent_param_map(cur)
+
+
+class HiGraphLatentDecoder(BaseGraphLatentDecoder):
+    """hi_graph_decoder.py:17-270: g2m onto the bottom level, up the hierarchy (InteractionNets; the latent is the
+    receiver state of the last upward step), down again (PropagationNets onto the upward pass' level states, intra-level
+    stacks on the upward pass' edge states), m2g onto the residual grid representation."""
+
+    def __init__(self, g2m_edge_index, m2m_edge_index, m2g_edge_index, mesh_up_edge_index, mesh_down_edge_index, hidden_dim,
+                 latent_dim, num_state_vars, intra_level_layers, hidden_layers=1, g2m_gnn_type="InteractionNet",
+                 m2g_gnn_type="InteractionNet", output_std=True):
+        super().__init__(hidden_dim, latent_dim, num_state_vars, hidden_layers, output_std)
+        _need_levels("HiGraphLatentDecoder", "GraphLatentDecoder", m2m_edge_index)
+        self.g2m_gnn = get_gnn_class(g2m_gnn_type)(g2m_edge_index, hidden_dim, hidden_layers=hidden_layers, update_edges=False)
+        self.m2g_gnn = get_gnn_class(m2g_gnn_type)(m2g_edge_index, hidden_dim, hidden_layers=hidden_layers, update_edges=False)
+        self.mesh_up_gnns = nn.ModuleList(
+            [InteractionNet(ei, hidden_dim, hidden_layers=hidden_layers, update_edges=False) for ei in mesh_up_edge_index])
+        self.mesh_down_gnns = nn.ModuleList(
+            [PropagationNet(ei, hidden_dim, hidden_layers=hidden_layers, update_edges=False) for ei in mesh_down_edge_index])
+        if intra_level_layers > 0:
+            self.intra_up_gnns = nn.ModuleList([make_gnn_seq(ei, intra_level_layers, hidden_layers, hidden_dim) for ei in m2m_edge_index])
+            self.intra_down_gnns = nn.ModuleList(
+                [make_gnn_seq(ei, intra_level_layers, hidden_layers, hidden_dim) for ei in list(m2m_edge_index)[:-1]])
+        else:
+            self.intra_up_gnns = self.intra_down_gnns = None
+
+    def combine_with_latent(self, original_grid_rep, latent_rep, residual_grid_rep, graph_emb):
+        cur = self.g2m_gnn(original_grid_rep, graph_emb["mesh"][0], graph_emb["g2m"])
+        mesh_level_reps, m2m_level_reps = [], []
+        receivers = list(graph_emb["mesh"][1:-1]) + [latent_rep]
+        for level, (up_gnn, up_rep, mesh_rep) in enumerate(zip(self.mesh_up_gnns, graph_emb["mesh_up"], receivers)):
+            new_mesh, new_m2m = cur, None
+            if self.intra_up_gnns is not None:   # these edge states feed the downward pass (:246-248): keep the last layer's
+                new_mesh, new_m2m = self.intra_up_gnns[level](new_mesh, graph_emb["m2m"][level])
+            mesh_level_reps.append(new_mesh)
+            m2m_level_reps.append(new_m2m)
+            cur = up_gnn(new_mesh, mesh_rep, up_rep)
+        if self.intra_up_gnns is not None:
+            cur, _ = self.intra_up_gnns[-1](cur, graph_emb["m2m"][-1], need_last_edges=False)
+        for level in reversed(range(len(self.mesh_down_gnns))):
+            cur = self.mesh_down_gnns[level](cur, mesh_level_reps[level], graph_emb["mesh_down"][level])
+            if self.intra_down_gnns is not None:
+                cur, _ = self.intra_down_gnns[level](cur, m2m_level_reps[level], need_last_edges=False)
+        return self.m2g_gnn(cur, residual_grid_rep, graph_emb["m2g"])

@@ -246,12 +246,71 @@ def latent_case(ref, name, d, latent_dim, m2m_layers, B, seed, output_dist="diag
     print(f"  latent case {name}: loss={float(loss):.6f}")
 
 
+def hi_latent_case(ref, name, d, latent_dim, intra_layers, B, seed, output_dist="diagonal", g2m_gnn_type="InteractionNet",
+                   m2g_gnn_type="InteractionNet"):
+    """Hierarchical Graph-EFM latent encoder + decoder (reference files models/latent/hi_graph_{encoder,decoder}.py,
+    imported unmodified) on a 3-level hierarchy: distribution parameters, decoder outputs, all gradients."""
+    import importlib
+
+    latent = importlib.import_module("neural_lam.models.latent")
+    nx, ny = 81, 30
+    raw = G.create_regular_grid_graph(G.regular_grid_xy(nx, ny), n_max_levels=3, hierarchical=True)
+    g2m, m2g = raw["g2m_edge_index"], raw["m2g_edge_index"]
+    m2m, up, down = list(raw["m2m_edge_index"]), list(raw["mesh_up_edge_index"]), list(raw["mesh_down_edge_index"])
+    n_grid = nx * ny
+    n_mesh = [int(f.shape[0]) for f in raw["mesh_features"]]
+    num_state = 5
+    torch.manual_seed(seed)
+    enc = latent.HiGraphLatentEncoder(latent_dim, g2m, m2m, up, d, intra_layers, hidden_layers=1, g2m_gnn_type=g2m_gnn_type,
+                                      output_dist=output_dist)
+    dec = latent.HiGraphLatentDecoder(g2m, m2m, m2g, up, down, d, latent_dim, num_state, intra_layers, hidden_layers=1,
+                                      g2m_gnn_type=g2m_gnn_type, m2g_gnn_type=m2g_gnn_type, output_std=True)
+    gen = torch.Generator().manual_seed(seed + 1)
+    t = lambda *shape: torch.randn(*shape, generator=gen)  # noqa: E731
+    inputs = {"grid_rep": t(B, n_grid, d), "g2m": t(B, g2m.shape[1], d), "m2g": t(B, m2g.shape[1], d), "eps": t(B, n_mesh[-1], latent_dim)}
+    for lv, n in enumerate(n_mesh):
+        inputs[f"mesh_{lv}"] = t(B, n, d)
+        inputs[f"m2m_{lv}"] = t(B, m2m[lv].shape[1], d)
+    for lv in range(len(up)):
+        inputs[f"mesh_up_{lv}"] = t(B, up[lv].shape[1], d)
+        inputs[f"mesh_down_{lv}"] = t(B, down[lv].shape[1], d)
+    leaves = {k: v.clone().requires_grad_() for k, v in inputs.items() if k != "eps"}
+    L = len(n_mesh)
+    emb = {"g2m": leaves["g2m"], "m2g": leaves["m2g"], "mesh": [leaves[f"mesh_{lv}"] for lv in range(L)],
+           "m2m": [leaves[f"m2m_{lv}"] for lv in range(L)], "mesh_up": [leaves[f"mesh_up_{lv}"] for lv in range(L - 1)],
+           "mesh_down": [leaves[f"mesh_down_{lv}"] for lv in range(L - 1)]}
+    dist = enc(leaves["grid_rep"], graph_emb=emb)
+    z = dist.mean + dist.stddev * inputs["eps"]
+    mean_delta, pred_std = dec(leaves["grid_rep"], z, emb)
+    cot = {"mean": t(*dist.mean.shape), "std": t(*dist.stddev.shape), "delta": t(*mean_delta.shape), "pstd": t(*pred_std.shape)}
+    loss = (dist.mean * cot["mean"]).sum() + (dist.stddev * cot["std"]).sum() + (mean_delta * cot["delta"]).sum() + (pred_std * cot["pstd"]).sum()
+    loss.backward()
+    case = {
+        "note": NOTE, "d": d, "latent_dim": latent_dim, "intra_layers": intra_layers, "num_state": num_state, "output_dist": output_dist,
+        "g2m_gnn_type": g2m_gnn_type, "m2g_gnn_type": m2g_gnn_type, "levels": L,
+        "g2m_edge_index": g2m, "m2g_edge_index": m2g, "m2m_edge_index": m2m, "mesh_up_edge_index": up, "mesh_down_edge_index": down,
+        "inputs": inputs, "cotangents": cot,
+        "enc_state_dict": {k: v.clone() for k, v in enc.state_dict().items()},
+        "dec_state_dict": {k: v.clone() for k, v in dec.state_dict().items()},
+        "ref_latent_mean": dist.mean.detach().clone(), "ref_latent_std": dist.stddev.detach().clone(),
+        "ref_mean_delta": mean_delta.detach().clone(), "ref_pred_std": pred_std.detach().clone(),
+        # (a leaf the computation never reaches has no gradient: stored as None and checked as such)
+        "ref_grad_inputs": {k: (None if v.grad is None else v.grad.clone()) for k, v in leaves.items()},
+        "ref_grad_enc": {k: p.grad.clone() for k, p in enc.named_parameters()},
+        "ref_grad_dec": {k: p.grad.clone() for k, p in dec.named_parameters()},
+    }
+    torch.save(case, HERE / f"{name}.pt")
+    print(f"  hierarchical latent case {name}: levels={L} nodes={n_mesh} loss={float(loss):.6f}")
+
+
 def main():
     ref = rh.load_reference()
     if "--latent-only" in sys.argv:
         latent_case(ref, "latent_flat_d64", 64, 16, 2, 2, 50)
         latent_case(ref, "latent_flat_d16_prop", 16, 8, 1, 1, 51, output_dist="isotropic", g2m_gnn_type="PropagationNet",
                     m2g_gnn_type="PropagationNet")
+        hi_latent_case(ref, "latent_hi_d32", 32, 8, 1, 1, 52)
+        hi_latent_case(ref, "latent_hi_d16_nointra", 16, 4, 0, 1, 53, output_dist="isotropic", g2m_gnn_type="PropagationNet")
         return
     if "--wide-only" in sys.argv:
         make_layers_wide(ref)
@@ -263,6 +322,8 @@ def main():
     latent_case(ref, "latent_flat_d64", 64, 16, 2, 2, 50)
     latent_case(ref, "latent_flat_d16_prop", 16, 8, 1, 1, 51, output_dist="isotropic", g2m_gnn_type="PropagationNet",
                 m2g_gnn_type="PropagationNet")
+    hi_latent_case(ref, "latent_hi_d32", 32, 8, 1, 1, 52)
+    hi_latent_case(ref, "latent_hi_d16_nointra", 16, 4, 0, 1, 53, output_dist="isotropic", g2m_gnn_type="PropagationNet")
     ds_small = DS_SMALL
     model_case(ref, "graphlam_30x27", "GraphLAM", ds_small, dict(n_max_levels=None, hierarchical=False),
                dict(hidden_dim=16, hidden_layers=1, processor_layers=2), B=2, T=2, seed=42)

@@ -44,9 +44,10 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "nlam_hip.h"\n'
-        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nlam_src_t), sizeof(nlam_mlp_fwd_t),'
+        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nlam_src_t), sizeof(nlam_mlp_fwd_t),'
         " sizeof(nlam_mlp_bwd_t), sizeof(nlam_wgrad_t), offsetof(nlam_mlp_fwd_t, rstd),"
-        " offsetof(nlam_mlp_bwd_t, vec_partials), offsetof(nlam_wgrad_t, partials)); return 0;}\n"
+        " offsetof(nlam_mlp_bwd_t, vec_partials), offsetof(nlam_wgrad_t, partials), sizeof(nlam_window_t),"
+        " offsetof(nlam_window_t, n_times), offsetof(nlam_window_t, ar_steps)); return 0;}\n"
     )
     exe = tmp_path / "sz"
     subprocess.run(["gcc", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)], check=True)
@@ -54,6 +55,7 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     assert sizes == [
         C.sizeof(L.Src), C.sizeof(L.MlpFwd), C.sizeof(L.MlpBwd), C.sizeof(L.Wgrad),
         L.MlpFwd.rstd.offset, L.MlpBwd.vec_partials.offset, L.Wgrad.partials.offset,
+        C.sizeof(L.Window), L.Window.n_times.offset, L.Window.ar_steps.offset,
     ]
 
 
