@@ -266,6 +266,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-data-path", action="store_true", help="skip the leg that trains from the HBM-resident dataset")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying a HIP graph")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = run the step inside torch.autocast(bfloat16), as Lightning --precision bf16-mixed does (cfg5)")
@@ -348,6 +349,54 @@ def main():
         torch.cuda.synchronize()
         fc_elapsed = time.perf_counter() - t0
     forecast_steps_per_s = world * cfg["B"] * cfg["T"] * fsteps / fc_elapsed
+
+    # the same step fed by the data path: samples cut from an HBM-resident series by nlam_window_batch with
+    # on_after_batch_transfer folded in, written straight into the captured step's input buffers -- reported beside
+    # `value`, which stays the reference-shaped step (a batch handed over on the device)
+    data_path = None
+    if world == 1 and not args.no_data_path and not args.eager and args.precision == "fp32":
+        from neural_lam_amd import models as hm
+        from neural_lam_amd.data import DeviceWeatherDataset
+
+        ds2, _, _, fc2, _, _ = build(cfg, device, seed_offset=rank)
+        step2 = hm.ForecasterStep(fc2, ds2, standardize=False).to(device)
+        tr2 = Trainer(step2, lr=1e-3, use_graph=True)
+        n_times, N = 24, ds2.num_grid_points
+        gg = torch.Generator(device=device).manual_seed(7)
+        series_state = torch.randn(n_times, N, cfg["ns"], device=device, generator=gg)
+        series_forcing = torch.randn(n_times, N, cfg["nf"], device=device, generator=gg)
+        dset = DeviceWeatherDataset(series_state, series_forcing, None, ar_steps=cfg["T"], num_past_forcing_steps=1,
+                                    num_future_forcing_steps=1, standardization=step2.standardization_stats())
+        perm = dset.epoch_permutation(seed=0)
+        nb = len(dset) // cfg["B"]
+        for k in range(args.warmup):
+            tr2.step_from(dset, perm[(k % nb) * cfg["B"] : (k % nb + 1) * cfg["B"]])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            tr2.step_from(dset, perm[(k % nb) * cfg["B"] : (k % nb + 1) * cfg["B"]])
+        torch.cuda.synchronize()
+        dp_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        # the window launch alone: HIP events, algorithmic bytes = every output float read once and written once
+        idx = perm[: cfg["B"]]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        outs = dset.batch(idx, standardize=True)
+        torch.cuda.synchronize()
+        wg = torch.cuda.CUDAGraph()   # 50 launches replayed back to back: the Python call (~30 us) is longer than the kernel
+        with torch.cuda.graph(wg):
+            for _ in range(50):
+                dset.batch(idx, standardize=True, out=outs)
+        wg.replay()
+        e0.record()
+        wg.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        w_us = e0.elapsed_time(e1) / 50 * 1e3
+        w_bytes = 2 * 4 * sum(t.numel() for t in outs[:3])
+        data_path = {"ms_per_step": dp_ms, "samples": "DeviceWeatherDataset: %d-step series resident in HBM, window 1+1+1, indices from a resident permutation" % n_times,
+                     "window_launch_us": w_us, "window_algorithmic_bytes": w_bytes, "window_GBps": w_bytes / w_us * 1e-3,
+                     "window_hbm_frac": w_bytes / w_us * 1e-3 / PEAK_HBM_GBS}
+        del tr2, step2, fc2, dset
 
     roofline = None
     if not args.no_roofline:
@@ -432,6 +481,8 @@ def main():
             },
             "roofline": roofline,
         }
+        if data_path is not None:
+            out["from_device_dataset"] = data_path
         if world == 1 and not args.no_cpu_baseline:
             o0 = oracle_loss_step0(cfg)
             out["oracle_loss_step0"] = o0

@@ -2730,52 +2730,99 @@ __global__ void step_tail_bwd_kernel(const float* __restrict__ g_pred, const flo
 // row-wise concatenation (nlam_concat): a workgroup owns 64 consecutive rows; every source's 64 x w_k block is one
 // contiguous span in memory (read coalesced into the LDS row image), and so is the 64 x wtot output block
 constexpr int kCatRows = 64;
-// nlam_window_batch: blockIdx.z = sample of the batch, blockIdx.y = 0 -> the 2 + ar_steps state rows (contiguous
-// (nodes x d_state) blocks of the series), 1 -> the windowed forcing (a (window x d_forcing) -> (d_forcing x window)
-// transpose per node: consecutive lanes write consecutive floats; their reads walk `window` contiguous streams)
+// nlam_window_batch: blockIdx.z = sample of the batch, blockIdx.y = row: 0 .. 1 + ar_steps -> one (nodes x d_state) block
+// of the state series (a contiguous copy), then ar_steps rows of windowed forcing (a (window x d_forcing) ->
+// (d_forcing x window) transpose per node: consecutive lanes write consecutive floats, their reads walk `window`
+// contiguous streams).  Four consecutive floats per thread and 32-bit index arithmetic: one division per four
+// elements, the feature / window counters advance incrementally (64-bit divisions per element made the first version
+// run at a tenth of the HBM rate).
 __global__ __launch_bounds__(256) void window_batch_kernel(const nlam_window_t p) {
     const int b = blockIdx.z;
     const long i = p.sample_idx[b];
     const int past = p.num_past_forcing_steps, fut = p.num_future_forcing_steps;
     const long last = p.n_times - 1;
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long)gridDim.x * blockDim.x;
-    if (blockIdx.y == 0) {
-        const long per = (long)p.nodes * p.d_state;
-        const long t0 = i + max(0, past - 2);
-        const long total = (long)(2 + p.ar_steps) * per;
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+    const int nstate_rows = 2 + p.ar_steps;
+    if ((int)blockIdx.y < nstate_rows) {
+        const int r = blockIdx.y;
+        const unsigned per = (unsigned)p.nodes * (unsigned)p.d_state;
+        const long t = min(max(i + max(0, past - 2) + r, 0L), last);
+        const float* src = p.state + t * (long)per;
+        float* dst = r < 2 ? p.init_states + ((long)b * 2 + r) * per : p.target_states + ((long)b * p.ar_steps + (r - 2)) * per;
         const bool stdz = p.state_mean != nullptr;
-        for (long e = tid; e < total; e += nthr) {
-            const long r = e / per, rem = e - r * per;
-            const long t = min(max(t0 + r, 0L), last);
-            float v = p.state[t * per + rem];
-            if (stdz) {
-                const int f = (int)(rem % p.d_state);
-                v = __fdiv_rn(__fsub_rn(v, p.state_mean[f]), p.state_std[f]);
+        const unsigned d = p.d_state;
+        const bool vec = (per & 3u) == 0 && ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) & 15) == 0;
+        for (unsigned q = tid; q < (per + 3) / 4; q += nthr) {
+            const unsigned e0 = 4 * q;
+            float v[4];
+            if (vec) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(src + e0);
+                v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = e0 + k < per ? src[e0 + k] : 0.f;
             }
-            if (r < 2) p.init_states[((long)b * 2 + r) * per + rem] = v;
-            else p.target_states[((long)b * p.ar_steps + (r - 2)) * per + rem] = v;
+            if (stdz) {
+                unsigned f = e0 % d;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = __fdiv_rn(__fsub_rn(v[k], p.state_mean[f]), p.state_std[f]);
+                    f = f + 1 == d ? 0 : f + 1;
+                }
+            }
+            if (vec) {
+                *reinterpret_cast<f32x4*>(dst + e0) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (e0 + k < per) dst[e0 + k] = v[k];
+            }
         }
-        if (p.target_times != nullptr && p.times != nullptr && blockIdx.x == 0 && threadIdx.x < p.ar_steps) {
-            const long t = min(max(i + max(2, past) + (long)threadIdx.x, 0L), last);
-            p.target_times[(long)b * p.ar_steps + threadIdx.x] = p.times[t];
+        if (r == 2 && p.target_times != nullptr && p.times != nullptr && blockIdx.x == 0 && (int)threadIdx.x < p.ar_steps) {
+            const long tt = min(max(i + max(2, past) + (long)threadIdx.x, 0L), last);
+            p.target_times[(long)b * p.ar_steps + threadIdx.x] = p.times[tt];
         }
     } else {
         if (p.d_forcing == 0) return;
-        const int W = past + fut + 1;
-        const int fw = p.d_forcing * W;
-        const long per_in = (long)p.nodes * p.d_forcing, per_out = (long)p.nodes * fw;
-        const long off = i + max(2, past);
-        const long total = (long)p.ar_steps * per_out;
+        const int step = (int)blockIdx.y - nstate_rows;
+        const unsigned W = past + fut + 1, df = p.d_forcing;
+        const unsigned fw = df * W;
+        const unsigned per_out = (unsigned)p.nodes * fw;
+        const long per_in = (long)p.nodes * df;
+        const long t0 = i + max(2, past) + step - past;   // time of window slot 0
+        float* dst = p.forcing_windowed + ((long)b * p.ar_steps + step) * per_out;
         const bool stdz = p.forcing_mean != nullptr;
-        for (long e = tid; e < total; e += nthr) {
-            const long step = e / per_out, rem = e - step * per_out;
-            const long n = rem / fw;
-            const int j = (int)(rem - n * fw);
-            const int f = j / W, w = j - f * W;
-            const long t = min(max(off + step - past + w, 0L), last);
-            float v = p.forcing[t * per_in + n * p.d_forcing + f];
-            if (stdz) v = __fdiv_rn(__fsub_rn(v, p.forcing_mean[f]), p.forcing_std[f]);
-            p.forcing_windowed[((long)b * p.ar_steps + step) * per_out + rem] = v;
+        const bool vec = (per_out & 3u) == 0 && (reinterpret_cast<size_t>(dst) & 15) == 0;
+        for (unsigned q = tid; q < (per_out + 3) / 4; q += nthr) {
+            const unsigned e0 = 4 * q;
+            unsigned n = e0 / fw;
+            unsigned jj = e0 - n * fw;
+            unsigned fi = jj / W, w = jj - fi * W;
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x = 0.f;
+                if (e0 + k < per_out) {
+                    const long t = min(max(t0 + (long)w, 0L), last);
+                    x = p.forcing[t * per_in + (long)n * df + fi];
+                    if (stdz) x = __fdiv_rn(__fsub_rn(x, p.forcing_mean[fi]), p.forcing_std[fi]);
+                }
+                v[k] = x;
+                if (++w == W) {
+                    w = 0;
+                    if (++fi == df) {
+                        fi = 0;
+                        ++n;
+                    }
+                }
+            }
+            if (vec) {
+                *reinterpret_cast<f32x4*>(dst + e0) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (e0 + k < per_out) dst[e0 + k] = v[k];
+            }
         }
     }
 }
@@ -3923,13 +3970,14 @@ int32_t nlam_window_batch(const nlam_window_t* p, void* hip_stream) {
         return NLAM_EINVAL;   // the series is shorter than one sample
     if (p->batch == 0 || p->nodes == 0) return 0;
     const long window = p->num_past_forcing_steps + p->num_future_forcing_steps + 1;
-    const long e_state = (long)(2 + p->ar_steps) * p->nodes * p->d_state;
-    const long e_forc = (long)p->ar_steps * p->nodes * p->d_forcing * window;
-    long blocks = ((e_state > e_forc ? e_state : e_forc) + 1023) / 1024;   // four elements per thread
+    const long e_state = (long)p->nodes * p->d_state;                       // one row of the launch (blockIdx.y)
+    const long e_forc = (long)p->nodes * p->d_forcing * window;
+    if (e_state >= (1L << 31) || e_forc >= (1L << 31) || p->batch > 65535) return NLAM_EUNSUP;   // 32-bit offsets inside a row
+    long blocks = ((e_state > e_forc ? e_state : e_forc) + 2047) / 2048;    // four elements per thread, two rounds
     if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;
-    if (p->batch > 65535) return NLAM_EUNSUP;
-    hipLaunchKernelGGL(window_batch_kernel, dim3((int)blocks, p->d_forcing > 0 ? 2 : 1, p->batch), dim3(256), 0, (hipStream_t)hip_stream, *p);
+    if (blocks > 512) blocks = 512;
+    const int rows = 2 + p->ar_steps + (p->d_forcing > 0 ? p->ar_steps : 0);
+    hipLaunchKernelGGL(window_batch_kernel, dim3((int)blocks, rows, p->batch), dim3(256), 0, (hipStream_t)hip_stream, *p);
     return (int32_t)hipGetLastError();
 }
 

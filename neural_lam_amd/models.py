@@ -666,6 +666,14 @@ class ForecasterStep(nn.Module):
         else:
             self.forcing_mean = self.forcing_std = None
 
+    def standardization_stats(self):
+        """The statistics ``on_after_batch_transfer`` uses (module.py:159-215; std clamped to eps, :306-324), in the form
+        ``neural_lam_amd.data.DeviceWeatherDataset(standardization=...)`` takes to fold the hook into its batch launch."""
+        d = {"state_mean": self.state_mean, "state_std": self.state_std}
+        if self.forcing_mean is not None:
+            d.update(forcing_mean=self.forcing_mean, forcing_std=self.forcing_std)
+        return d
+
     def standardize(self, init_states, target_states, forcing):
         """module.py:326-367: one launch for the three tensors (``nlam_standardize``)."""
         from .ops import standardize as std_launch

@@ -347,3 +347,30 @@ class Trainer:
         self.buckets.finish_step()
         self.opt.step(1.0 / self.world)
         return loss
+
+    def step_from(self, dataset, indices, standardize=True):
+        """One optimizer step on ``dataset.batch(indices)`` (``neural_lam_amd.data.DeviceWeatherDataset``): the data path of
+        the reference's training loop -- WeatherDataset.__getitem__ + collation + on_after_batch_transfer,
+        weather_dataset.py:467-533, models/module.py:326-367 -- as ONE launch in front of the step.  With a captured
+        step the samples are written straight into the graph's static input buffers (no staging copy); ``indices`` may
+        be a slice of a device-resident permutation, so an epoch runs without host->device traffic.
+
+        ``standardize=True`` folds on_after_batch_transfer into that launch: the module must then NOT standardise again
+        (``ForecasterStep(standardize=False)``).  Returns the loss; ``self.batch_times`` holds the target times."""
+        if getattr(self.module, "standardize_inputs", False) and standardize:
+            raise ValueError("the module standardises its inputs itself: pass standardize=False or build it with standardize=False")
+        if self.use_graph and self._graph is not None:
+            B = int(indices.numel()) if isinstance(indices, torch.Tensor) else len(indices)
+            if self._static_in[0].shape[0] == B and len(self._static_in) == 3:
+                if self.batch_times is None or self.batch_times.shape != (B, dataset.ar_steps):
+                    self.batch_times = torch.empty((B, dataset.ar_steps), device=self._static_in[0].device, dtype=torch.int64)
+                dataset.batch(indices, standardize=standardize, out=(*self._static_in, self.batch_times))
+                self._graph.replay()
+                if self.world > 1:
+                    self.buckets.all_reduce_whole()
+                self.opt.step(1.0 / self.world)
+                return self._static_loss.clone()
+        init, target, forcing, self.batch_times = dataset.batch(indices, standardize=standardize)
+        return self.step(init, target, forcing)
+
+    batch_times = None

@@ -234,3 +234,47 @@ def test_hip_dataset_full_size_round_trip_properties():
         for w in range(W):
             assert torch.equal(fr[..., w], forcing[off + t - past + w : off + t - past + w + len(ds)])
     assert torch.equal(target[:-1, 1], target[1:, 0])   # sample i's second target is sample i + 1's first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_training_from_the_device_dataset_equals_training_from_handed_over_batches(tmp_path, use_graph):
+    """Trainer.step_from(dataset, indices) -- samples written by nlam_window_batch, on_after_batch_transfer folded in, straight
+    into the captured step's input buffers -- against the reference-shaped loop (raw batch handed over, the module
+    standardises): identical losses and parameters, step after step."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import models as hm
+    from neural_lam_amd.data import DeviceWeatherDataset
+    from neural_lam_amd.datastore import SyntheticDatastore
+    from neural_lam_amd.trainer import Trainer
+
+    dev = torch.device("cuda:0")
+    dstore = SyntheticDatastore(30, 27, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+    ext = dstore.get_xy_extent("state")
+    graph = G.normalise_graph(G.create_regular_grid_graph(dstore.get_xy("state")), max(ext[1] - ext[0], ext[3] - ext[2]))
+
+    def make(std_in_module):
+        torch.manual_seed(3)
+        fc = hm.ARForecaster(hm.GraphLAM(dstore, graph=graph, hidden_dim=16, processor_layers=2), dstore)
+        return Trainer(hm.ForecasterStep(fc, dstore, standardize=std_in_module).to(dev), lr=1e-3, use_graph=use_graph)
+
+    t_ref, t_dev = make(True), make(False)
+    N, T, past, fut = dstore.num_grid_points, 2, 1, 1
+    state, forcing, times = _series(14, N, 5, 2, seed=9)
+    data = DeviceWeatherDataset(state, forcing, times, ar_steps=T, num_past_forcing_steps=past, num_future_forcing_steps=fut,
+                                standardization=t_dev.module.standardization_stats())
+    perm = data.epoch_permutation(seed=2)
+    B = 2
+    for k in range(3):
+        idx = perm[k * B : (k + 1) * B]
+        raw = data.batch(idx)                                     # what the reference's DataLoader would hand over
+        l_ref = float(t_ref.step(raw[0], raw[1], raw[2]))
+        l_dev = float(t_dev.step_from(data, idx))
+        assert l_ref == l_dev, (k, l_ref, l_dev)
+        assert torch.equal(t_ref.fp.flat, t_dev.fp.flat)
+        assert torch.equal(t_dev.batch_times, raw[3])
+    assert (t_dev._graph is not None) == use_graph
+    with pytest.raises(ValueError):
+        t_ref.step_from(data, perm[:B])                           # would standardise twice
