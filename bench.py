@@ -405,12 +405,17 @@ def main():
         psteps = min(args.steps, 30)
         ops.PROFILE.reset(enabled=True)
         trainer.use_graph = False   # per-launch HIP events need eager launches
+        # ... on ONE stream: with the weight-gradient side streams on, an event pair around a 20 us launch also times the
+        # wait for side-stream workgroups to leave its CUs (a 6 561-row launch read 40 us instead of 23), i.e. the
+        # schedule, not the kernel.  The schedule is what `ms_per_step` and the committed timeline measure.
+        overlap_was, trainer.overlap_wgrad = trainer.overlap_wgrad, False
         for _ in range(psteps):
             trainer.step(*batch)
         torch.cuda.synchronize()
         recs, meta = ops.PROFILE.collect(), dict(ops.PROFILE.meta)
         ops.PROFILE.reset(enabled=False)
         trainer.use_graph = not args.eager
+        trainer.overlap_wgrad = overlap_was
         traffic = None
         for tfile in (ROOT / "profiles" / "round2" / "pmc_traffic.json", ):
             if tfile.exists() and args.config == "cfg2" and args.precision == "fp32":
@@ -439,7 +444,7 @@ def main():
                 "traffic": top["traffic"],
                 "kernel": top["launch"] + ": " + top["what"],
                 "note": "frac = max(executed MFMA FLOPs / dense peak of the instruction issued, algorithmic HBM bytes / 8 TB/s); "
-                        "times = HIP events on the launch stream, eager instrumented pass of %d steps" % psteps,
+                        "times = HIP events on the launch stream, eager instrumented pass of %d steps with every launch on one stream (uncontended kernel durations)" % psteps,
                 "kernels": rows[:6],
                 "step": {
                     "ms": ms_per_step,
