@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import math
 import os
+import warnings
 from dataclasses import dataclass
 from pathlib import Path
 
@@ -31,6 +32,7 @@ from scipy.spatial import KDTree  # same class + leafsize as the reference: 4-NN
 
 GRAPH_SPEC_VERSION = "0.1.0"  # create_graph.py:24
 METAINFO_FILENAME = "metainfo.yaml"  # create_graph.py:23
+LEGACY_GRAPH_SPEC_VERSION = "legacy"   # utils/graph.py:18
 DM_SCALE = 0.67  # create_graph.py:698
 MESH_CHILDREN = 3  # create_graph.py:436 (nx)
 
@@ -243,25 +245,71 @@ def read_graph_files(graph_dir: str | os.PathLike) -> dict:
             raw[f"{name}_features"] = ld(f"{name}_features.pt")
     meta = graph_dir / METAINFO_FILENAME
     if not meta.exists():
-        raise ValueError(
-            f"{meta} missing: only graph spec {GRAPH_SPEC_VERSION} is supported "
-            "(the reference's legacy pre-spec format is out of scope)"
+        # utils/graph.py:239-252: no metainfo = the legacy pre-spec format
+        warnings.warn(
+            "Graph metainfo file is missing; assuming this graph uses the legacy pre-spec format. Mesh node feature "
+            "normalization will be skipped because legacy mesh node features are assumed to already be normalized. Edge "
+            "indices will be zero-offset on load to convert legacy offset node labels to the per-node-set zero-based index "
+            "spaces required by the current graph spec.",
+            RuntimeWarning, stacklevel=3,
         )
-    spec = (yaml.safe_load(meta.read_text(encoding="utf-8")) or {}).get("spec_version")
+        raw["spec_version"] = LEGACY_GRAPH_SPEC_VERSION
+        return raw
+    try:
+        parsed = yaml.safe_load(meta.read_text(encoding="utf-8"))
+    except yaml.YAMLError as exc:
+        raise ValueError(f"Failed to parse {METAINFO_FILENAME}: {exc}") from exc
+    spec = None if parsed is None else parsed.get("spec_version")
+    if spec is None:
+        raise ValueError(f"{METAINFO_FILENAME} is missing 'spec_version' entry")
     if spec != GRAPH_SPEC_VERSION:
         raise ValueError(f"Unsupported graph spec version {spec!r} in {METAINFO_FILENAME}")
     return raw
+
+
+def zero_index_legacy(raw: dict) -> dict:
+    """Legacy (pre-spec) graphs label all nodes in ONE index space (mesh levels and grid offset against each other);
+    the current spec wants every node set zero-based.  utils/graph.py:20-143 (``zero_index_edge_index``,
+    ``zero_index_m2g``, ``zero_index_g2m``) and :305-323, :362-370 of ``load_graph``."""
+
+    def zero(ei):   # both rows start at 0
+        return ei - ei.min(dim=1, keepdim=True)[0]
+
+    out = dict(raw)
+    out["m2m_edge_index"] = [zero(e) for e in raw["m2m_edge_index"]]
+    g2m, m2g = raw["g2m_edge_index"], raw["m2g_edge_index"]
+    mins = m2g.min(dim=1, keepdim=True)[0]
+    mesh_first = bool(mins[0] < mins[1])
+    if mesh_first:   # grid labels were offset by the TOTAL mesh node count (all levels)
+        n_mesh = sum(int(f.shape[0]) for f in raw["mesh_features"])
+        out["g2m_edge_index"] = torch.stack((g2m[0] - n_mesh, g2m[1]), dim=0)
+        out["m2g_edge_index"] = torch.stack((m2g[0], m2g[1] - n_mesh), dim=0)
+    else:            # grid first: mesh labels were offset by the number of grid (g2m) / interior (m2g) nodes
+        out["g2m_edge_index"] = torch.stack((g2m[0], g2m[1] - (g2m[0].max() + 1)), dim=0)
+        out["m2g_edge_index"] = torch.stack((m2g[0] - (m2g[1].max() + 1), m2g[1]), dim=0)
+    assert int(out["m2g_edge_index"].min()) >= 0, "Negative node index in m2g"
+    assert int(out["g2m_edge_index"].min()) >= 0, "Negative node index in g2m"
+    for name in ("mesh_up", "mesh_down"):
+        if f"{name}_edge_index" in raw:
+            out[f"{name}_edge_index"] = [zero(e) for e in raw[f"{name}_edge_index"]]
+    return out
 
 
 def normalise_graph(raw: dict, mesh_node_features_scaling: float):
     """Load-time normalisation of utils/graph.py:291-303 (mesh coords / max grid
     span) and :343-350 (edge features / longest m2m edge); flat graphs unwrap
     level 0 (:399-408).  Returns (hierarchical, dict of tensors / lists)."""
-    if mesh_node_features_scaling == 0:
-        mesh_node_features_scaling = 1.0
+    legacy = raw.get("spec_version") == LEGACY_GRAPH_SPEC_VERSION
+    if legacy:   # :286-323: legacy mesh features are already normalised; node labels become zero-based per node set
+        raw = zero_index_legacy(raw)
     mesh = [m.clone().to(torch.float32) for m in raw["mesh_features"]]
-    for m in mesh:
-        m[:, :2] /= mesh_node_features_scaling
+    if not legacy:
+        if mesh_node_features_scaling == 0:
+            warnings.warn("Mesh node feature scaling is zero; falling back to 1.0 so mesh node coordinates are left unchanged "
+                          "after graph loading.", RuntimeWarning, stacklevel=2)
+            mesh_node_features_scaling = 1.0
+        for m in mesh:
+            m[:, :2] /= mesh_node_features_scaling
     m2m_ei = [e.clone() for e in raw["m2m_edge_index"]]
     hierarchical = len(m2m_ei) > 1
     longest = max(torch.max(f[:, 0]) for f in raw["m2m_features"])
@@ -300,7 +348,8 @@ def normalise_graph(raw: dict, mesh_node_features_scaling: float):
 
 
 def load_graph(graph_dir, mesh_node_features_scaling: float):
-    """Mirror of ``utils.load_graph`` (utils/graph.py:146) for spec-0.1.0 graphs."""
+    """Mirror of ``utils.load_graph`` (utils/graph.py:146-422): spec-0.1.0 graphs and, with a RuntimeWarning, the legacy
+    pre-spec format (no metainfo file: offset node labels, pre-normalised mesh coordinates)."""
     return normalise_graph(read_graph_files(graph_dir), mesh_node_features_scaling)
 
 

@@ -303,8 +303,54 @@ def hi_latent_case(ref, name, d, latent_dim, intra_layers, B, seed, output_dist=
     print(f"  hierarchical latent case {name}: levels={L} nodes={n_mesh} loss={float(loss):.6f}")
 
 
+def legacy_graph_cases(ref):
+    """Legacy (pre-spec) graph directories -- one node index space, no metainfo.yaml -- loaded by the reference's own
+    ``utils.load_graph`` (utils/graph.py:146-422).  The directories are made from the reference generator's output by
+    re-applying the legacy offsets: mesh levels first then the grid (hierarchical case), grid first then the mesh (flat)."""
+    import warnings
+
+    cases = {}
+    for name, nx, ny, kw, mesh_first in (("hi_mesh_first", 81, 30, dict(n_max_levels=3, hierarchical=True), True),
+                                         ("flat_grid_first", 30, 27, dict(n_max_levels=None, hierarchical=False), False)):
+        tmp = Path(tempfile.mkdtemp())
+        ref.create_graph.create_graph(str(tmp), G.regular_grid_xy(nx, ny), **kw)
+        raw = G.read_graph_files(tmp)
+        n_mesh = [int(f.shape[0]) for f in raw["mesh_features"]]
+        lvl_off = [sum(n_mesh[:l]) for l in range(len(n_mesh))]
+        n_grid = nx * ny
+        legacy = dict(raw)
+        legacy["m2m_edge_index"] = [e + lvl_off[l] + (0 if mesh_first else n_grid) for l, e in enumerate(raw["m2m_edge_index"])]
+        if mesh_first:
+            legacy["g2m_edge_index"] = torch.stack((raw["g2m_edge_index"][0] + sum(n_mesh), raw["g2m_edge_index"][1]))
+            legacy["m2g_edge_index"] = torch.stack((raw["m2g_edge_index"][0], raw["m2g_edge_index"][1] + sum(n_mesh)))
+        else:
+            legacy["g2m_edge_index"] = torch.stack((raw["g2m_edge_index"][0], raw["g2m_edge_index"][1] + n_grid))
+            legacy["m2g_edge_index"] = torch.stack((raw["m2g_edge_index"][0] + n_grid, raw["m2g_edge_index"][1]))
+        if "mesh_up_edge_index" in raw:
+            legacy["mesh_up_edge_index"] = [torch.stack((e[0] + lvl_off[l], e[1] + lvl_off[l + 1])) for l, e in enumerate(raw["mesh_up_edge_index"])]
+            legacy["mesh_down_edge_index"] = [torch.stack((e[0] + lvl_off[l + 1], e[1] + lvl_off[l])) for l, e in enumerate(raw["mesh_down_edge_index"])]
+        legacy["mesh_features"] = [f / 7.5 for f in raw["mesh_features"]]   # "already normalised": any fixed scaling
+        ldir = tmp / "legacy"
+        ldir.mkdir()
+        for k, v in legacy.items():
+            if k != "spec_version":
+                torch.save(v, ldir / f"{k}.pt")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            hier, loaded = ref.utils.load_graph(str(ldir), 123.0)   # the scaling must be ignored for legacy graphs
+        assert any(issubclass(x.category, RuntimeWarning) for x in w)
+        loaded = {k: (list(v) if not torch.is_tensor(v) else v) for k, v in loaded.items()}
+        cases[name] = {"legacy_files": compress_graph({k: v for k, v in legacy.items() if k != "spec_version"}),
+                       "ref_hierarchical": hier, "ref_graph_loaded": compress_graph(loaded)}
+        print(f"  legacy graph case {name}: hierarchical={hier} levels={len(n_mesh)}")
+    torch.save({"note": NOTE, "cases": cases}, HERE / "legacy_graphs.pt")
+
+
 def main():
     ref = rh.load_reference()
+    if "--legacy-only" in sys.argv:
+        legacy_graph_cases(ref)
+        return
     if "--latent-only" in sys.argv:
         latent_case(ref, "latent_flat_d64", 64, 16, 2, 2, 50)
         latent_case(ref, "latent_flat_d16_prop", 16, 8, 1, 1, 51, output_dist="isotropic", g2m_gnn_type="PropagationNet",
@@ -319,6 +365,7 @@ def main():
         return
     make_layers(ref)
     make_layers_wide(ref)
+    legacy_graph_cases(ref)
     latent_case(ref, "latent_flat_d64", 64, 16, 2, 2, 50)
     latent_case(ref, "latent_flat_d16_prop", 16, 8, 1, 1, 51, output_dist="isotropic", g2m_gnn_type="PropagationNet",
                 m2g_gnn_type="PropagationNet")

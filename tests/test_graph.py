@@ -70,6 +70,39 @@ def test_meps_sizes_match_reference_generator():
     assert G.graph_summary(G.create_regular_grid_graph(xy, n_max_levels=3, hierarchical=True)) == ref["hierarchical"]
 
 
+@pytest.mark.parametrize("name", ["hi_mesh_first", "flat_grid_first"])
+def test_legacy_graph_loads_like_the_reference_loader(name, tmp_path):
+    """Pre-spec graph directories (one node index space, no metainfo.yaml): zero-based per node set, mesh coordinates
+    left alone, RuntimeWarning -- against what the reference's own utils.load_graph returned for the same files
+    (tests/golden/make_golden.py::legacy_graph_cases; utils/graph.py:20-143, :239-252, :286-323, :362-370)."""
+    from conftest import to64
+
+    case = load_golden("legacy_graphs")["cases"][name]
+    for k, v in case["legacy_files"].items():
+        torch.save([to64(x) for x in v] if isinstance(v, list) else to64(v), tmp_path / f"{k}.pt")
+    with pytest.warns(RuntimeWarning, match="legacy pre-spec format"):
+        hier, loaded = G.load_graph(tmp_path, 123.0)   # the scaling is ignored for legacy graphs
+    assert hier == case["ref_hierarchical"]
+    for k, v in case["ref_graph_loaded"].items():
+        mine = loaded[k]
+        if isinstance(v, list):
+            assert len(mine) == len(v), k
+            for a, b in zip(mine, v):
+                assert torch.equal(a, to64(b)), k
+        else:
+            assert torch.equal(mine, to64(v)), k
+    for ei in [loaded["g2m_edge_index"], loaded["m2g_edge_index"]]:
+        assert int(ei.min()) >= 0   # (not necessarily 0: a node set need not be fully connected, utils/graph.py:46)
+
+
+def test_metainfo_without_spec_version_raises(tmp_path):
+    raw = G.create_regular_grid_graph(G.regular_grid_xy(27, 27))
+    G.save_graph(tmp_path, raw)
+    (tmp_path / G.METAINFO_FILENAME).write_text("something_else: 1\n")
+    with pytest.raises(ValueError, match="spec_version"):
+        G.load_graph(tmp_path, 1.0)
+
+
 def test_unsupported_spec_raises(tmp_path):
     raw = G.create_regular_grid_graph(G.regular_grid_xy(27, 27))
     G.save_graph(tmp_path, raw)
