@@ -346,8 +346,79 @@ def legacy_graph_cases(ref):
     torch.save({"note": NOTE, "cases": cases}, HERE / "legacy_graphs.pt")
 
 
+def efm_case(ref, name, cls_name, ds_kwargs, graph_kwargs, model_kwargs, B, seed):
+    """Graph-EFM step predictor (reference file models/step_predictors/graph/graph_efm.py, imported unmodified): one forward
+    with the prior sample the reference drew (the standard-normal noise is recorded and checked against the latent the
+    decoder received), its outputs, and the gradients of a fixed linear functional of them."""
+    import importlib
+
+    efm = importlib.import_module("neural_lam.models.step_predictors.graph.graph_efm")
+    tmp = tempfile.mkdtemp()
+    ds = SyntheticDatastore(root_path=tmp, **ds_kwargs)
+    gdir = Path(tmp) / "graph" / "g"
+    ref.create_graph.create_graph(str(gdir), ds.get_xy("state"), **graph_kwargs)
+    raw = G.read_graph_files(gdir)
+    torch.manual_seed(seed)
+    model = getattr(efm, cls_name)(ds, graph_name="g", **model_kwargs)
+    n_state, n_forc, N = ds.get_num_data_vars("state"), ds.get_num_data_vars("forcing"), ds.num_grid_points
+    g = torch.Generator().manual_seed(seed + 1)
+    prev, prev_prev = torch.randn(B, N, n_state, generator=g), torch.randn(B, N, n_state, generator=g)
+    forcing = torch.randn(B, N, n_forc * 3, generator=g)
+    if model_kwargs.get("output_clamping_lower") or model_kwargs.get("output_clamping_upper"):
+        prev, prev_prev = prev.abs() * 0.1 + 0.2, prev_prev.abs() * 0.1 + 0.2
+    seen = {}
+    model.decoder.register_forward_pre_hook(lambda mod, args: seen.__setitem__("latent", args[1].detach().clone()))
+    # the noise Normal.rsample will draw: same generator state, same shape (nothing else in forward touches the RNG)
+    lat_shape = (B, model.latent_spatial_dim, model.latent_dim)
+    torch.manual_seed(seed + 2)
+    noise = torch.empty(lat_shape).normal_()
+    torch.manual_seed(seed + 2)
+    pred_mean, pred_std = model(prev, prev_prev, forcing)
+    with torch.no_grad():
+        grid_emb, graph_emb = model.embedd_grid_and_graph(prev, prev_prev, forcing)
+        dist = model.prior_model(grid_emb, graph_emb=graph_emb)
+        assert torch.allclose(seen["latent"], dist.mean + dist.stddev * noise, rtol=0, atol=0), "recorded noise is not what rsample drew"
+        # the variational encoder is not on forward's path: its output goes into the fixture on its own
+        enc_in = model.embedd_grid_with_target(prev, prev_prev, forcing, prev + 0.1)
+        enc_dist = model.encoder(enc_in, graph_emb=graph_emb)
+    cot = {"mean": torch.randn(pred_mean.shape, generator=g)}
+    loss = (pred_mean * cot["mean"]).sum()
+    if pred_std is not None:
+        cot["std"] = torch.randn(pred_std.shape, generator=g)
+        loss = loss + (pred_std * cot["std"]).sum()
+    loss.backward()
+    case = {
+        "note": NOTE, "cls": cls_name, "ds_kwargs": ds_kwargs, "graph_kwargs": graph_kwargs, "model_kwargs": model_kwargs,
+        "ref_graph_raw": compress_graph(raw),
+        "state_dict": {k: v.detach().clone() for k, v in model.state_dict().items()},
+        "prev": prev, "prev_prev": prev_prev, "forcing": forcing, "noise": noise, "cotangents": cot,
+        "ref_latent": seen["latent"], "ref_pred_mean": pred_mean.detach(), "ref_pred_std": None if pred_std is None else pred_std.detach(),
+        "ref_enc_mean": enc_dist.mean.clone(), "ref_enc_std": enc_dist.stddev.clone(),
+        # parameters off forward's path (the variational encoder, grid_current_embedder) have no gradient: None
+        "ref_grads": {k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()},
+    }
+    torch.save(case, HERE / f"{name}.pt")
+    print(f"  EFM case {name}: loss={float(loss):.6f} params={sum(p.numel() for p in model.parameters())} latent={lat_shape}")
+
+
+def efm_cases(ref):
+    ds_hi = dict(nx=81, ny=30, num_state=5, num_forcing=2, num_static=1, boundary="frame", boundary_width=4, seed=5)
+    efm_case(ref, "efm_hi_81x30", "GraphEFM", ds_hi, dict(n_max_levels=3, hierarchical=True),
+             dict(hidden_dim=16, latent_dim=8, prior_intra_level_layers=1, encoder_intra_level_layers=1, decoder_intra_level_layers=2,
+                  output_std=True), B=1, seed=60)
+    efm_case(ref, "efm_ms_30x27", "GraphEFMMultiScale", DS_SMALL, dict(n_max_levels=None, hierarchical=False),
+             dict(hidden_dim=32, prior_m2m_layers=1, encoder_m2m_layers=1, decoder_m2m_layers=2, prior_dist="diagonal",
+                  output_clamping_lower={"state_var_0": 0.0}, output_clamping_upper={"state_var_2": 1.0}), B=2, seed=61)
+    efm_case(ref, "efm_hi_constprior_81x30", "GraphEFM", ds_hi, dict(n_max_levels=3, hierarchical=True),
+             dict(hidden_dim=8, latent_dim=4, prior_intra_level_layers=0, encoder_intra_level_layers=0, decoder_intra_level_layers=0,
+                  learn_prior=False, g2m_gnn_type="PropagationNet", m2g_gnn_type="PropagationNet"), B=1, seed=62)
+
+
 def main():
     ref = rh.load_reference()
+    if "--efm-only" in sys.argv:
+        efm_cases(ref)
+        return
     if "--legacy-only" in sys.argv:
         legacy_graph_cases(ref)
         return
@@ -366,6 +437,7 @@ def main():
     make_layers(ref)
     make_layers_wide(ref)
     legacy_graph_cases(ref)
+    efm_cases(ref)
     latent_case(ref, "latent_flat_d64", 64, 16, 2, 2, 50)
     latent_case(ref, "latent_flat_d16_prop", 16, 8, 1, 1, 51, output_dist="isotropic", g2m_gnn_type="PropagationNet",
                 m2g_gnn_type="PropagationNet")
