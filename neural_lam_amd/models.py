@@ -674,8 +674,9 @@ class ForecasterStep(nn.Module):
             d.update(forcing_mean=self.forcing_mean, forcing_std=self.forcing_std)
         return d
 
-    def standardize(self, init_states, target_states, forcing):
-        """module.py:326-367: one launch for the three tensors (``nlam_standardize``)."""
+    def standardize(self, init_states, target_states, forcing, out=None):
+        """module.py:326-367: one launch for the three tensors (``nlam_standardize``).  ``out``: three preallocated tensors
+        (the trainer hands over the static inputs of its captured step: no separate staging copy of the batch)."""
         from .ops import standardize as std_launch
 
         items = [(init_states, self.state_mean, self.state_std, 1), (target_states, self.state_mean, self.state_std, 1)]
@@ -683,8 +684,10 @@ class ForecasterStep(nn.Module):
         if has_forcing:
             window = forcing.shape[-1] // self.forcing_mean.shape[-1]
             items.append((forcing, self.forcing_mean, self.forcing_std, window))
-        outs = std_launch(items)
-        return outs[0], outs[1], (outs[2] if has_forcing else forcing)
+        outs = std_launch(items, None if out is None else list(out[: len(items)]))
+        if not has_forcing and out is not None:
+            out[2].copy_(forcing)
+        return outs[0], outs[1], (outs[2] if has_forcing else (forcing if out is None else out[2]))
 
     def forward(self, init_states, target_states, forcing, standardize: bool | None = None):
         if standardize is None:

@@ -1563,22 +1563,25 @@ class ConcatFunction(torch.autograd.Function):
         return tuple(grads)
 
 
-def standardize(items):
+def standardize(items, outs=None):
     """``ForecasterModule.on_after_batch_transfer`` (models/module.py:326-367) for up to four tensors in one launch.
 
     items: list of (x, mean, std, rep) -> list of ``(x - mean.repeat_interleave(rep)) / std.repeat_interleave(rep)``
-    (fp32, last dim = features).  The batch is data: no autograd."""
+    (fp32, last dim = features).  The batch is data: no autograd.  ``outs``: preallocated outputs (the static inputs of
+    a captured step: the standardisation then doubles as the copy of the batch into the graph's buffers)."""
     lib = L.load()
     assert 1 <= len(items) <= 4
     jobs = L.StdJobs()
-    outs, keep = [], []
+    given, outs, keep = outs, [], []
     for k, (x, mean, std, rep) in enumerate(items):
         _require_gpu(x, mean, std)
         xc, mc, sc = x.detach().contiguous(), mean.contiguous(), std.contiguous()
         width = xc.shape[-1]
         if width % rep != 0 or mc.numel() * rep != width or sc.numel() != mc.numel():
             raise RuntimeError(f"standardize: {mc.numel()} statistics x window {rep} do not cover {width} features")
-        out = torch.empty_like(xc)
+        out = torch.empty_like(xc) if given is None else given[k]
+        if out.shape != xc.shape or out.dtype != torch.float32 or not out.is_contiguous() or xc.dtype != torch.float32:
+            raise RuntimeError(f"standardize: output {tuple(out.shape)} / {out.dtype} does not fit input {tuple(xc.shape)} / {xc.dtype}")
         j = jobs.job[k]
         j.x, j.out, j.mean, j.std = _ptr(xc), _ptr(out), _ptr(mc), _ptr(sc)
         j.rows, j.width, j.rep = (xc.numel() // width if width else 0), width, rep
