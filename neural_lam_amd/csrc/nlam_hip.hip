@@ -2531,6 +2531,58 @@ __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32
     }
 }
 
+// Long segments (the sender view of the mesh -> grid edges: 6 561 segments of ~39 rows): with one thread per
+// (segment, float4 column) the launch is 105 k threads -- six waves per CU walking ~40 dependent-ish rows each -- and ran
+// 46 us for 65 MB.  Here S groups of width / 4 lanes share a segment: group g sums rows lo + g, lo + g + S, ... (each
+// group still reads whole 256-byte rows), the groups are combined with cross-lane shuffles in a fixed order.
+template <int S>
+__global__ __launch_bounds__(256) void segment_sum_split_kernel(const float* in, long in_bstride, const int32_t* ptr, const int32_t* order,
+                                                                const float* scale, float* out, int nseg, int width, int batch,
+                                                                int accumulate) {
+    const int w4 = width >> 2;            // lanes per group; S * w4 divides 64
+    const long total = (long)batch * nseg * S * w4;
+    const long nthr = (long)gridDim.x * blockDim.x;
+    for (long gid0 = (long)blockIdx.x * blockDim.x; gid0 < total; gid0 += nthr) {   // whole waves stay together for the shuffles
+        const long gid = gid0 + threadIdx.x;
+        const bool live = gid < total;
+        const long g = live ? gid : total - 1;
+        const int c4 = (int)(g % w4);
+        const int part = (int)((g / w4) % S);
+        const long rest = g / ((long)w4 * S);
+        const int sgm = (int)(rest % nseg);
+        const int b = (int)(rest / nseg);
+        const int lo = ptr[sgm], hi_ = ptr[sgm + 1];
+        const float* base = in + (long)b * in_bstride + 4 * c4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int q = lo + part;
+        for (; q + 7 * S < hi_; q += 8 * S) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long row = order != nullptr ? order[q + u * S] : q + u * S;
+                v[u] = *reinterpret_cast<const f32x4*>(base + row * width);
+            }
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; q < hi_; q += S) {
+            const long row = order != nullptr ? order[q] : q;
+            acc += *reinterpret_cast<const f32x4*>(base + row * width);
+        }
+#pragma unroll
+        for (int off = w4 * (S / 2); off >= w4; off >>= 1) {   // fixed combination order: (0 + 2) + (1 + 3) for S = 4
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
+        }
+        if (live && part == 0) {
+            const float sc = scale != nullptr ? scale[sgm] : 1.f;
+            float* o = out + ((size_t)b * nseg + sgm) * width + 4 * c4;
+            acc = acc * sc;
+            if (accumulate) acc += *reinterpret_cast<const f32x4*>(o);
+            *reinterpret_cast<f32x4*>(o) = acc;
+        }
+    }
+}
+
 // out[idx] (+)= sum_p partials[p][idx]: lane -> idx, the block's 4 waves split the parts,
 // fixed summation order (deterministic)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partials, int nparts, long stride, int n,
@@ -4062,6 +4114,22 @@ static int32_t segment_sum_launch(const float* in, int64_t in_bstride, const int
                                   float* out, int32_t nseg, int32_t width, int32_t batch, int accumulate, void* hip_stream) {
     if (in == nullptr || ptr == nullptr || out == nullptr || nseg < 0 || width < 1 || batch < 1) return NLAM_EINVAL;
     if (nseg == 0) return 0;
+    // segments of 16+ rows on average (known when the input has its own batch stride): several lane groups per segment
+    const int w4 = width / 4;
+    const long rows = in_bstride > 0 ? in_bstride / width : 0;
+    if ((width & 3) == 0 && w4 <= 32 && 64 % w4 == 0 && rows >= 16L * nseg) {
+        const int S = w4 <= 16 ? 4 : 2;
+        const long tot = (long)batch * nseg * S * w4;
+        long blk = (tot + 255) / 256;
+        if (blk > 256 * 16) blk = 256 * 16;
+        if (S == 4)
+            hipLaunchKernelGGL(segment_sum_split_kernel<4>, dim3((int)blk), dim3(256), 0, (hipStream_t)hip_stream, in, (long)in_bstride, ptr,
+                               order, scale, out, nseg, width, batch, accumulate);
+        else
+            hipLaunchKernelGGL(segment_sum_split_kernel<2>, dim3((int)blk), dim3(256), 0, (hipStream_t)hip_stream, in, (long)in_bstride, ptr,
+                               order, scale, out, nseg, width, batch, accumulate);
+        return (int32_t)hipGetLastError();
+    }
     const long total = (long)batch * nseg * ((width + 3) / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
