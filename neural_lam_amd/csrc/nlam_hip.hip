@@ -2569,9 +2569,9 @@ __global__ __launch_bounds__(256) void segment_sum_split_kernel(const float* in,
             acc += *reinterpret_cast<const f32x4*>(base + row * width);
         }
 #pragma unroll
-        for (int off = w4 * (S / 2); off >= w4; off >>= 1) {   // fixed combination order: (0 + 2) + (1 + 3) for S = 4
+        for (int k = S / 2; k >= 1; k >>= 1) {   // fixed combination order: (0 + 2) + (1 + 3) for S = 4
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
+            for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], k * w4, 64);
         }
         if (live && part == 0) {
             const float sc = scale != nullptr ? scale[sgm] : 1.f;
@@ -2673,6 +2673,19 @@ __global__ __launch_bounds__(kRedWaves * 64) void reduce_jobs_kernel(const nlam_
     }
 }
 
+// element e of a (.., nodes, width) tensor -> (row e / width, node row % nodes); 32-bit divisions whenever the tensor has
+// fewer than 2^31 elements (a 64-bit division is ~100 instructions: per element it kept these passes at ~1 TB/s)
+__device__ __forceinline__ void row_and_node(long e, int width, int nodes, bool small, long& r, int& n) {
+    if (small) {
+        const unsigned r32 = (unsigned)e / (unsigned)width;
+        r = r32;
+        n = (int)(r32 % (unsigned)nodes);
+    } else {
+        r = e / width;
+        n = (int)(r % nodes);
+    }
+}
+
 // masked, weighted MSE (metrics.wmse + mask_and_reduce_metric + the batch / time means of
 // training_step) as one HBM-bound pass: partial[block] = sum rw[row % nodes] * inv_var[v] * (pred - target)^2
 __global__ __launch_bounds__(256) void wmse_fwd_kernel(const float* pred, const float* target, const float* inv_var,
@@ -2680,10 +2693,13 @@ __global__ __launch_bounds__(256) void wmse_fwd_kernel(const float* pred, const 
                                                        float* partials) {
     __shared__ float red[4];
     float s = 0.f;
+    const bool small = total < (1L << 31);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long row = e / nvars;
+        long row;
+        int n;
+        row_and_node(e, nvars, nodes, small, row, n);
         const int v = (int)(e - row * nvars);
-        const float w = row_weight[row % nodes];
+        const float w = row_weight[n];
         if (w != 0.f) {
             const float d = pred[e] - target[e];
             s += w * inv_var[v] * d * d;
@@ -2700,10 +2716,12 @@ __global__ __launch_bounds__(256) void wmse_fwd_kernel(const float* pred, const 
 __global__ void affine_mix_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ y,
                                   const float* __restrict__ c, const float* __restrict__ z, const float* __restrict__ s,
                                   const float* __restrict__ m, float* __restrict__ out, long total, int nodes, int width) {
+    const bool small = total < (1L << 31);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long r = e / width;
+        long r;
+        int n;
+        row_and_node(e, width, nodes, small, r, n);
         const int f = (int)(e - r * width);
-        const int n = (int)(r % nodes);
         float inner = 0.f;
         if (y != nullptr) inner += y[e];
         if (z != nullptr) inner += z[e] * s[f];
@@ -2719,8 +2737,10 @@ __global__ void standardize_kernel(const nlam_std_jobs_t jobs) {
     if ((int)blockIdx.y >= jobs.njobs) return;
     const nlam_std_job_t jb = jobs.job[blockIdx.y];
     const long total = jb.rows * jb.width;
+    const bool small = total < (1L << 31);   // 32-bit modulo (see step_tail_fwd_kernel)
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int f = (int)(e % jb.width) / jb.rep;
+        const int c = small ? (int)((unsigned)e % (unsigned)jb.width) : (int)(e % jb.width);
+        const int f = c / jb.rep;
         jb.out[e] = __fdiv_rn(__fsub_rn(jb.x[e], jb.mean[f]), jb.std[f]);
     }
 }
@@ -2736,12 +2756,14 @@ __global__ __launch_bounds__(256) void step_tail_fwd_kernel(const float* __restr
     __shared__ float red[4];
     float s = 0.f;
     // a block walks whole 256-element spans; (row, variable) of the first element by one division per span, then incrementally
+    const bool small = total < (1L << 31);
     for (long e0 = (long)blockIdx.x * blockDim.x; e0 < total; e0 += (long)gridDim.x * blockDim.x) {
         const long e = e0 + threadIdx.x;
         if (e < total) {
-            const long r = e / width;
+            long r;
+            int n;
+            row_and_node(e, width, nodes, small, r, n);
             const int f = (int)(e - r * width);
-            const int n = (int)(r % nodes);
             float nw = prev[e] + (dstd != nullptr ? delta[e] * dstd[f] : delta[e]);
             if (dmean != nullptr) nw += dmean[f];
             const float bm = bmask[n];
@@ -2766,10 +2788,12 @@ __global__ void step_tail_bwd_kernel(const float* __restrict__ g_pred, const flo
                                      const float* __restrict__ inv_var, const float* __restrict__ row_weight, float scale,
                                      float* __restrict__ d_delta, float* __restrict__ d_prev, long total, int nodes, int width) {
     const float g2 = 2.f * scale * gloss[0];
+    const bool small = total < (1L << 31);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long r = e / width;
+        long r;
+        int n;
+        row_and_node(e, width, nodes, small, r, n);
         const int f = (int)(e - r * width);
-        const int n = (int)(r % nodes);
         const float w = row_weight[n];
         float G = g_pred != nullptr ? g_pred[e] : 0.f;
         if (w != 0.f) G += g2 * w * inv_var[f] * (pred[e] - target[e]);
@@ -2909,10 +2933,13 @@ __global__ __launch_bounds__(256) void concat_kernel(const nlam_cat_t p, int wto
 __global__ void wmse_bwd_kernel(const float* pred, const float* target, const float* inv_var, const float* row_weight,
                                 const float* gscalar, long total, int nodes, int nvars, float scale, float* dpred) {
     const float g = 2.f * scale * gscalar[0];
+    const bool small = total < (1L << 31);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long row = e / nvars;
+        long row;
+        int n;
+        row_and_node(e, nvars, nodes, small, row, n);
         const int v = (int)(e - row * nvars);
-        const float w = row_weight[row % nodes];
+        const float w = row_weight[n];
         dpred[e] = w != 0.f ? g * w * inv_var[v] * (pred[e] - target[e]) : 0.f;
     }
 }
