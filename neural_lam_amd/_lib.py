@@ -19,6 +19,7 @@ NLAM_MAX_GROUP = 8
 F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD, F_LEAF_WGRAD = 1, 2, 4, 8, 16, 32
 TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning keys (include/nlam_hip.h)
 TUNE_WGRAD_CHUNKS = 2
+TUNE_LIN_WGS = 3
 TILE_SPLIT = 1 << 30
 
 EXPORTS = [
@@ -333,6 +334,8 @@ def load():
     lib.nlam_standardize.restype = i32
     if lib.nlam_abi_version() != ABI_VERSION:
         raise RuntimeError("libnlam_hip.so ABI version mismatch")
+    if os.environ.get("NLAM_LIN_WGS"):
+        lib.nlam_set_tuning(TUNE_LIN_WGS, int(os.environ["NLAM_LIN_WGS"]))
     if os.environ.get("NLAM_WGRAD_CHUNKS"):
         lib.nlam_set_tuning(TUNE_WGRAD_CHUNKS, int(os.environ["NLAM_WGRAD_CHUNKS"]))
     _lib = lib

@@ -66,6 +66,7 @@ int32_t bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream);      // slice 4
 int32_t wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream);      // slice 4
 extern int wbf_min_supertiles;                                     // nlam_set_tuning (defined in slice 1)
 extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
+extern int lin_resident_wgs;                                       // workgroups of a resident-weight nlam_linear launch (slice 1)
 }  // namespace nlam_detail
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -3039,13 +3040,16 @@ __global__ __launch_bounds__(kFwdThreads) void linear_bf_kernel(const nlam_linea
 // out2, the pairs n/64 .. 2n/64 - 1 belong to it: both node-level products of a layer whose senders are its receivers
 // in one launch); the workgroup streams that pair's K dimension in 64-column chunks, the next chunk's weight block
 // staged (split) into the other LDS buffer while this one is multiplied.  One wave = one 32-row tile per round.
+constexpr int kLinResidentChunks = 4;   // 64-column K chunks of one output pair that stay in LDS (K <= 256)
+constexpr unsigned kLinResidentFlag = 1u << 30;   // launcher -> kernel, not part of the C-ABI
 template <int NS>
 __global__ __launch_bounds__(kFwdThreads) void linear_bfw_kernel(const nlam_linear_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int S = 4;                                           // K = 16 steps per 64-column chunk
     constexpr size_t kWb = (size_t)NS * 2 * S * 64;                // u32x4 per weight buffer: [NS][2 blocks][S][64]
-    u32x4* Ws = reinterpret_cast<u32x4*>(smem);                    // two buffers
-    float* stg_all = reinterpret_cast<float*>(Ws + 2 * kWb);
+    const bool resident = (p.flags & kLinResidentFlag) != 0;   // set by the launcher (K <= 64 * kLinResidentChunks)
+    u32x4* Ws = reinterpret_cast<u32x4*>(smem);                    // two buffers, or all K / 64 of them (resident)
+    float* stg_all = reinterpret_cast<float*>(Ws + (size_t)(resident ? p.k / 64 : 2) * kWb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, hi = lane >> 5;
     float* stg = stg_all + (size_t)wave * 32 * kStgStride;
@@ -3062,6 +3066,14 @@ __global__ __launch_bounds__(kFwdThreads) void linear_bfw_kernel(const nlam_line
     }
     const float* Wp = Wm + (long)(64 * np) * p.ldn;
     const long rounds = (ntiles + (long)gridDim.x * nwaves - 1) / ((long)gridDim.x * nwaves);
+    // K <= 256: all of this output pair's weight blocks fit LDS (4 x 24 KB as three bf16 terms) -- staged ONCE per
+    // workgroup, no barrier inside the K loop and none between rounds.  (Streaming them two at a time cost a staging
+    // latency + barrier per 64 columns of K and re-staged the whole strip every round: a 6 561-row product of 1.7 GFLOP
+    // took 50 us with 5 % of it on the matrix cores.)
+    if (resident) {
+        for (int kc = 0; kc < KC; ++kc) stage_split<NS>(Ws + (size_t)kc * kWb, S, 0, Wp + (long)(64 * kc) * p.ldk, p.ldn, 64, 2, 64, false, p.ldk);
+        __syncthreads();
+    }
     for (long rd = 0; rd < rounds; ++rd) {
         const long t = (rd * nwaves + wave) * gridDim.x + blockIdx.x;
         const bool live = t < ntiles;
@@ -3081,16 +3093,19 @@ __global__ __launch_bounds__(kFwdThreads) void linear_bfw_kernel(const nlam_line
             }
         };
         load_x(0);
-        stage_split<NS>(Ws, S, 0, Wp, p.ldn, 64, 2, 64, false, p.ldk);
-        __syncthreads();
+        if (!resident) {
+            stage_split<NS>(Ws, S, 0, Wp, p.ldn, 64, 2, 64, false, p.ldk);
+            __syncthreads();
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[mb][q] = 0.f;
         for (int kc = 0; kc < KC; ++kc) {
-            if (kc + 1 < KC) stage_split<NS>(Ws + (size_t)((kc + 1) & 1) * kWb, S, 0, Wp + (long)(64 * (kc + 1)) * p.ldk, p.ldn, 64, 2, 64, false, p.ldk);
-            const u32x4* Wb = Ws + (size_t)(kc & 1) * kWb;
+            if (!resident && kc + 1 < KC)
+                stage_split<NS>(Ws + (size_t)((kc + 1) & 1) * kWb, S, 0, Wp + (long)(64 * (kc + 1)) * p.ldk, p.ldn, 64, 2, 64, false, p.ldk);
+            const u32x4* Wb = Ws + (size_t)(resident ? kc : (kc & 1)) * kWb;
             BfFrag<NS> B[4];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -3103,7 +3118,7 @@ __global__ __launch_bounds__(kFwdThreads) void linear_bfw_kernel(const nlam_line
             if (kc + 1 < KC) load_x(kc + 1);   // the next chunk's rows are in flight during this chunk's MFMAs
 #pragma unroll
             for (int st = 0; st < 4; ++st) mma_split_lds<NS, 2>(acc, Wb, 2, S, st, lane, B[st]);
-            __syncthreads();   // the next block is staged; everyone is done with this one
+            if (!resident) __syncthreads();   // the next block is staged; everyone is done with this one
         }
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -3319,6 +3334,7 @@ void group_blocks(const long* tiles, int n, int* blocks) {
 // ---------------------------------------------------------------------------
 #if NLAM_IN_TU(1)
 int nlam_detail::wbf_min_supertiles = 192;
+int nlam_detail::lin_resident_wgs = 256;    // NLAM_LIN_WGS (experiments): one per CU
 int nlam_detail::wgrad_chunks_per_wg = 8;   // A/B at cfg2 (tools/ab_bench.sh): 2.13 -> 2.06 ms per step against one chunk per workgroup
 #endif
 
@@ -3345,6 +3361,11 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_WBF_MIN_SUPERTILES) {
         if (value < 0) return NLAM_EINVAL;
         nlam_detail::wbf_min_supertiles = value;
+        return 0;
+    }
+    if (key == NLAM_TUNE_LIN_WGS) {
+        if (value < 0) return NLAM_EINVAL;
+        nlam_detail::lin_resident_wgs = value;
         return 0;
     }
     if (key == NLAM_TUNE_WGRAD_CHUNKS) {
@@ -4113,16 +4134,22 @@ int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream) {
     else if (KB == 2 && MB == 2) NLAM_LAUNCH_LIN(2, 2);
     else if (p->k % 64 == 0 && p->n % 64 == 0 && p->k <= kMaxWide && p->n <= kMaxWide) {
         // 64 x 64 weight blocks streamed through two LDS buffers (linear_bfw_kernel)
-        const size_t wlds = (size_t)2 * ns * 2 * 4 * 64 * 16 + (size_t)kFwdWaves * 32 * kStgStride * sizeof(float);
+        const int kc_all = p->k / 64;
+        const bool resident = kc_all <= kLinResidentChunks && nlam_detail::lin_resident_wgs > 0;   // the output pair's whole weight strip stays in LDS
+        nlam_linear_t q = *p;
+        q.flags = (q.flags & ~kLinResidentFlag) | (resident ? kLinResidentFlag : 0u);
+        const size_t wlds = (size_t)(resident ? kc_all : 2) * ns * 2 * 4 * 64 * 16 + (size_t)kFwdWaves * 32 * kStgStride * sizeof(float);
         const int wby = (p->n / 64) * (p->W2 != nullptr ? 2 : 1);
         long wbx = (ntiles + kFwdWaves - 1) / kFwdWaves;   // eight tiles (one per wave) share each staged weight block
-        if (wbx * wby > 4 * kNumCUs) wbx = (4 * kNumCUs + wby - 1) / wby;
+        // resident weights: one workgroup per CU (135 KB of LDS), each walking several rounds of tiles over its one staging
+        const long cap = resident ? nlam_detail::lin_resident_wgs : 4 * kNumCUs;
+        if (wbx * wby > cap) wbx = (cap + wby - 1) / wby;
         if (wbx < 1) wbx = 1;
 #define NLAM_LAUNCH_LINW(NS_)                                                                              \
     do {                                                                                                   \
         int rc = set_lds(linear_bfw_kernel<NS_>, wlds);                                                    \
         if (rc != 0) return rc;                                                                            \
-        hipLaunchKernelGGL((linear_bfw_kernel<NS_>), dim3(wbx, wby), dim3(kFwdThreads), wlds, stream, *p); \
+        hipLaunchKernelGGL((linear_bfw_kernel<NS_>), dim3(wbx, wby), dim3(kFwdThreads), wlds, stream, q);  \
     } while (0)
         if (ns == 3) NLAM_LAUNCH_LINW(3);
         else if (ns == 2) NLAM_LAUNCH_LINW(2);
