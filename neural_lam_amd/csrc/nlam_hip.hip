@@ -1714,6 +1714,11 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
     }
 
     const long total_tiles = (long)p.ntiles * p.batch;
+    // LW (one wave per SIMD: nothing else hides a load): the g_out rows of the NEXT tile are fetched while this tile is worked
+    // on, when the next tile's rows are known without loads (plain 32-row tiles, identity row order: the embedders)
+    const bool lw_prefetch = LW && p.tiles == nullptr && p.out_idx == nullptr && p.g_aggr == nullptr && p.g_out != nullptr;
+    f32x4 gpre[LW ? OB : 1][4];
+    bool gpre_ready = false;
     for (long gt = (long)wave * wg_count + wg_id; gt < total_tiles; gt += (long)wg_count * NWV) {
         const int b = (int)(gt / p.ntiles);
         const TileInfo tl = get_tile(p.tiles, (int)(gt % p.ntiles), p.rows);
@@ -1771,12 +1776,27 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
                 for (int tt = 0; tt < 4; ++tt) {
                     const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
                     f32x4 g = {0.f, 0.f, 0.f, 0.f};
-                    if (grow != nullptr) g = *reinterpret_cast<const f32x4*>(grow + c0);
+                    if (LW && gpre_ready) g = gpre[LW ? ob : 0][tt];
+                    else if (grow != nullptr) g = *reinterpret_cast<const f32x4*>(grow + c0);
                     if (garow != nullptr) g += *reinterpret_cast<const f32x4*>(garow + c0) * gscale;
                     if (!valid) g = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (has_ln) xh[tt] = *reinterpret_cast<const f32x4*>(xrow + c0);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) dz2[ob][4 * tt + c] = g[c];
+                }
+                if (LW && ob == OB - 1) {   // all of this tile's g rows are in dz2: issue the next tile's
+                    gpre_ready = false;
+                    const long gn = gt + (long)wg_count * NWV;
+                    if (lw_prefetch && gn < total_tiles) {
+                        const int bn = (int)(gn / p.ntiles);
+                        const long rown = min((long)(gn % p.ntiles) * 32 + j, (long)p.rows - 1);
+                        const float* gnrow = p.g_out + (long)bn * p.out_bstride + rown * p.dout;
+#pragma unroll
+                        for (int o2 = 0; o2 < OB; ++o2)
+#pragma unroll
+                            for (int t2 = 0; t2 < 4; ++t2) gpre[LW ? o2 : 0][t2] = *reinterpret_cast<const f32x4*>(gnrow + 8 * (o2 * 4 + t2) + 4 * hi);
+                        gpre_ready = true;
+                    }
                 }
                 if (has_ln) {
                     // dbeta = colsum(dmsg), dgamma = colsum(dmsg * xhat), through the staged block
