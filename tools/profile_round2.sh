@@ -19,6 +19,15 @@ cd $GRAFT_REPO_ROOT
 python tools/step_timeline.py $(find $OUT/tr -name "*kernel_trace.csv" | head -1) > $OUT/cfg2_step_timeline.txt
 cp $(find $OUT/tr -name "*kernel_stats.csv" | head -1) $OUT/bench_cfg2_kernel_stats.csv
 rm -rf $OUT/tr
+for c in cfg3 cfg4; do
+  cd /tmp
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/tr_$c -o t -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 6 --warmup 2 --no-cpu-baseline --no-gpu-baseline --no-roofline --no-data-path > /dev/null 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/step_timeline.py $(find $OUT/tr_$c -name "*kernel_trace.csv" | head -1) > $OUT/${c}_step_timeline_full.txt
+  grep "^#" $OUT/${c}_step_timeline_full.txt > $OUT/${c}_step_kernel_totals.txt
+  rm -rf $OUT/tr_$c $OUT/${c}_step_timeline_full.txt
+done
+python tools/hbm_kernels_bench.py 64 2>&1 | grep -v amdgpu.ids > $OUT/hbm_kernels_d64.log
 tail -2 $OUT/smoke.log
 python -c "
 import json
