@@ -865,3 +865,41 @@ def test_interaction_net_with_two_hidden_layers(dev):
         assert rel_err(a.grad.cpu(), b.grad) < TOL
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         assert rel_err(p.grad.cpu(), q.grad) < TOL, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width,nseg,avg,batch", [(64, 700, 39, 2), (32, 300, 20, 1), (128, 200, 17, 2), (64, 50, 3, 1), (20, 90, 25, 1),
+                                                  (256, 40, 30, 1), (64, 6561, 39, 1)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_segment_sum_long_and_short_segments_match_index_add(width, nseg, avg, batch, accumulate):
+    """nlam_segment_sum / _acc directly (the CSC scatter-by-sender and CSR aggregate of the layers): long segments take the
+    kernel that gives one segment to several lane groups (widths 32 / 64: four groups, 128: two), short ones, odd widths and
+    width 256 the one-thread-per-column kernel; ragged segment lengths incl. empty segments, a gather order, per-segment
+    scales, a batch stride, accumulation onto an existing output; deterministic."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from neural_lam_amd import ops
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(width * 1000 + nseg)
+    lens = torch.randint(0, 2 * avg + 1, (nseg,), generator=g)
+    lens[::7] = 0                                   # some empty segments
+    rows = int(lens.sum())
+    ptr = torch.zeros(nseg + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    order = torch.randperm(rows, generator=g).to(torch.int32)
+    x = torch.randn(batch, rows, width, generator=g)
+    scale = torch.rand(nseg, generator=g) + 0.5
+    base = torch.randn(batch, nseg, width, generator=g)
+    seg_of_pos = torch.repeat_interleave(torch.arange(nseg), lens)
+    ref = torch.zeros(batch, nseg, width, dtype=torch.float64)
+    ref.index_add_(1, seg_of_pos, x[:, order.long()].double())
+    ref = ref * scale.double()[None, :, None] + (base.double() if accumulate else 0.0)
+    out = base.clone().to(dev) if accumulate else None
+    got = ops.segment_sum(x.to(dev), rows * width, ptr.to(dev), order.to(dev), scale.to(dev), nseg, width, batch, out=out,
+                          accumulate=accumulate)
+    again = ops.segment_sum(x.to(dev), rows * width, ptr.to(dev), order.to(dev), scale.to(dev), nseg, width, batch,
+                            out=base.clone().to(dev) if accumulate else None, accumulate=accumulate)
+    assert torch.equal(got, again)
+    assert rel_err(got.cpu().double(), ref) < 1e-5
+    assert float(got[:, ::7].cpu().sub(base[:, ::7] if accumulate else 0.0).abs().max()) == 0.0   # empty segments: zero contribution
