@@ -119,3 +119,23 @@ def test_graph_efm_rolls_out_inside_the_forecaster(tmp_path):
             new = fc.boundary_mask * target[:, t] + fc.interior_mask * p
             assert rel_err(pred[:, t], new) < 1e-6
             prev_prev, prev = prev, new
+
+
+def test_construction_variants_and_no_cpu_fallback(tmp_path):
+    """CPU: prior kinds (learnable graph encoder / constant N(0, 1)), latent sizes, predicted-std output width; a CPU
+    forward raises instead of falling back to anything."""
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import graph_efm, latent
+    from neural_lam_amd.datastore import SyntheticDatastore
+
+    ds = SyntheticDatastore(30, 27, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+    G.save_graph(tmp_path / "graph" / "multiscale", G.create_regular_grid_graph(ds.get_xy("state")))
+    m = graph_efm.GraphEFMMultiScale(ds, hidden_dim=16, prior_m2m_layers=1, encoder_m2m_layers=1, decoder_m2m_layers=1)
+    assert isinstance(m.prior_model, latent.GraphLatentEncoder) and m.latent_dim == 16 and m.latent_spatial_dim == 81
+    assert m.encoder.output_dist == "diagonal" and m.prior_model.output_dist == "isotropic"
+    m2 = graph_efm.GraphEFMMultiScale(ds, hidden_dim=16, learn_prior=False, latent_dim=4, output_std=True)
+    assert isinstance(m2.prior_model, latent.ConstantLatentEncoder) and m2.latent_dim == 4 and m2.grid_output_dim == 10
+    assert m2.decoder.param_map[-1].out_features == 10
+    N = ds.num_grid_points
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m(torch.zeros(1, N, 5), torch.zeros(1, N, 5), torch.zeros(1, N, 6))
