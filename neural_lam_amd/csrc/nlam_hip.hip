@@ -2759,6 +2759,24 @@ __global__ void standardize_kernel(const nlam_std_jobs_t jobs) {
     const nlam_std_job_t jb = jobs.job[blockIdx.y];
     const long total = jb.rows * jb.width;
     const bool small = total < (1L << 31);   // 32-bit modulo (see step_tail_fwd_kernel)
+    if ((total & 3) == 0 && small && ((reinterpret_cast<uintptr_t>(jb.x) | reinterpret_cast<uintptr_t>(jb.out)) & 15) == 0) {
+        // four consecutive elements per thread (16-byte accesses), one modulo per four, the column counter advances
+        const unsigned nq = (unsigned)(total >> 2), nthr = gridDim.x * blockDim.x;
+        for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += nthr) {
+            const unsigned e = 4 * q;
+            int c = (int)(e % (unsigned)jb.width);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(jb.x + e);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int f = c / jb.rep;
+                o[k] = __fdiv_rn(__fsub_rn(x[k], jb.mean[f]), jb.std[f]);
+                if (++c == jb.width) c = 0;
+            }
+            *reinterpret_cast<f32x4*>(jb.out + e) = o;
+        }
+        return;
+    }
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int c = small ? (int)((unsigned)e % (unsigned)jb.width) : (int)(e % jb.width);
         const int f = c / jb.rep;
@@ -2776,9 +2794,43 @@ __global__ __launch_bounds__(256) void step_tail_fwd_kernel(const float* __restr
                                                             float* __restrict__ partials, long total, int nodes, int width) {
     __shared__ float red[4];
     float s = 0.f;
-    // a block walks whole 256-element spans; (row, variable) of the first element by one division per span, then incrementally
     const bool small = total < (1L << 31);
-    for (long e0 = (long)blockIdx.x * blockDim.x; e0 < total; e0 += (long)gridDim.x * blockDim.x) {
+    // four consecutive elements per thread as 16-byte accesses: one (row, node) division per four elements, the variable /
+    // node counters advance incrementally (the scalar loop below is the general path)
+    const bool vec = (total & 3) == 0 && small &&
+                     ((reinterpret_cast<uintptr_t>(delta) | reinterpret_cast<uintptr_t>(prev) | reinterpret_cast<uintptr_t>(truth) |
+                       reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(pred)) & 15) == 0;
+    if (vec) {
+        const unsigned nq = (unsigned)(total >> 2), nthr = gridDim.x * blockDim.x;
+        for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += nthr) {
+            const unsigned e = 4 * q;
+            unsigned r = e / (unsigned)width;
+            int f = (int)(e - r * (unsigned)width);
+            int n = (int)(r % (unsigned)nodes);
+            const f32x4 dl = *reinterpret_cast<const f32x4*>(delta + e), pr = *reinterpret_cast<const f32x4*>(prev + e);
+            const f32x4 tr = *reinterpret_cast<const f32x4*>(truth + e), tg = *reinterpret_cast<const f32x4*>(target + e);
+            f32x4 pv4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float nw = pr[c] + (dstd != nullptr ? dl[c] * dstd[f] : dl[c]);
+                if (dmean != nullptr) nw += dmean[f];
+                const float bm = bmask[n];
+                const float pv = bm * tr[c] + (1.f - bm) * nw;
+                pv4[c] = pv;
+                const float w = row_weight[n];
+                if (w != 0.f) {
+                    const float d = pv - tg[c];
+                    s += w * inv_var[f] * d * d;
+                }
+                if (++f == width) {
+                    f = 0;
+                    if (++n == nodes) n = 0;
+                }
+            }
+            *reinterpret_cast<f32x4*>(pred + e) = pv4;
+        }
+    }
+    for (long e0 = vec ? total : (long)blockIdx.x * blockDim.x; e0 < total; e0 += (long)gridDim.x * blockDim.x) {
         const long e = e0 + threadIdx.x;
         if (e < total) {
             long r;
