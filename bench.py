@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- training-step throughput of the GraphCast-LAM hot path on MI355X.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (for N > 1
-launched under torch.distributed.run, one rank per GPU over RCCL).  W untimed
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``: for N > 1 either
+launched under torch.distributed.run (one rank per GPU over RCCL), or on its own, in
+which case it re-launches itself that way (127.0.0.1 rendezvous, free port).  W untimed
 warm-up steps, then exactly K training steps bracketed by barrier +
 synchronize; the max over ranks is the job time; rank 0 prints ONE JSON line.
 
@@ -273,11 +274,27 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: re-launch under torch.distributed.run, one rank per GPU of this node
+        # (the reference's launch mode, train_model.py:564-578 / README.md:486-514); rank 0 of that job prints the JSON
+        # line on the inherited stdout.  Under an external torchrun WORLD_SIZE is set and this branch is skipped.
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL needs it)
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); CPU numbers come from the cpu_baseline leg only")
     # dry run of the N > 1 code on a 1-GPU box: NLAM_BENCH_DRYRUN=1 puts every rank on cuda:0 over gloo (numbers are

@@ -397,7 +397,7 @@ typedef struct {
     float* init_states;          /* (batch, 2, nodes, d_state) */
     float* target_states;        /* (batch, ar_steps, nodes, d_state) */
     float* forcing_windowed;     /* (batch, ar_steps, nodes, d_forcing * window) or NULL when d_forcing == 0 */
-    int64_t* target_times;       /* (batch, ar_steps) or NULL */
+    int64_t* target_times;       /* (batch, ar_steps) or NULL; with times == NULL it receives the (clamped) time index */
     const float* state_mean;     /* (d_state)   all four NULL: raw values, as the reference's dataset returns them */
     const float* state_std;      /* (d_state) */
     const float* forcing_mean;   /* (d_forcing) */

@@ -2927,9 +2927,10 @@ __global__ __launch_bounds__(256) void window_batch_kernel(const nlam_window_t p
                     if (e0 + k < per) dst[e0 + k] = v[k];
             }
         }
-        if (r == 2 && p.target_times != nullptr && p.times != nullptr && blockIdx.x == 0 && (int)threadIdx.x < p.ar_steps) {
+        if (r == 2 && p.target_times != nullptr && blockIdx.x == 0 && (int)threadIdx.x < p.ar_steps) {
+            // without time stamps the (clamped, like the data) time INDEX of every target step is reported
             const long tt = min(max(i + max(2, past) + (long)threadIdx.x, 0L), last);
-            p.target_times[(long)b * p.ar_steps + threadIdx.x] = p.times[tt];
+            p.target_times[(long)b * p.ar_steps + threadIdx.x] = p.times != nullptr ? p.times[tt] : tt;
         }
     } else {
         if (p.d_forcing == 0) return;

@@ -99,12 +99,25 @@ class DeviceWeatherDataset:
         for i in range(len(self)):
             yield self[i]
 
+    def check_indices(self, indices):
+        """IndexError (as weather_dataset.py:497-503) if any entry of a DEVICE-resident index tensor lies outside
+        ``[0, len(self))`` -- ``batch`` does not validate such tensors (the kernel clamps the time index instead of
+        faulting, so a bad index would silently repeat boundary time steps).  One host synchronisation: call it once per
+        epoch on the permutation, or pass ``validate=True`` to ``batch`` while debugging."""
+        idx = torch.as_tensor(indices).reshape(-1)
+        if idx.numel():
+            lo, hi = int(idx.min()), int(idx.max())
+            if lo < 0 or hi >= len(self):
+                raise IndexError(f"sample index out of range for WeatherDataset of length {len(self)}: [{lo}, {hi}]")
+        return indices
+
     # ---- the batched launch ----
-    def batch(self, indices, standardize=False, out=None):
+    def batch(self, indices, standardize=False, out=None, validate=False):
         """(init_states (B, 2, N, d), target_states (B, T, N, d), forcing (B, T, N, F * window), target_times (B, T)).
 
-        ``indices``: a device int64 tensor is used as it is (not validated: the kernel clamps); anything else is
-        validated on the host like ``__getitem__``.  ``out``: optional tuple of four preallocated tensors (e.g. the
+        ``indices``: a device int64 tensor is used as it is (not validated unless ``validate=True``, which costs a host
+        synchronisation: the kernel clamps; see ``check_indices``); anything else is validated on the host like
+        ``__getitem__``.  ``out``: optional tuple of four preallocated tensors (e.g. the
         static input buffers of a captured training step)."""
         if not (isinstance(indices, torch.Tensor) and indices.is_cuda):
             host = torch.as_tensor(indices, dtype=torch.int64).reshape(-1)
@@ -113,6 +126,8 @@ class DeviceWeatherDataset:
             if host.numel() and (int(host.min()) < 0 or int(host.max()) >= n):
                 raise IndexError(f"sample index out of range for WeatherDataset of length {n}")
             indices = host.to(self.device)
+        elif validate:
+            self.check_indices(indices)
         indices = indices.to(torch.int64).contiguous()
         B, T = indices.numel(), self.ar_steps
         N, ds = self.state.shape[1], self.state.shape[2]
@@ -131,8 +146,7 @@ class DeviceWeatherDataset:
         p.state, p.forcing, p.sample_idx = _ptr(self.state), _ptr(self.forcing), _ptr(indices)
         p.init_states, p.target_states = _ptr(init), _ptr(target)
         p.forcing_windowed = _ptr(forcing) if fw else None
-        if self.times is not None:
-            p.times, p.target_times = _ptr(self.times), _ptr(times)
+        p.times, p.target_times = _ptr(self.times), _ptr(times)   # times == None: the kernel reports the time index of every target step
         if standardize:
             p.state_mean, p.state_std = _ptr(self.stats["state_mean"]), _ptr(self.stats["state_std"])
             if fw:
@@ -141,9 +155,6 @@ class DeviceWeatherDataset:
         p.d_forcing = 0 if self.forcing is None else self.forcing.shape[2]
         p.ar_steps, p.num_past_forcing_steps, p.num_future_forcing_steps = T, self.num_past_forcing_steps, self.num_future_forcing_steps
         L.check(self._lib.nlam_window_batch(C.byref(p), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nlam_window_batch")
-        if self.times is None:   # no time stamps: report the time index of every target step
-            off = max(2, self.num_past_forcing_steps)
-            times.copy_(indices[:, None] + off + torch.arange(T, device=self.device)[None, :])
         return init, target, forcing, times
 
     def epoch_permutation(self, seed=0):

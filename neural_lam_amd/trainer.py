@@ -91,6 +91,7 @@ class GradBuckets:
         self.pending = [0] * len(self.bounds)
         self.uses = {}        # parameter index -> fused-MLP forwards that used it and have not yet back-propagated
         self.done = set()
+        self.done_via = {}    # parameter index -> "direct" | "hook": which mechanism reported it complete this step
         self.handles = []
         self.launched = []    # bucket indices in launch order (tests read it)
         self.enabled = True   # False while a HIP graph owns the step (collectives run after the replay)
@@ -120,13 +121,29 @@ class GradBuckets:
             h.wait()
         self.handles = []
         for view, low in self._comm_tmp:
+            # `low` was allocated on whichever stream was current when the bucket completed (a weight-gradient side stream in
+            # the eager direct-gradient path); this copy runs on the current stream: tell the caching allocator, or the
+            # block could be handed back to the side stream while the copy is still pending
+            if low.is_cuda:
+                low.record_stream(torch.cuda.current_stream())
             view.copy_(low)
         self._comm_tmp = []
 
-    def _param_done(self, i):
+    def _param_done(self, i, via="hook"):
         if i in self.done:
+            # A parameter is reported complete by exactly ONE mechanism per step: the fused-MLP backward that accumulates
+            # its gradient itself (note_done, after its last counted use) or autograd's AccumulateGrad hook.  A parameter
+            # fed by both (a weight shared between a fused MLP and a plain torch op) would be marked done by whichever
+            # finishes first, and the other contribution would land after the bucket's collective has started: wrong
+            # gradients without an error.  Refuse instead.
+            if self.done_via.get(i) != via:
+                raise RuntimeError(
+                    f"parameter #{i} ({tuple(self.fp.params[i].shape)}) receives gradient both from a fused MLP's direct "
+                    "accumulation and through autograd in one step: early bucket all-reduce cannot order the two; "
+                    "do not share this parameter with plain torch ops, or run the HIP-graph step (one collective after the replay)")
             return
         self.done.add(i)
+        self.done_via[i] = via
         b = self.bucket_of[i]
         self.pending[b] -= 1
         if self.pending[b] == 0:
@@ -161,11 +178,11 @@ class GradBuckets:
             left = self.uses.get(i, 1) - 1
             self.uses[i] = left
             if left <= 0:   # the last AR step's contribution is in: the gradient is complete
-                self._param_done(i)
+                self._param_done(i, via="direct")
 
     def begin_step(self):
         self.pending = [len(mem) for (_, _, mem) in self.bounds]
-        self.uses, self.done = {}, set()
+        self.uses, self.done, self.done_via = {}, set(), {}
         self.handles, self.launched = [], []
 
     def finish_step(self):
@@ -382,7 +399,15 @@ class Trainer:
             if self._static_in[0].shape[0] == B and len(self._static_in) == 3:
                 if self.batch_times is None or self.batch_times.shape != (B, dataset.ar_steps):
                     self.batch_times = torch.empty((B, dataset.ar_steps), device=self._static_in[0].device, dtype=torch.int64)
-                dataset.batch(indices, standardize=standardize, out=(*self._static_in, self.batch_times))
+                if self._pre_standardize:
+                    # the captured step was recorded WITHOUT on_after_batch_transfer (it is hoisted out of the capture into
+                    # module.standardize(..., out=static inputs)): cut the raw batch, then standardise it into the graph's
+                    # input buffers -- writing the raw samples there would train on unstandardised data
+                    raw = dataset.batch(indices, standardize=False)
+                    self.module.standardize(*raw[:3], out=self._static_in)
+                    self.batch_times = raw[3]
+                else:
+                    dataset.batch(indices, standardize=standardize, out=(*self._static_in, self.batch_times))
                 self._graph.replay()
                 if self.world > 1:
                     self.buckets.all_reduce_whole()

@@ -22,6 +22,7 @@ def load_golden(name):
 def golden_layers():
     cases = dict(load_golden("layers")["cases"])
     cases.update(load_golden("layers_wide")["cases"])  # d = 128 / 256 (wide kernels)
+    cases.update(load_golden("layers_wide_chunked")["cases"])  # SplitMLPs at d = 128 (the cfg4p / HiLAMParallel width)
     return cases
 
 

@@ -122,6 +122,20 @@ def make_layers_wide(ref):
     torch.save({"note": NOTE, "cases": cases}, HERE / "layers_wide.pt")
 
 
+def make_layers_wide_chunked(ref):
+    """SplitMLPs (gnn_layers.py:274-324) at the width HiLAMParallel is benchmarked at (cfg4p, d = 128): chunked edge and
+    node MLPs on row windows that start inside a 32-row tile, through the wide kernels.  Own file so that the older
+    fixtures stay byte-identical."""
+    cases = {}
+    cases["inet_chunked_b2_d128"] = layer_case(
+        ref, "inet_chunked_b2_d128", "InteractionNet", 45, 37, 700, 128, 2, 97,
+        edge_chunk_sizes=[301, 250, 149], aggr_chunk_sizes=[20, 10, 7])
+    cases["inet_chunked_noupdate_d128"] = layer_case(
+        ref, "inet_chunked_noupdate_d128", "InteractionNet", 70, 33, 450, 128, None, 98, update_edges=False,
+        edge_chunk_sizes=[64, 386], aggr_chunk_sizes=[32, 1])
+    torch.save({"note": NOTE, "cases": cases}, HERE / "layers_wide_chunked.pt")
+
+
 def compress_graph(raw):
     out = {}
     for k, v in raw.items():
@@ -429,6 +443,9 @@ def main():
         hi_latent_case(ref, "latent_hi_d32", 32, 8, 1, 1, 52)
         hi_latent_case(ref, "latent_hi_d16_nointra", 16, 4, 0, 1, 53, output_dist="isotropic", g2m_gnn_type="PropagationNet")
         return
+    if "--wide-chunked-only" in sys.argv:
+        make_layers_wide_chunked(ref)
+        return
     if "--wide-only" in sys.argv:
         make_layers_wide(ref)
         model_case(ref, "graphlam_30x27_d128", "GraphLAM", DS_SMALL, dict(n_max_levels=None, hierarchical=False),
@@ -436,6 +453,7 @@ def main():
         return
     make_layers(ref)
     make_layers_wide(ref)
+    make_layers_wide_chunked(ref)
     legacy_graph_cases(ref)
     efm_cases(ref)
     latent_case(ref, "latent_flat_d64", 64, 16, 2, 2, 50)

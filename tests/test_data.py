@@ -251,7 +251,13 @@ def test_training_from_the_device_dataset_equals_training_from_handed_over_batch
     from neural_lam_amd.trainer import Trainer
 
     dev = torch.device("cuda:0")
-    dstore = SyntheticDatastore(30, 27, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+    import numpy as np
+
+    rng = np.random.default_rng(5)   # non-trivial statistics: a step that skips on_after_batch_transfer must show
+    dstore = SyntheticDatastore(30, 27, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1,
+                                state_stats={"state_mean": rng.normal(size=5) * 2, "state_std": rng.uniform(0.5, 3.0, size=5)})
+    dstore._forcing_stats.forcing_mean.values = rng.normal(size=2).astype(np.float32)
+    dstore._forcing_stats.forcing_std.values = rng.uniform(0.5, 2.0, size=2).astype(np.float32)
     ext = dstore.get_xy_extent("state")
     graph = G.normalise_graph(G.create_regular_grid_graph(dstore.get_xy("state")), max(ext[1] - ext[0], ext[3] - ext[2]))
 
@@ -260,7 +266,7 @@ def test_training_from_the_device_dataset_equals_training_from_handed_over_batch
         fc = hm.ARForecaster(hm.GraphLAM(dstore, graph=graph, hidden_dim=16, processor_layers=2), dstore)
         return Trainer(hm.ForecasterStep(fc, dstore, standardize=std_in_module).to(dev), lr=1e-3, use_graph=use_graph)
 
-    t_ref, t_dev = make(True), make(False)
+    t_ref, t_dev, t_mod = make(True), make(False), make(True)
     N, T, past, fut = dstore.num_grid_points, 2, 1, 1
     state, forcing, times = _series(14, N, 5, 2, seed=9)
     data = DeviceWeatherDataset(state, forcing, times, ar_steps=T, num_past_forcing_steps=past, num_future_forcing_steps=fut,
@@ -275,6 +281,12 @@ def test_training_from_the_device_dataset_equals_training_from_handed_over_batch
         assert l_ref == l_dev, (k, l_ref, l_dev)
         assert torch.equal(t_ref.fp.flat, t_dev.fp.flat)
         assert torch.equal(t_dev.batch_times, raw[3])
+        # a module that standardises itself + raw samples from the dataset: with a captured step the standardisation is
+        # hoisted out of the graph, and step_from must still apply it on every call (not only on the capturing one)
+        l_mod = float(t_mod.step_from(data, idx, standardize=False))
+        assert l_mod == l_ref, (k, l_ref, l_mod)
+        assert torch.equal(t_ref.fp.flat, t_mod.fp.flat)
+        assert torch.equal(t_mod.batch_times, raw[3])
     assert (t_dev._graph is not None) == use_graph
     with pytest.raises(ValueError):
         t_ref.step_from(data, perm[:B])                           # would standardise twice

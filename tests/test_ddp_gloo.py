@@ -339,3 +339,46 @@ def test_hip_modules_inside_torch_distributed_data_parallel(tmp_path, backend, w
         # the averaged gradient of the last step = mean of the two ranks' single-process gradients on the final weights'
         # predecessor is checked indirectly: both ranks saw different data yet hold the same gradient
         assert not torch.equal(r0["batch"][0], r1["batch"][0])
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` with no external launcher: bench.py re-launches itself under torch.distributed.run
+    (one process per GPU, train_model.py:564-578); rank 0 prints ONE JSON line for the whole job.  On a 1-GPU box the
+    dry-run switch puts both ranks on cuda:0 over gloo: the numbers mean nothing, the multi-rank control flow (rendezvous,
+    per-rank build, barrier-bracketed timing, max over ranks, all-reduce after every replay) is what runs."""
+    import json
+    import subprocess
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = dict(os.environ, NLAM_BENCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "cfg1",
+                          "--no-roofline", "--no-data-path"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks_seen"] == 2 and out["steps"] == 3
+    assert out["config"]["global_batch"] == 2 * 2 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["final_loss"] == out["final_loss"]
+
+
+def test_bench_self_launch_reaches_both_ranks_without_a_gpu():
+    """CPU side of the same contract: ``python bench.py --gpus 2`` with no WORLD_SIZE in the environment spawns two ranks
+    under torch.distributed.run; without a GPU each of them stops at bench.py's "needs an MI355X" guard (there is no CPU
+    fallback), which is what this checks -- the re-launch, the rendezvous arguments and the per-rank entry."""
+    import subprocess
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check (the GPU box runs test_bench_launches_its_own_ranks)")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert res.stderr.count("bench.py needs an MI355X") >= 2, res.stderr[-2000:]
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

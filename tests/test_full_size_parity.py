@@ -48,86 +48,115 @@ def row_rel_err(a, b):
     return float(((a - b).abs().amax(dim=-1) / denom).max())
 
 
-@pytest.fixture(params=["auto", "wbf"])
-def wide_family(request):
-    from neural_lam_amd import _lib as L
+class _Tuning:
+    """Force a wide kernel family / the factorised or plain edge MLP for the duration of a block."""
 
-    lib = L.load()
-    if request.param == "wbf":
-        assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 0) == 0
-    yield request.param
-    assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
+    def __init__(self, family, factorise):
+        self.family, self.factorise = family, factorise
+
+    def __enter__(self):
+        from neural_lam_amd import _lib as L
+        from neural_lam_amd import gnn_layers as hl
+
+        self.hl, self.lib, self.L = hl, L.load(), L
+        self.old = (hl.FACTORISE_MIN_EDGES_WIDE, hl.FACTORISE_MIN_WORK_WIDE, hl.FACTORISE_MIN_WIDTH_WIDE)
+        hl.FACTORISE_MIN_WORK_WIDE = 0
+        hl.FACTORISE_MIN_WIDTH_WIDE = 0
+        if self.factorise == "plain":
+            hl.FACTORISE_MIN_EDGES_WIDE = 1 << 30
+        if self.family == "wbf":
+            assert self.lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 0) == 0
+        return self
+
+    def __exit__(self, *exc):
+        hl = self.hl
+        hl.FACTORISE_MIN_EDGES_WIDE, hl.FACTORISE_MIN_WORK_WIDE, hl.FACTORISE_MIN_WIDTH_WIDE = self.old
+        assert self.lib.nlam_set_tuning(self.L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
 
 
-@pytest.fixture(params=["factorised", "plain"])
-def wide_factorise(request):
-    """Widths above 64 run the factorised edge MLP (node-level products + gathered addends) wherever the split-bf16
-    super-tile kernels apply; "plain" switches it off so the un-factorised kernels stay covered at full size."""
-    from neural_lam_amd import gnn_layers as hl
+class _Threads:
+    """torch's CPU scatter / index_add paths degrade when oversubscribed on a many-core host (bench.py's probe): the big
+    oracle runs use a bounded thread count."""
 
-    old, old_w = hl.FACTORISE_MIN_EDGES_WIDE, hl.FACTORISE_MIN_WORK_WIDE
-    hl.FACTORISE_MIN_WORK_WIDE = 0
-    hl.FACTORISE_MIN_WIDTH_WIDE = 0
-    if request.param == "plain":
-        hl.FACTORISE_MIN_EDGES_WIDE = 1 << 30
-    yield request.param
-    hl.FACTORISE_MIN_EDGES_WIDE, hl.FACTORISE_MIN_WORK_WIDE = old, old_w
-    hl.FACTORISE_MIN_WIDTH_WIDE = 256
+    def __init__(self, n=32):
+        self.n = n
+
+    def __enter__(self):
+        import os
+
+        self.old = torch.get_num_threads()
+        torch.set_num_threads(max(1, min(self.n, os.cpu_count() or 1)))
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.old)
 
 
 LAYERS = [
-    # (edge set, d, class, update_edges)
-    ("m2g", 64, "InteractionNet", False),
-    ("g2m", 64, "InteractionNet", False),
-    ("m2m", 64, "InteractionNet", True),
-    ("m2g", 64, "PropagationNet", True),
-    ("m2g", 128, "InteractionNet", False),
-    ("m2m", 128, "InteractionNet", True),
-    ("g2m", 128, "PropagationNet", False),
-    ("m2g", 256, "InteractionNet", False),
-    ("g2m", 256, "InteractionNet", False),
-    ("m2m", 256, "InteractionNet", True),
+    # (edge set, d, class, update_edges, batch)
+    ("m2g", 64, "InteractionNet", False, 2),
+    ("g2m", 64, "InteractionNet", False, 2),
+    ("m2m", 64, "InteractionNet", True, 2),
+    ("m2g", 64, "PropagationNet", True, 2),
+    ("m2g", 128, "InteractionNet", False, 2),
+    ("m2m", 128, "InteractionNet", True, 2),
+    ("g2m", 128, "PropagationNet", False, 2),
+    ("m2g", 256, "InteractionNet", False, 2),
+    ("g2m", 256, "InteractionNet", False, 2),
+    ("m2m", 256, "InteractionNet", True, 2),
+    # cfg5 width (BASELINE configs[4]) on the real edge sets, fp32 matrix mode (bf16x3), one sample
+    ("m2g", 512, "InteractionNet", False, 1),
+    ("m2m", 512, "InteractionNet", True, 1),
 ]
 
 
-@pytest.mark.parametrize("which,d,cls_name,update_edges", LAYERS)
-def test_meps_layer_matches_oracle(dev, meps_raw, which, d, cls_name, update_edges, wide_family, wide_factorise):
-    if d <= 64 and (wide_family == "wbf" or wide_factorise == "plain"):
-        pytest.skip("one kernel family at d <= 64")
-    if wide_family == "wbf" and wide_factorise == "plain":
-        pytest.skip("covered by the auto family: both take the super-tile kernels at this size")
+def _variants(d):
+    """(kernel family, factorised?) combinations a width can take: one family at d <= 64; above, the launch-size dispatch
+    ("auto"), the forced super-tile family ("wbf"), each with the factorised edge MLP, and the plain kernels."""
+    if d <= 64:
+        return [("auto", "factorised")]
+    return [("auto", "factorised"), ("auto", "plain"), ("wbf", "factorised")]
+
+
+@pytest.mark.parametrize("which,d,cls_name,update_edges,B", LAYERS)
+def test_meps_layer_matches_oracle(dev, meps_raw, which, d, cls_name, update_edges, B):
+    """One oracle run per layer, every kernel family / factorisation variant of the HIP path against it."""
     from neural_lam_amd import gnn_layers as hl
     from oracle import gnn_layers as og
 
     ei = meps_raw[f"{which}_edge_index"] if which != "m2m" else meps_raw["m2m_edge_index"][0]
     ns, nr, E = int(ei[0].max()) + 1, int(ei[1].max()) + 1, ei.shape[1]
-    B = 2
     torch.manual_seed(7)
     ref = getattr(og, cls_name)(ei, d, update_edges=update_edges)
-    net = getattr(hl, cls_name)(ei, d, update_edges=update_edges)
-    net.load_state_dict(ref.state_dict(), strict=True)
-    net.to(dev)
     send, rec, edge = torch.randn(B, ns, d), torch.randn(B, nr, d), torch.randn(B, E, d)
     srg, rrg, erg = (t.clone().requires_grad_() for t in (send, rec, edge))
-    r_out = ref(srg, rrg, erg)
-    r_outs = r_out if isinstance(r_out, tuple) else (r_out,)
-    cots = [torch.randn_like(o) for o in r_outs]
-    sum((o * c).sum() for o, c in zip(r_outs, cots)).backward()
+    with _Threads():
+        r_out = ref(srg, rrg, erg)
+        r_outs = r_out if isinstance(r_out, tuple) else (r_out,)
+        cots = [torch.randn_like(o) for o in r_outs]
+        sum((o * c).sum() for o, c in zip(r_outs, cots)).backward()
+    r_outs = [o.detach() for o in r_outs]
+    ref_grads = {k: p.grad for k, p in ref.named_parameters()}
 
-    sg, rg, eg = (t.to(dev).requires_grad_() for t in (send, rec, edge))
-    h_out = net(sg, rg, eg)
-    h_outs = h_out if isinstance(h_out, tuple) else (h_out,)
-    assert len(h_outs) == len(r_outs)
-    for o, r in zip(h_outs, r_outs):
-        assert rel_err(o.cpu(), r) < TOL
-        assert row_rel_err(o.cpu(), r) < 10 * TOL   # per-row: rows are LayerNorm outputs + residual, O(1) each
-    sum((o * c.to(dev)).sum() for o, c in zip(h_outs, cots)).backward()
-    assert rel_err(sg.grad.cpu(), srg.grad) < TOL
-    assert rel_err(rg.grad.cpu(), rrg.grad) < TOL
-    assert rel_err(eg.grad.cpu(), erg.grad) < TOL
-    ref_grads = dict(ref.named_parameters())
-    for k, p in net.named_parameters():
-        assert rel_err(p.grad.cpu(), ref_grads[k].grad) < TOL, k
+    for family, factorise in _variants(d):
+        tag = f"{family}/{factorise}"
+        with _Tuning(family, factorise):
+            net = getattr(hl, cls_name)(ei, d, update_edges=update_edges)
+            net.load_state_dict(ref.state_dict(), strict=True)
+            net.to(dev)
+            sg, rg, eg = (t.to(dev).requires_grad_() for t in (send, rec, edge))
+            h_out = net(sg, rg, eg)
+            h_outs = h_out if isinstance(h_out, tuple) else (h_out,)
+            assert len(h_outs) == len(r_outs)
+            for o, r in zip(h_outs, r_outs):
+                assert rel_err(o.cpu(), r) < TOL, tag
+                assert row_rel_err(o.cpu(), r) < 10 * TOL, tag   # per-row: rows are LayerNorm outputs + residual, O(1) each
+            sum((o * c.to(dev)).sum() for o, c in zip(h_outs, cots)).backward()
+            assert rel_err(sg.grad.cpu(), srg.grad) < TOL, tag
+            assert rel_err(rg.grad.cpu(), rrg.grad) < TOL, tag
+            assert rel_err(eg.grad.cpu(), erg.grad) < TOL, tag
+            for k, p in net.named_parameters():
+                assert rel_err(p.grad.cpu(), ref_grads[k]) < TOL, (tag, k)
+            del net, sg, rg, eg, h_out, h_outs
 
 
 def _model_parity(dev, cfg_name, check_one_step=True):
@@ -170,6 +199,110 @@ def test_cfg2_training_step_matches_oracle_at_bench_size(dev):
 def test_cfg4_hilam_d128_training_step_matches_oracle_at_bench_size(dev):
     """BASELINE configs[3]: Hi-LAM, 3 levels, d = 128, full MEPS size (46 layer calls on 544 ... 255 136-edge sets)."""
     _model_parity(dev, "cfg4")
+
+
+def test_cfg4p_hilam_parallel_d128_training_step_matches_oracle_at_bench_size(dev):
+    """HiLAMParallel (hi_lam_parallel.py:145-218) at the benchmarked shape (bench.py cfg4p: d = 128, full MEPS size): the
+    chunked edge / node MLPs (gnn_layers.py:274-324) ride the WIDE kernels on row windows here, which the d = 8 goldens
+    never reach."""
+    _model_parity(dev, "cfg4p")
+
+
+def _oracle_step(cfg, T=None):
+    """Oracle prediction, loss and parameter gradients of bench.py's workload ``cfg`` (optionally with fewer AR steps)."""
+    import bench
+    from oracle import models as om
+
+    ds, _, _, o_fc, _, batch_cpu = bench.build(cfg, torch.device("cpu"), oracle=True)
+    if T is not None:
+        batch_cpu = (batch_cpu[0], batch_cpu[1][:, :T].contiguous(), batch_cpu[2][:, :T].contiguous())
+    pvs, mask = om.per_var_std_uniform(ds), om.interior_mask_bool(ds)
+    with _Threads():
+        o_pred, o_loss = om.training_loss(o_fc, om.standardize_batch(ds, *batch_cpu), pvs, mask)
+        o_loss.backward()
+    grads = {k: p.grad.clone() for k, p in o_fc.named_parameters()}
+    sd = {k: v.clone() for k, v in o_fc.state_dict().items()}
+    return o_pred.detach(), float(o_loss), grads, sd
+
+
+def test_cfg3_rollout_trainer_step_matches_oracle_at_bench_size(dev):
+    """BASELINE configs[2] as bench.py runs it on one GPU: GraphLAM d = 256, 8 processor layers, **ar_steps 4**, full
+    MEPS size -- the rollout case in which every parameter's gradient is a read-modify-write accumulation over four
+    back-propagated AR steps (autoregressive.py:113-149).  The product's trainer step (direct gradient accumulation into
+    the flat buffer) must give the oracle's loss and every oracle parameter gradient in all four launch modes: eager /
+    HIP-graph replay x weight-gradient side streams on / off.  lr = 0 keeps the weights at their seed-42 values, so the
+    four modes and the oracle see the same model."""
+    import gc
+
+    import bench
+    from neural_lam_amd.trainer import Trainer
+
+    cfg = bench.CONFIGS["cfg3"]
+    o_pred, o_loss, o_grads, o_sd = _oracle_step(cfg)
+    _, _, _, h_fc, step, batch = bench.build(cfg, dev)
+    for k, v in h_fc.state_dict().items():
+        assert torch.equal(v.cpu(), o_sd[k]), f"seed-42 init differs between the oracle and the HIP model: {k}"
+    with torch.no_grad():
+        h_pred, h_loss0 = step(*batch)
+    assert rel_err(h_pred.cpu(), o_pred) < TOL
+    assert abs(float(h_loss0) - o_loss) < TOL * abs(o_loss)
+    del h_pred
+    for use_graph in (False, True):
+        for overlap in (True, False):
+            tag = f"graph={use_graph} overlap_wgrad={overlap}"
+            tr = Trainer(step, lr=0.0, use_graph=use_graph, overlap_wgrad=overlap)
+            for it in range(2):   # the second step re-uses the zeroed flat buffer / replays the captured graph
+                loss = tr.step(*batch)
+                torch.cuda.synchronize()
+                assert abs(float(loss) - o_loss) < TOL * abs(o_loss), (tag, it)
+                for k, p in h_fc.named_parameters():
+                    g = o_grads[k]
+                    assert p.grad is not None, (tag, k)
+                    assert float((p.grad.cpu() - g).abs().max()) < TOL * max(float(g.abs().max()), 1e-6), (tag, it, k)
+            if use_graph:
+                assert tr._graph is not None, "the HIP-graph capture fell back to eager launches"
+            del tr
+            gc.collect()
+            torch.cuda.synchronize()
+
+
+CFG5_AUTOCAST_TOL = 3e-2   # bf16 operands (what autocast does to the reference's nn.Linear), fp32 accumulate / LN / aggregation
+
+
+def test_cfg5_two_step_rollout_under_bf16_autocast_at_bench_size(dev):
+    """BASELINE configs[4]: GraphLAM d = 512, 8 processor layers, bf16 mixed precision (Lightning --precision bf16-mixed =
+    torch.autocast, train_model.py:163-168), full MEPS size, two AR steps of the eight (the oracle needs ~40 GB of host
+    memory per pair).  Against the fp32 oracle: prediction and loss within 3e-2; every parameter gradient finite and within
+    bf16-operand distance of the oracle's (relative L2 error <= 1e-1, cosine >= 0.99)."""
+    import bench
+    from neural_lam_amd.trainer import Trainer
+
+    cfg = dict(bench.CONFIGS["cfg5"])
+    T = 2
+    o_pred, o_loss, o_grads, o_sd = _oracle_step(cfg, T=T)
+    _, _, _, h_fc, step, batch = bench.build(cfg, dev)
+    batch = (batch[0], batch[1][:, :T].contiguous(), batch[2][:, :T].contiguous())
+    for k, v in h_fc.state_dict().items():
+        assert torch.equal(v.cpu(), o_sd[k]), k
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.no_grad():
+            h_pred, h_loss0 = step(*batch)
+        assert rel_err(h_pred.float().cpu(), o_pred) < CFG5_AUTOCAST_TOL
+        assert abs(float(h_loss0) - o_loss) < CFG5_AUTOCAST_TOL * abs(o_loss)
+        del h_pred
+        tr = Trainer(step, lr=0.0, use_graph=True)
+        loss = tr.step(*batch)
+        torch.cuda.synchronize()
+    assert abs(float(loss) - o_loss) < CFG5_AUTOCAST_TOL * abs(o_loss)
+    worst_l2, worst_cos = 0.0, 1.0
+    for k, p in h_fc.named_parameters():
+        g, h = o_grads[k].double().reshape(-1), p.grad.cpu().double().reshape(-1)
+        assert bool(torch.isfinite(h).all()), k
+        l2 = float((h - g).norm() / g.norm().clamp(min=1e-30))
+        cos = float((h @ g) / (h.norm() * g.norm()).clamp(min=1e-30))
+        worst_l2, worst_cos = max(worst_l2, l2), min(worst_cos, cos)
+        assert l2 < 1e-1 and cos > 0.99, (k, l2, cos)
+    print(f"cfg5 (T={T}) bf16 autocast vs fp32 oracle: worst gradient rel-L2 {worst_l2:.3e}, worst cosine {worst_cos:.6f}")
 
 
 def test_cfg2_hip_graph_trainer_step_matches_oracle_adamw(dev):

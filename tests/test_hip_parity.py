@@ -68,6 +68,7 @@ LAYER_CASES = [
     "inet_sum_update_d8", "inet_mean_noupdate_b2_d8", "propnet_b2_d8", "propnet_noupdate_d16",
     "inet_chunked_d8", "inet_100to10_gap_d16", "inet_sum_update_b2_d64", "inet_highdeg_d32", "inet_hidden12_d8",
     "inet_sum_update_b2_d128", "propnet_d256", "inet_mean_noupdate_d128",
+    "inet_chunked_b2_d128", "inet_chunked_noupdate_d128",
 ]
 
 
