@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define NLAM_ABI_VERSION 3
+#define NLAM_ABI_VERSION 4
 #define NLAM_MAX_SRC 3
 
 #define NLAM_EINVAL (-1)   /* inconsistent sizes / null pointers        */
@@ -179,6 +179,10 @@ typedef struct {
     int64_t wpack_floats;
     const float* b1;       /* NLAM_F_LEAF_WGRAD only: first-layer bias; with z1 == NULL the kernel recomputes the pre-activation
                               z1 = W1 x + b1 from the (<= 4-column) input instead of reading a saved copy */
+    int32_t dz2_ld;        /* floats between rows of dz2: MUST equal nlam_mlp_bwd_dz2_ld(p) -- 0 = dout, except for an output width
+                              that is not a multiple of 32 on the split-bf16 kernel (output_map, dout = 17): then 32-padded, the
+                              columns past dout are written as zeros, and nlam_wgrad takes dz2 with m = that stride */
+    int32_t _pad2;
 } nlam_mlp_bwd_t;
 
 typedef struct {
@@ -223,11 +227,36 @@ int64_t nlam_mlp_fwd_wpack_floats(const nlam_mlp_fwd_t* p);
 int64_t nlam_mlp_bwd_wpack_floats(const nlam_mlp_bwd_t* p);
 /* workgroups nlam_mlp_bwd launches for this call (rows of vec_partials it writes) */
 int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p);
+/* row stride the call's dz2 buffer must have (set p->dz2_ld to it); 0 = dout (every shape but a ragged output width) */
+int32_t nlam_mlp_bwd_dz2_ld(const nlam_mlp_bwd_t* p);
 /* number of row slices (p->nparts) that fills the chip for this weight-gradient shape */
 int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p);
 
 int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream);
 int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream);
+
+/* Pre-packed weights for the narrow (hid, dout <= 64) split-bf16 kernels.  The reference's nn.Linear weights
+ * (utils/networks.py:8-40) change once per optimizer step (models/module.py:293-304) but every fused-MLP workgroup of
+ * every launch used to re-read them as fp32 and split them into bf16 terms itself.  nlam_mlp_pack writes, for a table of
+ * MLPs, the images the kernels lay out in LDS; nlam_mlp_fwd / nlam_mlp_bwd (and the grouped launches) then take such an
+ * image in `wpack` (wpack_floats = its size) and fetch it by LDS-DMA.  An image is valid for the (source widths, hid,
+ * dout, NLAM_F_PRE_ADD, matrix mode, ldw1) it was packed for and until the weights change; passing NULL keeps the
+ * self-staging path.  Launches the images do not serve (fp32 matrix mode, generic shapes) ignore `wpack`; the wide
+ * kernels keep their own meaning of `wpack` (scratch they pack per launch), so pass an image to narrow launches only.
+ * nlam_mlp_pack_floats: size of the forward (which = 0) / backward (which = 1) image, 0 when the shape is not served. */
+typedef struct {
+    const float* W1;       /* (hid, ldw1 or sum of widths) */
+    const float* W2;       /* (dout, hid) */
+    float* fwd_image;      /* >= nlam_mlp_pack_floats(job, 0) floats, 16-byte aligned, or NULL */
+    float* bwd_image;      /* >= nlam_mlp_pack_floats(job, 1) floats, 16-byte aligned, or NULL */
+    int32_t hid, dout, nsrc;
+    int32_t ldw1;          /* floats between rows of W1; 0 = sum of the GEMM sources' widths */
+    int32_t width[NLAM_MAX_SRC];
+    uint32_t flags;        /* NLAM_F_PRE_ADD | NLAM_F_MM_BF16X1..3 */
+} nlam_pack_job_t;
+int64_t nlam_mlp_pack_floats(const nlam_pack_job_t* job, int32_t which);
+/* `jobs_device`: the job table in DEVICE memory (addresses are stable, so it is uploaded once); one launch packs all */
+int32_t nlam_mlp_pack(const nlam_pack_job_t* jobs_device, int32_t njobs, void* hip_stream);
 
 /* GROUPED launches: n <= NLAM_MAX_GROUP independent fused MLPs of the same kernel shape in ONE grid (every workgroup is
  * bound to one member, the 256 workgroups are dealt in proportion to the members' tile counts).  For the embedders of

@@ -32,9 +32,12 @@ EXPORTS = [
     "nlam_mlp_fwd_wpack_floats",
     "nlam_mlp_bwd_wpack_floats",
     "nlam_mlp_bwd_blocks",
+    "nlam_mlp_bwd_dz2_ld",
     "nlam_wgrad_nparts",
     "nlam_mlp_fwd",
     "nlam_mlp_bwd",
+    "nlam_mlp_pack_floats",
+    "nlam_mlp_pack",
     "nlam_wgrad",
     "nlam_segment_sum",
     "nlam_segment_sum_acc",
@@ -138,6 +141,8 @@ class MlpBwd(C.Structure):
         ("wpack", C.c_void_p),
         ("wpack_floats", C.c_int64),
         ("b1", C.c_void_p),
+        ("dz2_ld", C.c_int32),
+        ("_pad2", C.c_int32),
     ]
 
 
@@ -247,7 +252,22 @@ class StdJobs(C.Structure):
     _fields_ = [("job", StdJob * 4), ("njobs", C.c_int32), ("_pad", C.c_int32)]
 
 
-ABI_VERSION = 3
+class PackJob(C.Structure):
+    _fields_ = [
+        ("W1", C.c_void_p),
+        ("W2", C.c_void_p),
+        ("fwd_image", C.c_void_p),
+        ("bwd_image", C.c_void_p),
+        ("hid", C.c_int32),
+        ("dout", C.c_int32),
+        ("nsrc", C.c_int32),
+        ("ldw1", C.c_int32),
+        ("width", C.c_int32 * NLAM_MAX_SRC),
+        ("flags", C.c_uint32),
+    ]
+
+
+ABI_VERSION = 4
 _lib = None
 
 
@@ -286,10 +306,16 @@ def load():
     lib.nlam_mlp_fwd_wpack_floats.restype = i64
     lib.nlam_mlp_bwd_wpack_floats.argtypes = [C.POINTER(MlpBwd)]
     lib.nlam_mlp_bwd_wpack_floats.restype = i64
+    lib.nlam_mlp_bwd_dz2_ld.argtypes = [C.POINTER(MlpBwd)]
+    lib.nlam_mlp_bwd_dz2_ld.restype = i32
     lib.nlam_mlp_bwd_blocks.argtypes = [C.POINTER(MlpBwd)]
     lib.nlam_mlp_bwd_blocks.restype = i32
     lib.nlam_wgrad_nparts.argtypes = [C.POINTER(Wgrad)]
     lib.nlam_wgrad_nparts.restype = i32
+    lib.nlam_mlp_pack_floats.argtypes = [C.POINTER(PackJob), i32]
+    lib.nlam_mlp_pack_floats.restype = i64
+    lib.nlam_mlp_pack.argtypes = [vp, i32, vp]
+    lib.nlam_mlp_pack.restype = i32
     lib.nlam_mlp_fwd.argtypes = [C.POINTER(MlpFwd), vp]
     lib.nlam_mlp_fwd.restype = i32
     lib.nlam_mlp_bwd.argtypes = [C.POINTER(MlpBwd), vp]

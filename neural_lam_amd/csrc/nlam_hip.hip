@@ -452,15 +452,14 @@ __device__ __forceinline__ void mma_split_lds(f32x16 (&acc)[NB], const u32x4* Wp
 // Stage an (M x K) weight slice as split-bf16 A fragments:
 //   dst[((term * MB + mb) * S + s0 + s) * 64 + lane] (16 B) = slots q = 0..7 of row mb*32 + (lane & 31),
 //   k = perm2 ? 32*(s>>1) + 16*(s&1) + (q&3) + 8*(q>>2) + 4*hi : 16*s + 8*hi + q ;  A[m][k] = W[m*ldm + k]
+// (tid, nthr): the caller's thread index / thread count -- a workgroup staging into its LDS passes (threadIdx.x, blockDim.x),
+// the pack kernel (nlam_mlp_pack: the same images written ONCE per optimizer step into global memory) its grid-wide ones.
 template <int NS>
-__device__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2, long ldk = 1,
-                            int Kpad = 0) {
-#ifdef NLAM_EXPERIMENT_NOSTAGE   // tools/ab experiments only: how much of a launch is weight staging (results are garbage)
-    return;
-#endif
+__device__ void stage_split_impl(u32x4* dst, int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2, long ldk,
+                                 int Kpad, int tid, int nthr) {
     const int nst = (Kpad > 0 ? Kpad : K) >> 4;   // steps written (columns k >= K are zero)
     const int total = MB * nst * 64;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    for (int idx = tid; idx < total; idx += nthr) {
         const int lane = idx & 63;
         const int rest = idx >> 6;
         const int st = rest % nst, mb = rest / nst;
@@ -490,6 +489,30 @@ __device__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm,
 #pragma unroll
         for (int p = 0; p < NS; ++p) dst[(((size_t)p * MB + mb) * S + s0 + st) * 64 + lane] = f.t[p];
     }
+}
+
+template <int NS>
+__device__ __forceinline__ void stage_split(u32x4* dst, int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2,
+                                            long ldk = 1, int Kpad = 0) {
+#ifdef NLAM_EXPERIMENT_NOSTAGE   // tools/ab experiments only: how much of a launch is weight staging (results are garbage)
+    return;
+#endif
+    stage_split_impl<NS>(dst, S, s0, W, ldm, M, MB, K, perm2, ldk, Kpad, (int)threadIdx.x, (int)blockDim.x);
+}
+
+// Pre-packed weights (nlam_mlp_pack): the split-bf16 A fragments of an MLP exactly as the narrow kernels lay them out in LDS,
+// written once per optimizer step; a workgroup then fetches its weights by LDS-DMA (global_load_lds_dwordx4: 1 KiB per
+// wave-instruction, no staging registers, no conversion work) instead of loading fp32 rows and splitting them itself.
+// `bytes` is a multiple of 1024 (every image piece is: 2048 * NS * blocks * steps bytes); dst / src are 16-byte aligned; the
+// caller's next __syncthreads() (which drains the wave's LDS-DMA: vmcnt(0)) publishes the data.
+__device__ __forceinline__ void lds_dma_copy(float* dst_lds, const float* src, size_t bytes) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = (int)(blockDim.x >> 6);
+    const int npieces = (int)(bytes >> 10);
+    for (int c = wave; c < npieces; c += nw)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(dst_lds + (size_t)c * 256), 16, 0, 0);
 }
 
 // FAST = every source width is a multiple of 8, hid == 32*HB and dout == 32*OB: no
@@ -1021,7 +1044,10 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
     }
 
     // ---- weights -> LDS while the first tile's descriptor / index / row loads are in flight ----
-    {
+    if (p.wpack != nullptr) {
+        // pre-packed image (nlam_mlp_pack, once per optimizer step): [W1s | W2s] in exactly this LDS layout
+        lds_dma_copy(smem, p.wpack, ((size_t)NS * HB * S1 * 64 + (size_t)NS * OB * S2 * 64) * 16);
+    } else {
         int s0 = 0, off = 0;
         for (int s = 0; s < ngemm; ++s) {
             const int w = p.src[s].width;
@@ -1242,8 +1268,22 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
                         *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = m[tt];
                     }
                     wave_lds_sync();
-                    block_rows_out(stg, tl.nrows, 32, lane,
-                                   [&](int r) { return obase + (long)__shfl(oidx, r, 64) * p.dout + 32 * ob; });
+                    if (RAG && (p.dout & 31) != 0) {
+                        // output width not a whole 32-column block (output_map, graph/base.py:322: 17 state variables; no
+                        // LayerNorm): rows of p.dout floats are not 16-byte aligned, so the block leaves as dwords -- lane ->
+                        // (row, column) in row-major order of the tile, which is contiguous in memory for identity row order
+                        const int wb = min(32, p.dout - 32 * ob);
+                        const int total = tl.nrows * wb;
+                        for (int base = 0; base < total; base += 64) {
+                            const int item = base + lane;
+                            const int r = min(item / wb, 31), c = item - r * wb;
+                            float* d = obase + (long)__shfl(oidx, r, 64) * p.dout + 32 * ob;
+                            if (item < total) d[c] = stg[r * kStgStride + c];
+                        }
+                    } else {
+                        block_rows_out(stg, tl.nrows, 32, lane,
+                                       [&](int r) { return obase + (long)__shfl(oidx, r, 64) * p.dout + 32 * ob; });
+                    }
                     wave_lds_sync();
                 }
             }
@@ -1616,7 +1656,10 @@ __device__ __forceinline__ float block_colsum_half(const float* stg, int lane) {
 // the K dimension: lane (i, hi) reads rows 8 hi .. 8 hi + 7 of column i of the row-major staged block), dW1[:, k] as
 // column sums of dz1 weighted with input column k.  dz1 / dz2 never leave the chip; p.dz2 receives the workgroup's
 // (dout x hid) partial, vec_partials has 7 rows per workgroup (db1, db2, dgamma, dbeta, dW1[:, 0..2]).
-template <int HB, int OB, int NS, bool LW = false, int NWV = kWavesPerBlock>
+// RO: the output width is not a whole 32-column block (output_map, graph/base.py:322: dout = 17, no LayerNorm): g_out rows are
+// read element-wise and zero-filled past dout, dz2 is written with a row stride of OB * 32 floats (p.dz2_ld; zero columns past
+// dout), so that its weight gradient runs on the LDS-DMA kernel with m = OB * 32.
+template <int HB, int OB, int NS, bool LW = false, int NWV = kWavesPerBlock, bool RO = false>
 __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const int wg_id, const int wg_count) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int DPH = HB * 32, OP = OB * 32;
@@ -1652,9 +1695,20 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
     float* colacc_all = stg_all + (size_t)NWV * 32 * kStgStride;   // NWV x 8 x 64 column accumulators
     float* xs_all = colacc_all + (size_t)NWV * 8 * 64;             // LW: NWV x [32][4] input rows of the tile
     float* w1l = xs_all + (size_t)NWV * 32 * 4;                    // LW with z1 == NULL: W1 rows padded to 4 columns [DPH][4], then b1 [DPH]
-    if constexpr (NS > 0) {
+    if (NS > 0 && p.wpack != nullptr) {
+        // pre-packed image (nlam_mlp_pack): [W2^T | W1_0^T | W1_1^T | W1_2^T], a W1 piece for every source whose width is a
+        // multiple of 32 (source 0 only for the factorised MLP); pieces of sources without a data gradient are skipped
+        lds_dma_copy(W2t, p.wpack, w2_floats * sizeof(float));
+        size_t ioff = w2_floats;
+        for (int s = 0; s < p.nsrc; ++s) {
+            const int w = p.src[s].width;
+            const size_t piece = ((w & 31) == 0 && (!pre || s == 0)) ? (size_t)NS * w * DPH / 2 : 0;
+            if (gemm_src(s)) lds_dma_copy(W1t + w1_off[s], p.wpack + ioff, piece * sizeof(float));
+            ioff += piece;
+        }
+    } else if constexpr (NS > 0) {
         // A[m = hidden][k = out (slot-permuted)] = W2[k][m]
-        stage_split<NSW>(reinterpret_cast<u32x4*>(W2t), S2, 0, p.W2, 1, p.hid, HB, p.dout, true, p.hid);
+        stage_split<NSW>(reinterpret_cast<u32x4*>(W2t), S2, 0, p.W2, 1, p.hid, HB, p.dout, true, p.hid, OP);
         int off = 0;
         for (int s = 0; s < p.nsrc; ++s) {
             const int w = p.src[s].width;
@@ -1777,7 +1831,12 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
                     const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
                     f32x4 g = {0.f, 0.f, 0.f, 0.f};
                     if (LW && gpre_ready) g = gpre[LW ? ob : 0][tt];
-                    else if (grow != nullptr) g = *reinterpret_cast<const f32x4*>(grow + c0);
+                    else if (RO) {
+                        if (grow != nullptr) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) g[c] = c0 + c < p.dout ? grow[c0 + c] : 0.f;
+                        }
+                    } else if (grow != nullptr) g = *reinterpret_cast<const f32x4*>(grow + c0);
                     if (garow != nullptr) g += *reinterpret_cast<const f32x4*>(garow + c0) * gscale;
                     if (!valid) g = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (has_ln) xh[tt] = *reinterpret_cast<const f32x4*>(xrow + c0);
@@ -1849,8 +1908,9 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
             wave_lds_sync();
             colacc[(kDb2 + ob) * 64] += block_colsum_half(stg, lane);
             if (!LW && p.dz2 != nullptr) {
-                float* dbase = p.dz2 + tile_row0 * p.dout + 32 * ob;
-                block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return dbase + (size_t)r * p.dout; });
+                const size_t ldz2 = RO ? (size_t)OP : (size_t)p.dout;
+                float* dbase = p.dz2 + tile_row0 * ldz2 + 32 * ob;
+                block_rows_out(stg, tl.nrows, 32, lane, [&](int r) { return dbase + (size_t)r * ldz2; });
             }
             wave_lds_sync();
         }
@@ -2154,9 +2214,9 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
     }
 }
 
-template <int HB, int OB, int NS>
+template <int HB, int OB, int NS, bool RO = false>
 __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_mlp_bwd_t p) {
-    mlp_bwd_fast_body<HB, OB, NS>(p, (int)blockIdx.x, (int)gridDim.x);
+    mlp_bwd_fast_body<HB, OB, NS, false, kWavesPerBlock, RO>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 struct bwd_group_t {
@@ -3213,6 +3273,88 @@ __global__ __launch_bounds__(kFwdThreads) void linear_bfw_kernel(const nlam_line
     }
 }
 
+// ---------------------------------------------------------------------------
+// nlam_mlp_pack: the LDS weight images of the narrow split-bf16 kernels, written ONCE per optimizer step.
+// Every chain workgroup used to load the fp32 weights and split them into bf16 terms itself (~95 us per cfg2 step in total,
+// on the critical path of ~30 latency-bound launches); with an image it issues a handful of LDS-DMA instructions instead.
+//   forward image : [W1s | W2s]                         (mlp_fwd_bf_body's layout: sources padded to 32-column units)
+//   backward image: [W2^T | W1_0^T | W1_1^T | W1_2^T]   (mlp_bwd_fast_body's layout; a W1 piece per source of width % 32 == 0)
+// grid = (blocks, jobs); the job table lives in device memory (built once: parameter and image addresses are stable).
+// ---------------------------------------------------------------------------
+struct PackShape {
+    int ns, HB, OB, ngemm, S1, ok;
+    size_t fwd_floats, bwd_floats;
+};
+
+__host__ __device__ inline PackShape pack_shape(const nlam_pack_job_t& j) {
+    PackShape r = {0, 0, 0, 0, 0, 0, 0, 0};
+    r.ns = (int)((j.flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
+    if (r.ns < 1 || r.ns > 3 || j.nsrc < 1 || j.nsrc > NLAM_MAX_SRC || j.hid < 1 || j.dout < 1) return r;
+    if (j.hid > kMaxWidth || j.dout > kMaxWidth || (j.hid & 31) != 0) return r;
+    r.HB = j.hid >> 5;
+    r.OB = (j.dout + 31) >> 5;
+    const bool pre = (j.flags & NLAM_F_PRE_ADD) != 0;
+    r.ngemm = pre ? 1 : j.nsrc;
+    int nunits = 0;
+    for (int s = 0; s < j.nsrc; ++s) {
+        if (j.width[s] < 1 || j.width[s] > kMaxWidth) return r;
+        if (s < r.ngemm) nunits += (j.width[s] + 31) >> 5;
+    }
+    r.S1 = 2 * nunits;
+    const int DPH = r.HB * 32, OP = r.OB * 32;
+    r.fwd_floats = ((size_t)r.ns * r.HB * r.S1 * 64 + (size_t)r.ns * r.OB * (DPH / 16) * 64) * 4;
+    r.bwd_floats = (size_t)r.ns * DPH * OP / 2;
+    for (int s = 0; s < r.ngemm; ++s)
+        if ((j.width[s] & 31) == 0) r.bwd_floats += (size_t)r.ns * j.width[s] * DPH / 2;
+    r.ok = 1;
+    return r;
+}
+
+template <int NS>
+__device__ void pack_job(const nlam_pack_job_t& j, const PackShape& sh, int tid, int nthr) {
+    const int DPH = sh.HB * 32, OP = sh.OB * 32;
+    int kin = 0;
+    for (int s = 0; s < sh.ngemm; ++s) kin += j.width[s];
+    const int ldw1 = j.ldw1 > 0 ? j.ldw1 : kin;
+    if (j.fwd_image != nullptr) {
+        u32x4* W1s = reinterpret_cast<u32x4*>(j.fwd_image);
+        u32x4* W2s = W1s + (size_t)NS * sh.HB * sh.S1 * 64;
+        int s0 = 0, off = 0;
+        for (int s = 0; s < sh.ngemm; ++s) {
+            const int w = j.width[s];
+            stage_split_impl<NS>(W1s, sh.S1, s0, j.W1 + off, ldw1, j.hid, sh.HB, w, false, 1, ((w + 31) >> 5) * 32, tid, nthr);
+            off += w;
+            s0 += 2 * ((w + 31) >> 5);
+        }
+        stage_split_impl<NS>(W2s, DPH / 16, 0, j.W2, j.hid, j.dout, sh.OB, j.hid, true, 1, 0, tid, nthr);
+    }
+    if (j.bwd_image != nullptr) {
+        float* W2t = j.bwd_image;
+        // A[m = hidden][k = out (slot-permuted)] = W2[k][m]
+        stage_split_impl<NS>(reinterpret_cast<u32x4*>(W2t), OP / 16, 0, j.W2, 1, j.hid, sh.HB, j.dout, true, j.hid, OP, tid, nthr);
+        size_t ioff = (size_t)NS * DPH * OP / 2;
+        int off = 0;
+        for (int s = 0; s < sh.ngemm; ++s) {
+            const int w = j.width[s];
+            if ((w & 31) == 0) {   // A[m = source column][k = hidden (slot-permuted)] = W1[k][off + m]
+                stage_split_impl<NS>(reinterpret_cast<u32x4*>(W2t + ioff), DPH / 16, 0, j.W1 + off, 1, w, w >> 5, j.hid, true, ldw1, 0, tid, nthr);
+                ioff += (size_t)NS * w * DPH / 2;
+            }
+            off += w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const nlam_pack_job_t* jobs) {
+    const nlam_pack_job_t j = jobs[blockIdx.y];
+    const PackShape sh = pack_shape(j);
+    if (!sh.ok) return;
+    const int tid = (int)(blockIdx.x * blockDim.x + threadIdx.x), nthr = (int)(gridDim.x * blockDim.x);
+    if (sh.ns == 3) pack_job<3>(j, sh, tid, nthr);
+    else if (sh.ns == 2) pack_job<2>(j, sh, tid, nthr);
+    else pack_job<1>(j, sh, tid, nthr);
+}
+
 #include "nlam_wide.inc"
 #include "nlam_wbf.inc"
 
@@ -3313,6 +3455,18 @@ bool bwd_is_wide(const nlam_mlp_bwd_t* p) {
     for (int s = 0; s < p->nsrc; ++s)
         if (p->src[s].width > kMaxWidth) return true;
     return false;
+}
+
+// narrow backward with an output width that is not a whole 32-column block on the split-bf16 fast kernel (RO instantiation):
+// one output block, no LayerNorm / aggregation / residual, a split-bf16 matrix mode, FAST hidden width and source widths
+bool bwd_ragged_out(const nlam_mlp_bwd_t* p) {
+    if (bwd_is_wide(p) || p->dout % 32 == 0 || p->dout > 32 || p->hid % 32 != 0) return false;
+    if (p->ln_w != nullptr || p->g_aggr != nullptr || p->g_out == nullptr || p->out_idx != nullptr) return false;
+    if ((p->flags & (NLAM_F_ADD_SRC0 | NLAM_F_ADD_SRC1 | NLAM_F_PRE_ADD | NLAM_F_LEAF_WGRAD)) != 0) return false;
+    if ((p->flags & NLAM_F_MM_MASK) == 0) return false;
+    for (int s = 0; s < p->nsrc; ++s)
+        if (p->dmode[s] != 0 && p->src[s].width != 32 && p->src[s].width != 64) return false;
+    return true;
 }
 
 int bwd_wide_maxw(const nlam_mlp_bwd_t* p) {
@@ -3449,6 +3603,21 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     return NLAM_EINVAL;
 }
 
+int64_t nlam_mlp_pack_floats(const nlam_pack_job_t* job, int32_t which) {
+    if (job == nullptr || job->W1 == nullptr || job->W2 == nullptr) return 0;
+    const PackShape sh = pack_shape(*job);
+    if (!sh.ok) return 0;
+    return (int64_t)(which == 0 ? sh.fwd_floats : sh.bwd_floats);
+}
+
+int32_t nlam_mlp_pack(const nlam_pack_job_t* jobs_device, int32_t njobs, void* hip_stream) {
+    if (jobs_device == nullptr || njobs < 0 || njobs > 65535) return NLAM_EINVAL;
+    if (njobs == 0) return 0;
+    // the largest piece (a 64 x 192 first layer) is 1 536 lane items: four 256-thread blocks per job
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(4, njobs), dim3(256), 0, (hipStream_t)hip_stream, jobs_device);
+    return (int32_t)hipGetLastError();
+}
+
 int64_t nlam_mlp_fwd_wpack_floats(const nlam_mlp_fwd_t* p) {
     if (p == nullptr || !fwd_is_wide(p)) return 0;
     const int ns = fwd_wbf_ns(p);
@@ -3465,6 +3634,11 @@ int64_t nlam_mlp_bwd_wpack_floats(const nlam_mlp_bwd_t* p) {
     for (int s = 0; s < p->nsrc; ++s)
         if (p->dmode[s] != 0) f += (int64_t)((p->src[s].width + 31) / 32) * HBT * 1024;
     return f;
+}
+
+int32_t nlam_mlp_bwd_dz2_ld(const nlam_mlp_bwd_t* p) {
+    if (p == nullptr) return 0;
+    return bwd_ragged_out(p) ? ((p->dout + 31) / 32) * 32 : 0;
 }
 
 int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p) {
@@ -3668,8 +3842,13 @@ int32_t nlam_detail::fwd_narrow(const nlam_mlp_fwd_t* p, hipStream_t stream) {
     const int nwaves = kFwdWaves;
     const int blocks = (int)(ttiles < 1 ? 1 : (ttiles < kMaxGridBlocks ? ttiles : kMaxGridBlocks));
     const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
-    const bool fast_out = (p->hid % 32 == 0) && (p->dout % 32 == 0);
-    bool fast = fast_out, w64 = true, ragged = false;
+    // an output width that is not a whole 32-column block runs on the split-bf16 kernels when nothing downstream of GEMM2
+    // needs whole blocks: no LayerNorm, no aggregation, no residual (output_map, graph/base.py:322); W2 / b2 are zero-padded
+    // when staged and the ragged-input instantiation stores the block as dwords
+    const bool ragged_out = (p->dout % 32 != 0) && p->ln_w == nullptr && p->aggr == nullptr && p->nsrc == 1 && p->out != nullptr &&
+                            (p->flags & (NLAM_F_ADD_SRC0 | NLAM_F_ADD_SRC1 | NLAM_F_PRE_ADD)) == 0 && p->xhat == nullptr;
+    const bool fast_out = (p->hid % 32 == 0) && (p->dout % 32 == 0 || ragged_out);
+    bool fast = fast_out && !ragged_out, w64 = true, ragged = ragged_out;
     for (int s = 0; s < p->nsrc; ++s) {
         fast = fast && (p->src[s].width % 8 == 0);
         w64 = w64 && p->src[s].width <= 64;
@@ -3967,7 +4146,9 @@ extern "C" int32_t nlam_mlp_bwd_group(const nlam_mlp_bwd_t* ps, int32_t n, void*
 int32_t nlam_detail::bwd_narrow(const nlam_mlp_bwd_t* p, hipStream_t stream) {
     const int blocks = grid_blocks((long)p->ntiles * p->batch);
     const int HB = (p->hid + 31) / 32, OB = (p->dout + 31) / 32;
-    bool fast = (p->hid % 32 == 0) && (p->dout % 32 == 0);
+    const bool ro = bwd_ragged_out(p);   // output_map: dout not a whole block, no LayerNorm -> split-bf16 fast kernel, dz2 padded to OB * 32 columns
+    if ((ro ? OB * 32 : 0) != p->dz2_ld) return NLAM_EINVAL;   // the caller sized dz2 with nlam_mlp_bwd_dz2_ld
+    bool fast = (p->hid % 32 == 0) && (p->dout % 32 == 0 || ro);
     for (int s = 0; s < p->nsrc; ++s)
         if (p->dmode[s] != 0) fast = fast && (p->src[s].width == 32 || p->src[s].width == 64);
     if ((p->flags & NLAM_F_ADD_SRC0) && p->dmode[0] != 0 && p->src[0].width != p->dout) fast = false;
@@ -3993,6 +4174,24 @@ int32_t nlam_detail::bwd_narrow(const nlam_mlp_bwd_t* p, hipStream_t stream) {
         else if (ns == 1) NLAM_LAUNCH_BWDF1(HB_, OB_, 1); \
         else NLAM_LAUNCH_BWDF1(HB_, OB_, 0);              \
     } while (0)
+#define NLAM_LAUNCH_BWDRO1(HB_, OB_, NS_)                                                                                  \
+    do {                                                                                                                  \
+        const size_t lds = bwd_fast_lds_bytes(p, HB_, OB_, NS_);                                                          \
+        int rc = set_lds(mlp_bwd_fast_kernel<HB_, OB_, NS_, true>, lds);                                                  \
+        if (rc != 0) return rc;                                                                                           \
+        hipLaunchKernelGGL((mlp_bwd_fast_kernel<HB_, OB_, NS_, true>), dim3(blocks), dim3(kBlockThreads), lds, stream, *p); \
+    } while (0)
+#define NLAM_LAUNCH_BWDRO(HB_, OB_)                     \
+    do {                                                \
+        if (ns == 3) NLAM_LAUNCH_BWDRO1(HB_, OB_, 3);      \
+        else if (ns == 2) NLAM_LAUNCH_BWDRO1(HB_, OB_, 2); \
+        else NLAM_LAUNCH_BWDRO1(HB_, OB_, 1);              \
+    } while (0)
+        if (ro) {   // OB == 1 by construction (dout < 32 ... the only shape the reference has: output_map)
+            if (HB == 1) NLAM_LAUNCH_BWDRO(1, 1);
+            else NLAM_LAUNCH_BWDRO(2, 1);
+            return (int32_t)hipGetLastError();
+        }
         if (HB == 1 && OB == 1) NLAM_LAUNCH_BWDF(1, 1);
         else if (HB == 2 && OB == 1) NLAM_LAUNCH_BWDF(2, 1);
         else if (HB == 1 && OB == 2) NLAM_LAUNCH_BWDF(1, 2);

@@ -64,14 +64,16 @@ EARLY_LEAF_BACKWARD = False
 
 
 @contextlib.contextmanager
-def direct_param_grads(listener=None, early_leaf=True):
-    global DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD
-    prev = (DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD)
-    DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD = True, listener, bool(early_leaf)
+def direct_param_grads(listener=None, early_leaf=True, packer=None):
+    global DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD, PACKER
+    prev = (DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD, PACKER)
+    DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD, PACKER = True, listener, bool(early_leaf), packer
     try:
+        if packer is not None:
+            packer.begin_step()   # the weight images of every registered MLP, rewritten from the current weights
         yield
     finally:
-        DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD = prev
+        DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD, PACKER = prev
 
 
 def early_backward_leaf(out):
@@ -160,6 +162,76 @@ class _WgradOverlap:
 OVERLAP = _WgradOverlap()
 
 
+class WeightPacker:
+    """Pre-packed weight images of the narrow fused kernels (``nlam_mlp_pack``), owned by a trainer.
+
+    The reference's ``nn.Linear`` weights change once per optimizer step (models/module.py:293-304), but every workgroup of
+    every fused-MLP launch used to read them as fp32 and split them into bf16 terms itself (~95 us of a 1.9 ms cfg2 step, on
+    the critical path of ~30 latency-bound launches).  While a trainer has a packer installed (``direct_param_grads``), each
+    fused MLP registers the image it needs the first time it runs; from the next step on ``begin_step`` rewrites ALL images
+    with one launch and the kernels fetch them by LDS-DMA.  Keys are parameter addresses: the trainer's flat parameter
+    buffer never moves."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("NLAM_PACK_WEIGHTS", "1") == "1"
+        self.entries = {}
+        self.table = None          # device copy of the nlam_pack_job_t array
+        self.table_entries = []    # the entries it describes, in table order
+        self.dirty = False
+        self.step_id = 0
+
+    class Entry:
+        __slots__ = ("job", "fwd", "bwd", "packed_step")
+
+    def get(self, W1, W2, widths, hid, dout, pre, ldw1, mm_flags):
+        """The entry whose images are valid for THIS step, or None (not served / registered only now)."""
+        if not self.enabled:
+            return None
+        key = (W1.data_ptr(), W2.data_ptr(), tuple(widths), hid, dout, bool(pre), int(ldw1), int(mm_flags))
+        e = self.entries.get(key)
+        if e is None:
+            job = L.PackJob()
+            job.W1, job.W2, job.hid, job.dout, job.nsrc, job.ldw1 = W1.data_ptr(), W2.data_ptr(), hid, dout, len(widths), int(ldw1)
+            for k, w in enumerate(widths):
+                job.width[k] = int(w)
+            job.flags = int(mm_flags) | (L.F_PRE_ADD if pre else 0)
+            lib = L.load()
+            nf, nb = int(lib.nlam_mlp_pack_floats(C.byref(job), 0)), int(lib.nlam_mlp_pack_floats(C.byref(job), 1))
+            e = WeightPacker.Entry()
+            e.job, e.fwd, e.bwd, e.packed_step = job, None, None, -1
+            if nf > 0 and nb > 0:
+                e.fwd = torch.empty((nf,), device=W1.device, dtype=torch.float32)
+                e.bwd = torch.empty((nb,), device=W1.device, dtype=torch.float32)
+                job.fwd_image, job.bwd_image = e.fwd.data_ptr(), e.bwd.data_ptr()
+                self.dirty = True
+            self.entries[key] = e
+        return e if (e.fwd is not None and e.packed_step == self.step_id) else None
+
+    def begin_step(self):
+        """Rewrite every registered image from the current weights: one launch, first thing in the step (inside a captured
+        step it is the first kernel of the graph).  Entries registered since the last call join the table here -- except
+        during a stream capture (a host-to-device copy of the table is not capturable): they wait for the next eager call."""
+        self.step_id += 1
+        if not self.enabled:
+            return
+        if self.dirty and not torch.cuda.is_current_stream_capturing():
+            live = [e for e in self.entries.values() if e.fwd is not None]
+            arr = (L.PackJob * len(live))(*[e.job for e in live])
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.table = host.to(live[0].fwd.device)
+            self.table_entries = live
+            self.dirty = False
+        if self.table is None:
+            return
+        L.check(L.load().nlam_mlp_pack(C.c_void_p(self.table.data_ptr()), len(self.table_entries), _stream()), "nlam_mlp_pack")
+        for e in self.table_entries:
+            e.packed_step = self.step_id
+
+
+# Installed by a trainer for the duration of its own forward + backward (direct_param_grads)
+PACKER = None
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -211,11 +283,11 @@ def _ptr(t):
 _MM_NAMES = {0: "f32", 1: "bf16", 2: "bf16x2", 3: "bf16x3"}
 
 
-def _mm_executed(mm_flags, hid, dout, widths):
+def _mm_executed(mm_flags, hid, dout, widths, ragged_out_ok=False):
     """Matrix instruction a fused-MLP launch issues (mirrors the dispatch of csrc/nlam_hip.hip: shapes the split-bf16
     kernels do not cover run the fp32 MFMA) -> (name, bf16 MFMAs executed per algorithmic product block; 0 = fp32 MFMA)."""
     ns = (mm_flags >> 8) & 3
-    covered = hid % 32 == 0 and dout % 32 == 0 and all(w % 4 == 0 for w in widths)
+    covered = hid % 32 == 0 and (dout % 32 == 0 or (ragged_out_ok and dout < 32 and len(widths) == 1)) and all(w % 4 == 0 for w in widths)
     if max([hid, dout, *widths]) <= 64:
         covered = covered and (len(widths) == 1 or all(w % 32 == 0 for w in widths))
     if ns == 0 or not covered:
@@ -367,9 +439,15 @@ class FusedMLPFunction(torch.autograd.Function):
                 rstd = torch.empty((B, rows), device=dev, dtype=torch.float32)
                 p.xhat, p.rstd = _ptr(xhat), _ptr(rstd)
         nwp = lib.nlam_mlp_fwd_wpack_floats(C.byref(p))
+        pack = None
         if nwp > 0:  # wide kernels: scratch for the weights in MFMA A-operand order
             wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
             p.wpack, p.wpack_floats = _ptr(wpack), nwp
+        elif PACKER is not None:   # narrow kernels under a trainer: the image packed once for this step
+            pack = PACKER.get(W1c, W2c, widths, hid, dout, pre, kin if pre else 0, mm_flags)
+            if pack is not None:
+                p.wpack, p.wpack_floats = pack.fwd.data_ptr(), pack.fwd.numel()
+        ctx.pack = pack
         key = ("mlp_fwd", rows * B, kin, hid, dout, geom.nsrc, bool(geom.aggregate), need_grad)
 
         def fwd_meta():
@@ -383,7 +461,7 @@ class FusedMLPFunction(torch.autograd.Function):
             for t_ in (z1, xhat, rstd):
                 if t_ is not None:
                     nbytes += t_.numel() * 4
-            name, mf = _mm_executed(mm_flags, hid, dout, widths)
+            name, mf = _mm_executed(mm_flags, hid, dout, widths, ragged_out_ok=ln_w is None and not geom.aggregate)
             k1 = widths[0] if pre else kin
             return {"flops": 2.0 * rows * B * (k1 * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
                     "what": ("gather + " if geom.nsrc == 3 else "") + ("factorised " if pre else "") + "Linear-SiLU-Linear" + ("-LayerNorm" if ln_w is not None else "")
@@ -451,8 +529,7 @@ class FusedMLPFunction(torch.autograd.Function):
         p.rowptr, p.inv_deg = _ptr(geom.rowptr), _ptr(geom.inv_deg)
         p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
         dz1 = torch.empty((B * rows, hid), device=dev, dtype=torch.float32)
-        dz2 = torch.empty((B * rows, dout), device=dev, dtype=torch.float32)
-        p.dz1, p.dz2 = _ptr(dz1), _ptr(dz2)
+        p.dz1 = _ptr(dz1)
         dsrc = [None] * nsrc
         tmp2 = [None] * nsrc
         for k in range(nsrc):
@@ -477,11 +554,14 @@ class FusedMLPFunction(torch.autograd.Function):
                 alloc = torch.zeros if geom.has_split else torch.empty
                 dsrc[k] = alloc((B, geom.nseg_total, w), device=dev, dtype=torch.float32)
                 p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), geom.nseg_total * w
+        dz2, dpad = _alloc_dz2(lib, p, B * rows, dout, dev)   # (rows, dout); 32-padded columns for a ragged output width (output_map)
         nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
         wpack = None
         if nwp > 0:
             wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
             p.wpack, p.wpack_floats = _ptr(wpack), nwp
+        elif ctx.pack is not None and PACKER is not None and ctx.pack.packed_step == PACKER.step_id:
+            p.wpack, p.wpack_floats = ctx.pack.bwd.data_ptr(), ctx.pack.bwd.numel()
         nblk = lib.nlam_mlp_bwd_blocks(C.byref(p))
         vs = _vec_stride(hid, dout)
         vecp = torch.empty((nblk, 4, vs), device=dev, dtype=torch.float32)
@@ -518,7 +598,8 @@ class FusedMLPFunction(torch.autograd.Function):
             nbytes = sum(t_.numel() * 4 for t_ in (g_out, g_aggr, z1, xhat, rstd, dz1, dz2) if t_ is not None)
             nbytes += sum(t_.numel() * 4 for t_ in (*dsrc, *tmp2) if t_ is not None)
             kin_live = sum(w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0 and not (pre and k_ > 0))
-            name, mf = _mm_executed(ctx.mm_flags, hid, dout, [w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0] or [hid])
+            name, mf = _mm_executed(ctx.mm_flags, hid, dout, [w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0] or [hid],
+                                    ragged_out_ok=dpad != dout)
             return {"flops": 2.0 * rows * B * (kin_live * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
                     "what": "LayerNorm/SiLU backward + dh = dz2 W2 + dx = dz1 W1 (data gradients; writes dz1, dz2 for the weight gradients)"}
 
@@ -579,7 +660,7 @@ class FusedMLPFunction(torch.autograd.Function):
         results = [None] * 6   # dW1, db1, dW2, db2, dgamma, dbeta
         with side_ctx:
             part1 = wgrad(dz1, hid, src_list, kin1, 0) if ctx.needs_input_grad[1] else None
-            part2 = wgrad(dz2, dout, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if ctx.needs_input_grad[3] else None
+            part2 = wgrad(dz2, dpad, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if ctx.needs_input_grad[3] else None
 
             # ---- one launch reduces every partial sum; with DIRECT_PARAM_GRADS it accumulates into .grad ----
             jobs = L.ReduceJobs()
@@ -607,8 +688,8 @@ class FusedMLPFunction(torch.autograd.Function):
                 add_job(0, _ptr(part1), part1.shape[0], hid * kin1, (hid, kin), prm[0], ncols=kin1 if pre else 0)
             if ctx.needs_input_grad[2]:
                 add_job(1, vbase + 0 * vs * 4, nblk, 4 * vs, (hid,), prm[1])
-            if part2 is not None:
-                add_job(2, _ptr(part2), part2.shape[0], dout * hid, (dout, hid), prm[2])
+            if part2 is not None:   # a padded dz2 gives (dpad, hid) partials: the first dout rows are the gradient
+                add_job(2, _ptr(part2), part2.shape[0], dpad * hid, (dout, hid), prm[2])
             if ctx.needs_input_grad[4]:
                 add_job(3, vbase + 1 * vs * 4, nblk, 4 * vs, (dout,), prm[3])
             if ctx.has_ln and ctx.needs_input_grad[5]:
@@ -817,8 +898,7 @@ class ChunkedMLPFunction(torch.autograd.Function):
                 p.inv_deg = _ptr(geom.inv_deg)
             p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
             dz1 = torch.empty((B * rows, hid), device=dev, dtype=torch.float32)
-            dz2 = torch.empty((B * rows, dout), device=dev, dtype=torch.float32)
-            p.dz1, p.dz2 = _ptr(dz1), _ptr(dz2)
+            p.dz1 = _ptr(dz1)
             for k in range(nsrc):
                 if not need_src[k]:
                     p.dmode[k] = 0
@@ -833,6 +913,7 @@ class ChunkedMLPFunction(torch.autograd.Function):
                         tc = torch.empty((B, rows, widths[k]), device=dev, dtype=torch.float32)
                         tmp_chunks[k].append(tc)
                         p.dsrc[k], p.dsrc_bstride[k] = _ptr(tc), rows * widths[k]
+            dz2, dpad = _alloc_dz2(lib, p, B * rows, dout, dev)
             nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
             if nwp > 0:
                 wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
@@ -898,7 +979,8 @@ def _chunk_weight_grads(lib, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, ve
         return partials
 
     part1 = wgrad(dz1, hid, src_list, kin, 0) if needs[0] else None
-    part2 = wgrad(dz2, dout, [(z1.data_ptr(), rows * hid, hid, None)], hid, L.F_SILU_B) if needs[2] else None
+    dpad = dz2.shape[1]   # dout, or 32-padded (zero columns) for a ragged output width: the first dout rows of the partials count
+    part2 = wgrad(dz2, dpad, [(z1.data_ptr(), rows * hid, hid, None)], hid, L.F_SILU_B) if needs[2] else None
     results = [None] * 6
     jobs = L.ReduceJobs()
     keep = []
@@ -922,7 +1004,7 @@ def _chunk_weight_grads(lib, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, ve
     if needs[1]:
         add_job(1, vbase + 0 * vs * 4, nblk, 4 * vs, (hid,), params[1])
     if part2 is not None:
-        add_job(2, _ptr(part2), part2.shape[0], dout * hid, (dout, hid), params[2])
+        add_job(2, _ptr(part2), part2.shape[0], dpad * hid, (dout, hid), params[2])
     if needs[3]:
         add_job(3, vbase + 1 * vs * 4, nblk, 4 * vs, (dout,), params[3])
     if has_ln and needs[4]:
@@ -934,6 +1016,23 @@ def _chunk_weight_grads(lib, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, ve
     if GRAD_LISTENER is not None:
         GRAD_LISTENER.note_done([q for q, nd in zip(params, needs) if nd and q is not None and is_direct(q, q.shape)])
     return results
+
+
+def _alloc_dz2(lib, p, nrows, dout, dev):
+    """The dz2 buffer of a backward launch (the row gradients of the second Linear, read by its weight gradient) with the row
+    stride the kernel chosen for ``p`` writes: dout, or 32-padded with zero columns for a ragged output width on the
+    split-bf16 kernels (``nlam_mlp_bwd_dz2_ld``).  Call once every field of ``p`` that decides the kernel is set."""
+    ld = int(lib.nlam_mlp_bwd_dz2_ld(C.byref(p)))
+    dpad = ld if ld > 0 else dout
+    dz2 = torch.empty((nrows, dpad), device=dev, dtype=torch.float32)
+    p.dz2, p.dz2_ld = _ptr(dz2), ld
+    return dz2, dpad
+
+
+def _set_bwd_pack(p, pack):
+    """Hand a narrow backward launch the weight image packed for this step (None / stale: the kernel stages its weights itself)."""
+    if pack is not None and PACKER is not None and pack.packed_step == PACKER.step_id:
+        p.wpack, p.wpack_floats = pack.bwd.data_ptr(), pack.bwd.numel()
 
 
 # Leaf MLPs of <= 3 input columns accumulate their weight gradients inside the grouped backward kernel (NLAM_F_LEAF_WGRAD)
@@ -961,7 +1060,7 @@ class GroupedMLPFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[1 : 1 + 6 * n])
         dev = xs[0].device
         arr = (L.MlpFwd * n)()
-        outs, saved, keep = [], [], []
+        outs, saved, keep, packs = [], [], [], []
         # leaf MLPs of <= 3 input columns: the grouped backward accumulates the weight gradients itself and recomputes the
         # pre-activation from the input (three FMAs per element), so the forward does not save z1 (a third of its bytes)
         lw = (n > 1 and FUSED_LEAF_WGRAD and (mm_flags >> 8) & 3 != 0
@@ -982,6 +1081,12 @@ class GroupedMLPFunction(torch.autograd.Function):
             keep.extend((t, W1c, b1c, W2c, b2c))
             p.W1, p.b1, p.W2, p.b2, p.ln_w, p.ln_b = _ptr(W1c), _ptr(b1c), _ptr(W2c), _ptr(b2c), _ptr(ln_w), _ptr(ln_b)
             p.eps, p.hid, p.dout, p.flags = 1e-5, hid, dout, mm_flags
+            pack = None
+            if PACKER is not None and max(hid, dout, kin) <= 64:
+                pack = PACKER.get(W1c, W2c, [kin], hid, dout, False, 0, mm_flags)
+                if pack is not None:
+                    p.wpack, p.wpack_floats = pack.fwd.data_ptr(), pack.fwd.numel()
+            packs.append(pack)
             out = torch.empty((B, rows, dout), device=dev, dtype=torch.float32)
             p.out, p.out_bstride = _ptr(out), rows * dout
             z1 = xhat = rstd = None
@@ -1013,11 +1118,13 @@ class GroupedMLPFunction(torch.autograd.Function):
                     wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
                     keep.append(wpack)
                     p.wpack, p.wpack_floats = _ptr(wpack), nwp
+                    packs[k] = None
                 L.check(lib.nlam_mlp_fwd(C.byref(p), _stream()), "nlam_mlp_fwd (group member)")
         else:
             L.check(rc, "nlam_mlp_fwd_group")
         if need_grad:
             ctx.lw = lw
+            ctx.packs = packs
             ctx.n, ctx.params, ctx.saved, ctx.mm_flags = n, params, saved, mm_flags
             ctx.set_materialize_grads(False)
             if GRAD_LISTENER is not None:
@@ -1053,9 +1160,10 @@ class GroupedMLPFunction(torch.autograd.Function):
             p.hid, p.dout, p.flags = hid, dout, ctx.mm_flags
             p.g_out, p.out_bstride = _ptr(g), rows * dout
             p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
+            _set_bwd_pack(p, ctx.packs[k])
             dz1 = torch.empty((B * rows, hid), device=dev, dtype=torch.float32)
-            dz2 = torch.empty((B * rows, dout), device=dev, dtype=torch.float32)
-            p.dz1, p.dz2 = _ptr(dz1), _ptr(dz2)
+            p.dz1 = _ptr(dz1)
+            dz2, _ = _alloc_dz2(lib, p, B * rows, dout, dev)
             tiles[i] = p.ntiles * B
             work.append([k, g, dz1, dz2, None, 0, None])
         blocks = (C.c_int32 * m)()
@@ -1146,6 +1254,7 @@ def _grouped_backward_fused(ctx, g_outs, live, grads):
         p.hid, p.dout, p.flags = hid, dout, ctx.mm_flags | L.F_LEAF_WGRAD
         p.g_out, p.out_bstride = _ptr(g), rows * dout
         p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
+        _set_bwd_pack(p, ctx.packs[k])
         b1c = params[k][1].contiguous()
         p.b1 = _ptr(b1c)
         nblk = int(blocks[i])

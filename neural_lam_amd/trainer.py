@@ -91,14 +91,21 @@ class GradBuckets:
         self.pending = [0] * len(self.bounds)
         self.uses = {}        # parameter index -> fused-MLP forwards that used it and have not yet back-propagated
         self.done = set()
-        self.done_via = {}    # parameter index -> "direct" | "hook": which mechanism reported it complete this step
         self.handles = []
         self.launched = []    # bucket indices in launch order (tests read it)
         self.enabled = True   # False while a HIP graph owns the step (collectives run after the replay)
         self.join_streams = lambda: None   # set by the trainer: make the launching stream wait for every producer stream
+        # Completion signal of a parameter's gradient.  With hooks registered (world > 1) it is ALWAYS autograd's
+        # post-accumulate hook: the AccumulateGrad node of a parameter runs once per backward, after every backward node that
+        # feeds it has been issued -- including a fused MLP that accumulated the gradient itself and returned None for it
+        # (the hook fires for an undefined gradient too) and including any plain torch op sharing the parameter.  The
+        # fused ops' own note_done reports are then ignored: a parameter fed by both mechanisms would otherwise be marked
+        # complete by whichever finishes first, and the late contribution would land after the bucket's collective started.
+        self.hooks_armed = False
         if self.world > 1:
             for i, p in enumerate(fp.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
+            self.hooks_armed = True
 
     def _reduce_slice(self, s, e):
         """Launch the all-reduce of grad[s:e]; in a reduced communication dtype the sum happens on a cast copy that
@@ -129,21 +136,10 @@ class GradBuckets:
             view.copy_(low)
         self._comm_tmp = []
 
-    def _param_done(self, i, via="hook"):
+    def _param_done(self, i):
         if i in self.done:
-            # A parameter is reported complete by exactly ONE mechanism per step: the fused-MLP backward that accumulates
-            # its gradient itself (note_done, after its last counted use) or autograd's AccumulateGrad hook.  A parameter
-            # fed by both (a weight shared between a fused MLP and a plain torch op) would be marked done by whichever
-            # finishes first, and the other contribution would land after the bucket's collective has started: wrong
-            # gradients without an error.  Refuse instead.
-            if self.done_via.get(i) != via:
-                raise RuntimeError(
-                    f"parameter #{i} ({tuple(self.fp.params[i].shape)}) receives gradient both from a fused MLP's direct "
-                    "accumulation and through autograd in one step: early bucket all-reduce cannot order the two; "
-                    "do not share this parameter with plain torch ops, or run the HIP-graph step (one collective after the replay)")
             return
         self.done.add(i)
-        self.done_via[i] = via
         b = self.bucket_of[i]
         self.pending[b] -= 1
         if self.pending[b] == 0:
@@ -177,12 +173,12 @@ class GradBuckets:
                 continue
             left = self.uses.get(i, 1) - 1
             self.uses[i] = left
-            if left <= 0:   # the last AR step's contribution is in: the gradient is complete
-                self._param_done(i, via="direct")
+            if left <= 0 and not self.hooks_armed:   # the last AR step's contribution is in: the gradient is complete
+                self._param_done(i)
 
     def begin_step(self):
         self.pending = [len(mem) for (_, _, mem) in self.bounds]
-        self.uses, self.done, self.done_via = {}, set(), {}
+        self.uses, self.done = {}, set()
         self.handles, self.launched = [], []
 
     def finish_step(self):
@@ -256,6 +252,7 @@ class Trainer:
                 cur.wait_stream(st)
 
     _main_stream = None
+    _packer = None           # ops.WeightPacker: weight images of the narrow fused kernels, rewritten once per step
     _unit = None
     _module_kwargs = {}      # extra keyword arguments of the module call inside the captured step
     _pre_standardize = False
@@ -272,7 +269,9 @@ class Trainer:
             loss.backward()
             return loss.detach()
         self._main_stream = torch.cuda.current_stream()
-        with ops.direct_param_grads(self.buckets, early_leaf=self.early_leaf_backward):
+        if self._packer is None:
+            self._packer = ops.WeightPacker()
+        with ops.direct_param_grads(self.buckets, early_leaf=self.early_leaf_backward, packer=self._packer):
             out = self.module(*batch, **self._module_kwargs)
             loss = out[-1] if isinstance(out, tuple) else out
             ov = ops.OVERLAP if self.overlap_wgrad else None

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()  # raises if the .so is missing
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nlam_abi_version() == L.ABI_VERSION == 3
+    assert lib.nlam_abi_version() == L.ABI_VERSION == 4
     assert lib.nlam_max_width() >= 64
     assert lib.nlam_num_blocks(1) == 1 and lib.nlam_num_blocks(10**6) == 256
     # tuning knob: known key accepted (and restored), unknown key / negative value rejected
@@ -44,10 +44,10 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "nlam_hip.h"\n'
-        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nlam_src_t), sizeof(nlam_mlp_fwd_t),'
+        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nlam_src_t), sizeof(nlam_mlp_fwd_t),'
         " sizeof(nlam_mlp_bwd_t), sizeof(nlam_wgrad_t), offsetof(nlam_mlp_fwd_t, rstd),"
         " offsetof(nlam_mlp_bwd_t, vec_partials), offsetof(nlam_wgrad_t, partials), sizeof(nlam_window_t),"
-        " offsetof(nlam_window_t, n_times), offsetof(nlam_window_t, ar_steps)); return 0;}\n"
+        " offsetof(nlam_window_t, n_times), offsetof(nlam_window_t, ar_steps), sizeof(nlam_pack_job_t), offsetof(nlam_pack_job_t, flags)); return 0;}\n"
     )
     exe = tmp_path / "sz"
     subprocess.run(["gcc", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)], check=True)
@@ -56,6 +56,7 @@ def test_ctypes_structs_match_c_layout(tmp_path):
         C.sizeof(L.Src), C.sizeof(L.MlpFwd), C.sizeof(L.MlpBwd), C.sizeof(L.Wgrad),
         L.MlpFwd.rstd.offset, L.MlpBwd.vec_partials.offset, L.Wgrad.partials.offset,
         C.sizeof(L.Window), L.Window.n_times.offset, L.Window.ar_steps.offset,
+        C.sizeof(L.PackJob), L.PackJob.flags.offset,
     ]
 
 

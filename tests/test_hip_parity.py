@@ -262,6 +262,9 @@ def test_wide_layers_on_awkward_graphs(dev, cls_name, d, ns, nr, e, wide_family)
     (3, 64, 64, True), (56, 64, 64, True), (64, 64, 17, False), (2, 16, 16, True), (7, 12, 5, False),
     (56, 256, 256, True), (256, 256, 17, False), (3, 128, 128, True), (128, 64, 64, True), (130, 96, 40, True),
     (512, 512, 34, False), (18, 512, 512, True),
+    # output widths that are not whole 32-column blocks on the split-bf16 kernels (output_map: no LayerNorm): zero-padded W2,
+    # dword output stores, 32-padded dz2 for the weight gradient; with a ragged input too; and the shapes that must stay generic
+    (32, 32, 5, False), (64, 32, 17, False), (56, 64, 17, False), (64, 64, 31, False), (32, 64, 33, False),
 ])
 def test_plain_mlp_matches_oracle(dev, kin, hid, dout, ln, wide_family):
     from oracle import gnn_layers as og
@@ -281,6 +284,42 @@ def test_plain_mlp_matches_oracle(dev, kin, hid, dout, ln, wide_family):
     assert rel_err(x2.grad.cpu(), x1.grad) < TOL
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         assert rel_err(p.grad.cpu(), q.grad) < TOL, k
+
+
+def test_prepacked_weights_give_identical_steps(dev, tmp_path):
+    """``nlam_mlp_pack``: under a trainer the narrow kernels fetch their weights as images packed once per step instead of
+    splitting the fp32 matrices in every workgroup.  Same bf16 terms, same LDS layout -> the step must be BIT-identical with
+    the packer on and off (loss, every gradient, the weights after AdamW), eager and captured, over a rollout of two steps."""
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import models as hm
+    from neural_lam_amd import ops
+    from neural_lam_amd.datastore import SyntheticDatastore
+    from neural_lam_amd.trainer import Trainer
+
+    ds = SyntheticDatastore(30, 27, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+    ext = ds.get_xy_extent("state")
+    graph = G.normalise_graph(G.create_regular_grid_graph(ds.get_xy("state")), max(ext[1] - ext[0], ext[3] - ext[2]))
+    N = ds.num_grid_points
+    g = torch.Generator().manual_seed(5)
+    batch = tuple(t.to(dev) for t in (torch.randn(2, 2, N, 5, generator=g), torch.randn(2, 2, N, 5, generator=g), torch.randn(2, 2, N, 6, generator=g)))
+
+    def run(packed, use_graph):
+        torch.manual_seed(11)
+        fc = hm.ARForecaster(hm.GraphLAM(ds, graph=graph, hidden_dim=64, processor_layers=2), ds)
+        tr = Trainer(hm.ForecasterStep(fc, ds).to(dev), lr=1e-3, use_graph=use_graph)
+        tr._packer = ops.WeightPacker()
+        tr._packer.enabled = packed
+        losses = [float(tr.step(*batch)) for _ in range(4)]
+        torch.cuda.synchronize()
+        return losses, tr.fp.grad.clone(), tr.fp.flat.clone(), tr._packer
+
+    for use_graph in (False, True):
+        l0, g0, w0, _ = run(False, use_graph)
+        l1, g1, w1, pk = run(True, use_graph)
+        assert pk.table is not None and len(pk.table_entries) >= 10          # edge / node / grid MLPs + the embedders registered
+        assert all(e.packed_step == pk.step_id for e in pk.table_entries)       # ... and were rewritten for the last step
+        assert l0 == l1, (use_graph, l0, l1)
+        assert torch.equal(g0, g1) and torch.equal(w0, w1), use_graph
 
 
 # ---------------------------------------------------------------------------
