@@ -54,6 +54,7 @@ extern "C" {
 
 #define NLAM_ABI_VERSION 4
 #define NLAM_MAX_SRC 3
+#define NLAM_MAX_CAT 6
 
 #define NLAM_EINVAL (-1)   /* inconsistent sizes / null pointers        */
 #define NLAM_EUNSUP (-2)   /* width outside what this build instantiates */
@@ -137,6 +138,20 @@ typedef struct {
     /* ---- scratch for the wide kernels (hid or dout or a source wider than 64) ---- */
     float* wpack;          /* >= nlam_mlp_fwd_wpack_floats(p) floats, or NULL when that is 0 */
     int64_t wpack_floats;  /* capacity of wpack */
+    /* ---- optional: src[0] as a row-wise CONCATENATION of ncat pieces ----
+     * The torch.cat of the grid input features in front of grid_embedder (step_predictors/graph/base.py:275-286:
+     * prev_state | prev_prev_state | forcing | static features) folded into the MLP's first load instead of a launch of its
+     * own that materialises (batch, rows, 56).  With ncat > 0: nsrc == 1, src[0].ptr is ignored, src[0].idx must be NULL,
+     * src[0].width = sum of cat_width (<= 64); piece k holds rows of cat_width[k] floats, cat_bstride[k] floats apart between
+     * batch items (0 = shared: expand_to_batch).  cat_out (optional, (batch, rows, src[0].width)): the kernel also writes the
+     * concatenated rows -- what the weight gradient and the backward pass read as the MLP's input.  Served by the
+     * split-bf16 narrow kernels (NLAM_EUNSUP otherwise: concatenate with nlam_concat and launch without pieces). */
+    int32_t ncat;
+    int32_t _pad3;
+    const float* cat_ptr[NLAM_MAX_CAT];
+    int64_t cat_bstride[NLAM_MAX_CAT];
+    int32_t cat_width[NLAM_MAX_CAT];
+    float* cat_out;
 } nlam_mlp_fwd_t;
 
 typedef struct {
@@ -394,7 +409,6 @@ int32_t nlam_step_tail_bwd(const float* g_pred, const float* gloss, const float*
 /* Row-wise concatenation of up to NLAM_MAX_CAT sources into out (rows, sum of widths): the torch.cat of the grid input
  * features (prev_state, prev_prev_state, forcing, static features; step_predictors/graph/base.py:275-283).  A source
  * with bstride 0 is shared by all batch items (expand_to_batch, step_predictors/base.py:122-139). */
-#define NLAM_MAX_CAT 6
 typedef struct {
     const float* ptr[NLAM_MAX_CAT];
     int64_t bstride[NLAM_MAX_CAT];   /* floats between batch items of the source; 0 = shared */

@@ -15,6 +15,7 @@ HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["NLAM_LIB"]) if os.environ.get("NLAM_LIB") else HERE / "libnlam_hip.so"
 
 NLAM_MAX_SRC = 3
+NLAM_MAX_CAT = 6
 NLAM_MAX_GROUP = 8
 F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD, F_LEAF_WGRAD = 1, 2, 4, 8, 16, 32
 TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning keys (include/nlam_hip.h)
@@ -101,6 +102,12 @@ class MlpFwd(C.Structure):
         ("rstd", C.c_void_p),
         ("wpack", C.c_void_p),
         ("wpack_floats", C.c_int64),
+        ("ncat", C.c_int32),
+        ("_pad3", C.c_int32),
+        ("cat_ptr", C.c_void_p * NLAM_MAX_CAT),
+        ("cat_bstride", C.c_int64 * NLAM_MAX_CAT),
+        ("cat_width", C.c_int32 * NLAM_MAX_CAT),
+        ("cat_out", C.c_void_p),
     ]
 
 

@@ -914,7 +914,9 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
 // The kernel body takes its workgroup index and grid size as arguments: the plain launch passes blockIdx.x / gridDim.x,
 // the GROUPED launch (nlam_mlp_fwd_group: several independent same-shape MLPs in one grid, each workgroup bound to one
 // member -- the embedders of the static graph features) passes the member-local ones.
-template <int HB, int OB, int NS, bool RAG, bool RES, bool PRE = false>
+// CAT (with RAG): the single source is a concatenation of pieces (p.ncat > 0); its own instantiation, because the piece
+// descriptors are ~35 more scalar registers the other ragged launches (embedders, output_map) should not carry
+template <int HB, int OB, int NS, bool RAG, bool RES, bool PRE = false, bool CAT = false>
 __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const int wg_id, const int wg_count) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int DPH = HB * 32, OP = OB * 32;
@@ -986,6 +988,8 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
 #pragma unroll
         for (int s = 0; s < NLAM_MAX_SRC; ++s)
             rp[s] = s < p.nsrc ? p.src[s].ptr + (long)b * p.src[s].bstride + (long)ridx[s] * p.src[s].width : nullptr;
+        if constexpr (CAT)   // concatenated pieces: no single row pointer -- pack (batch, row) for load_unit
+            rp[0] = reinterpret_cast<const float*>(((uintptr_t)(unsigned)b << 32) | (uintptr_t)(unsigned)ridx[0]);
     };
     auto load_idx = [&](const TileInfo& t, int (&ridx)[NLAM_MAX_SRC]) {
         const int pr = clamp_row(t);
@@ -999,7 +1003,39 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
                                                     // when 32 registers hold the residual rows: four spilled inside the tile loop
     constexpr int kTop = MAXU - kPre > 0 ? MAXU - kPre : 1;
     f32x4 xp[kPre][4];        // loop-carried: rows of the next tile
+    // RAG with p.ncat > 0: the single source is the row-wise concatenation of up to NLAM_MAX_CAT pieces (the torch.cat of the
+    // grid input features, graph/base.py:275-283, folded into this load): rp[0] then carries (row index, batch) instead of
+    // a row pointer -- see row_ptrs -- and every element picks its piece by column
     auto load_unit = [&](const float* const (&rp)[NLAM_MAX_SRC], int u, f32x4(&xu)[4]) {
+        if constexpr (CAT) {
+            // at most kCatPieces pieces (the launcher checks); an unused trailing piece has width 0, i.e. starts at the total width
+            // and is never selected for a column below it
+            constexpr int kCatPieces = 4;
+            const long crow = (long)(reinterpret_cast<uintptr_t>(rp[0]) & 0xffffffffu);
+            const long cb = (long)(reinterpret_cast<uintptr_t>(rp[0]) >> 32);
+            const int w0 = p.cat_width[0], w1 = p.cat_width[1], w2 = p.cat_width[2], w3 = p.cat_width[3];
+            const int s1 = w0, s2 = w0 + w1, s3 = w0 + w1 + w2;
+            // element pointers: q_k[col] is column `col` of the concatenated row
+            const float* q0 = p.cat_ptr[0] + cb * p.cat_bstride[0] + crow * w0;
+            const float* q1 = p.cat_ptr[1] + cb * p.cat_bstride[1] + crow * w1 - s1;
+            const float* q2 = p.cat_ptr[2] + cb * p.cat_bstride[2] + crow * w2 - s2;
+            const float* q3 = p.cat_ptr[3] + cb * p.cat_bstride[3] + crow * w3 - s3;
+            const int w = p.src[0].width, c0 = ucol[u] + 8 * hi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cq = c0 + (q & 1) * 4 + (q >> 1) * 16;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int col = min(cq + c, w - 1);   // clamped: the load is unconditional (a predicated load is a branch + a full wait per element)
+                    const float* src = col >= s3 ? q3 : (col >= s2 ? q2 : (col >= s1 ? q1 : q0));
+                    const float v = src[col];
+                    xu[q][c] = cq + c < w ? v : 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one quad's compare masks at a time (all 48 at once spill the scalar file)
+            }
+            (void)kCatPieces;
+            return;
+        }
         const float* row = usrc[u] == 0 ? rp[0] : (usrc[u] == 1 ? rp[1] : rp[2]);
         const int w = usrc[u] == 0 ? p.src[0].width : (usrc[u] == 1 ? p.src[1].width : p.src[2].width);
         const int c0 = ucol[u] + 8 * hi;
@@ -1008,12 +1044,15 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
             xu[1] = *reinterpret_cast<const f32x4*>(row + c0 + 4);
             xu[2] = *reinterpret_cast<const f32x4*>(row + c0 + 16);
             xu[3] = *reinterpret_cast<const f32x4*>(row + c0 + 20);
-        } else {               // ragged source: element-wise, zero past its width
+        } else {               // ragged source: element-wise, zero past its width (clamped column: unconditional loads)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cq = c0 + (q & 1) * 4 + (q >> 1) * 16;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) xu[q][c] = cq + c < w ? row[cq + c] : 0.f;
+                for (int c = 0; c < 4; ++c) {
+                    const float v = row[min(cq + c, w - 1)];
+                    xu[q][c] = cq + c < w ? v : 0.f;
+                }
             }
         }
     };
@@ -1126,6 +1165,24 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
             }
         }
         NLAM_T_MARK(2)
+        if (CAT && p.cat_out != nullptr) {
+            // the concatenated input rows, for the weight gradient / backward: unit by unit through the staging block, whole
+            // 16-byte pieces per lane (the row width is a multiple of 4: checked by the launcher)
+            float* cbase = p.cat_out + ((size_t)b * p.rows + tl.row0) * p.src[0].width;
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) {
+                if (u < nunits) {
+                    const f32x4(&x)[4] = xp[u < kPre ? u : 0];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * hi + (q & 1) * 4 + (q >> 1) * 16]) = x[q];
+                    wave_lds_sync();
+                    const int wb = min(32, p.src[0].width - 32 * u);
+                    block_rows_out(stg, tl.nrows, wb, lane, [&](int r) { return cbase + (size_t)r * p.src[0].width + 32 * u; });
+                    wave_lds_sync();
+                }
+            }
+        }
         // residual rows (C-layout chunks 8t + 4hi differ from the unit layout 8hi + ..: re-read below, ahead of the stores)
         const bool add0 = RES && (p.flags & NLAM_F_ADD_SRC0) != 0 && p.out != nullptr;
         const bool add1 = RES && (p.flags & NLAM_F_ADD_SRC1) != 0;
@@ -1306,9 +1363,9 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
     NLAM_T_FLUSH(t_ntiles_)
 }
 
-template <int HB, int OB, int NS, bool RAG, bool RES, bool PRE = false>
+template <int HB, int OB, int NS, bool RAG, bool RES, bool PRE = false, bool CAT = false>
 __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_fwd_t p) {
-    mlp_fwd_bf_body<HB, OB, NS, RAG, RES, PRE>(p, (int)blockIdx.x, (int)gridDim.x);
+    mlp_fwd_bf_body<HB, OB, NS, RAG, RES, PRE, CAT>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 struct fwd_group_t {
@@ -3724,6 +3781,19 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
     if ((p->flags & NLAM_F_MEAN) && p->inv_deg == nullptr) return NLAM_EINVAL;
     if ((p->flags & NLAM_F_ADD_SRC0) && p->src[0].width != p->dout) return NLAM_EINVAL;
     if ((p->flags & NLAM_F_ADD_SRC1) && (p->nsrc < 2 || p->src[1].width != p->dout)) return NLAM_EINVAL;
+    if (p->ncat != 0) {   // src[0] = concatenation of pieces: one un-gathered source of <= 64 columns, whole float4s per row
+        if (p->ncat < 0 || p->ncat > NLAM_MAX_CAT || p->nsrc != 1 || p->src[0].idx != nullptr) return NLAM_EINVAL;
+        int wsum = 0;
+        for (int k = 0; k < p->ncat; ++k) {
+            if (p->cat_ptr[k] == nullptr || p->cat_width[k] < 1) return NLAM_EINVAL;
+            wsum += p->cat_width[k];
+        }
+        if (wsum != p->src[0].width) return NLAM_EINVAL;
+        if (fwd_is_wide(p) || wsum % 4 != 0 || (p->flags & (NLAM_F_ADD_SRC0 | NLAM_F_ADD_SRC1 | NLAM_F_PRE_ADD)) != 0 || p->tiles != nullptr)
+            return NLAM_EUNSUP;
+        if (p->ncat > 4) return NLAM_EUNSUP;   // the kernel resolves a column among four pieces
+        if (p->rows > 0 && p->batch > 0 && ((long)p->rows >= (1L << 31) || p->batch >= (1 << 30))) return NLAM_EUNSUP;
+    }
     if (p->rows == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
     if (fwd_is_wide(p)) {
@@ -3855,6 +3925,7 @@ int32_t nlam_detail::fwd_narrow(const nlam_mlp_fwd_t* p, hipStream_t stream) {
         ragged = ragged || (p->src[s].width % 32 != 0);
     }
     if (ragged && p->nsrc != 1) w64 = false;   // ragged inputs are covered for single-source MLPs (embedders, grid MLPs)
+    if (p->ncat > 0) ragged = true;            // concatenated pieces are read by the ragged-input instantiation
     const bool resid = ((p->flags & NLAM_F_ADD_SRC0) != 0 && p->out != nullptr) || (p->flags & NLAM_F_ADD_SRC1) != 0;
     if (ragged && resid) w64 = false;
     if ((p->flags & (NLAM_F_ADD_SRC0 | NLAM_F_ADD_SRC1)) != 0) {   // residual rows are read as whole 16-B chunks
@@ -3865,6 +3936,31 @@ int32_t nlam_detail::fwd_narrow(const nlam_mlp_fwd_t* p, hipStream_t stream) {
     int ns = 0;
     if (fast_out && w64) ns = (int)((p->flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
     if (ns > 3) return NLAM_EINVAL;
+    if (p->ncat > 0) {   // concatenated pieces: the CAT instantiation of the ragged-input split-bf16 kernel, square MLPs
+        if (ns == 0 || HB != OB || HB > 2) return NLAM_EUNSUP;
+        nlam_mlp_fwd_t pc = *p;   // unused piece slots: width 0 (they start at the total width and are never selected)
+        for (int k = p->ncat; k < NLAM_MAX_CAT; ++k) {
+            pc.cat_ptr[k] = p->cat_ptr[0];
+            pc.cat_bstride[k] = 0;
+            pc.cat_width[k] = 0;
+        }
+#define NLAM_LAUNCH_FWDCAT1(HB_, NS_)                                                                                                    \
+    do {                                                                                                                                \
+        const size_t lds = fwd_lds_bytes(p, HB_, HB_, NS_);                                                                             \
+        int rc = set_lds(mlp_fwd_bf_kernel<HB_, HB_, NS_, true, false, false, true>, lds);                                              \
+        if (rc != 0) return rc;                                                                                                         \
+        hipLaunchKernelGGL((mlp_fwd_bf_kernel<HB_, HB_, NS_, true, false, false, true>), dim3(blocks), dim3(nwaves * 64), lds, stream, pc); \
+    } while (0)
+#define NLAM_LAUNCH_FWDCAT(HB_)                       \
+    do {                                              \
+        if (ns == 3) NLAM_LAUNCH_FWDCAT1(HB_, 3);      \
+        else if (ns == 2) NLAM_LAUNCH_FWDCAT1(HB_, 2); \
+        else NLAM_LAUNCH_FWDCAT1(HB_, 1);              \
+    } while (0)
+        if (HB == 1) NLAM_LAUNCH_FWDCAT(1);
+        else NLAM_LAUNCH_FWDCAT(2);
+        return (int32_t)hipGetLastError();
+    }
     if (p->flags & NLAM_F_PRE_ADD) {   // factorised edge MLP: split-bf16 modes, whole 32-column units, addends of width hid
         bool ok = ns > 0 && !ragged && p->nsrc >= 2 && (p->flags & NLAM_F_ADD_SRC1) == 0 && HB == OB;
         for (int s = 1; s < p->nsrc; ++s) ok = ok && p->src[s].width == p->hid;

@@ -49,6 +49,10 @@ def inverse_sigmoid(x):
 
 # nlam_affine_mix for the elementwise tail of a step (A/B on one box: +3 % forecast rate, +1 % training rate)
 FUSED_STATE_UPDATE = True
+# the torch.cat of the grid input features folded into grid_embedder (ops.CatMLPFunction); NLAM_FOLD_CAT=0 for A/B runs
+import os as _os
+
+FOLD_INPUT_CAT = _os.environ.get("NLAM_FOLD_CAT", "1") == "1"
 
 class BufferList(nn.Module):
     """utils/buffer_list.py:11: list of non-persistent buffers."""
@@ -287,14 +291,22 @@ class BaseGraphModel(StepPredictor):
     def forward(self, prev_state, prev_prev_state, forcing, raw_delta: bool = False):
         B = prev_state.shape[0]
         feats = (prev_state, prev_prev_state, forcing, self.expand_to_batch(self.grid_static_features, B))
-        if FUSED_STATE_UPDATE and prev_state.is_cuda and all(t.dtype == torch.float32 and t.dim() == 3 for t in feats):
-            from .ops import ConcatFunction
-
-            grid_features = ConcatFunction.apply(*feats)   # graph/base.py:275-283 in one launch; the static features are read un-expanded
-        else:
-            grid_features = torch.cat(feats, dim=-1)
         st = self._static if self._static is not None else self.compute_static_embeddings()
-        grid_emb = self.grid_embedder(grid_features)  # (B, N_grid, d)
+        fused_ok = FUSED_STATE_UPDATE and prev_state.is_cuda and all(t.dtype == torch.float32 and t.dim() == 3 for t in feats)
+        if fused_ok and FOLD_INPUT_CAT and self.grid_embedder.fully_fused and self.grid_input_dim <= 64 and self.grid_input_dim % 4 == 0:
+            from .ops import CatMLPFunction
+
+            # graph/base.py:275-286: the torch.cat of the input features folded into grid_embedder's first load (the (B, N, 56)
+            # tensor is only written as a by-product for the backward pass; the static features are read un-expanded)
+            grid_emb = CatMLPFunction.apply(*self.grid_embedder.params(), *feats)
+        else:
+            if fused_ok:
+                from .ops import ConcatFunction
+
+                grid_features = ConcatFunction.apply(*feats)   # graph/base.py:275-283 in one launch; the static features are read un-expanded
+            else:
+                grid_features = torch.cat(feats, dim=-1)
+            grid_emb = self.grid_embedder(grid_features)  # (B, N_grid, d)
         mesh_rep = self.g2m_gnn(
             grid_emb, self.expand_to_batch(st["mesh"], B), self.expand_to_batch(st["g2m"], B)
         )

@@ -495,229 +495,235 @@ class FusedMLPFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out, g_aggr):
-        lib = L.load()
-        geom: MlpGeometry = ctx.geom
-        W1, W2, ln_w, z1, xhat, rstd, *bases = ctx.saved_tensors
-        B, rows, ntiles = ctx.B, ctx.rows, ctx.ntiles
-        hid, kin = W1.shape
-        dout = W2.shape[0]
-        dev = W1.device
-        nsrc = geom.nsrc
-        widths = [s[-1] for s in ctx.src_shapes]
-        n_fixed = 7
-        if g_out is None and g_aggr is None:
-            return (None,) * (n_fixed + nsrc)
-        if g_out is not None:
-            g_out = g_out.reshape(B, -1, dout).contiguous()
-        if g_aggr is not None:
-            g_aggr = g_aggr.reshape(B, -1, dout).contiguous()
+        return _fused_mlp_backward(ctx, g_out, g_aggr, ctx.needs_input_grad)
 
-        p = L.MlpBwd()
-        for k in range(nsrc):
-            b_, bstride = ctx.binfo[k]
-            _fill_src(p.src[k], bases[k], bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k])
-        p.nsrc, p.batch, p.rows, p.ntiles = nsrc, B, rows, ntiles
-        p.tiles = _ptr(geom.tiles)
-        p.W1, p.W2, p.ln_w = _ptr(W1), _ptr(W2), _ptr(ln_w) if ctx.has_ln else None
-        p.hid, p.dout, p.flags, p.nseg_total = hid, dout, geom.flags | ctx.mm_flags, geom.nseg_total
-        pre = bool(geom.flags & L.F_PRE_ADD)
-        p.ldw1 = kin if pre else 0
-        if g_out is not None:
-            p.g_out, p.out_idx, p.out_bstride = _ptr(g_out), _ptr(geom.out_idx), g_out.shape[1] * dout
-        if g_aggr is not None:
-            p.g_aggr, p.seg_of_row = _ptr(g_aggr), _ptr(geom.seg_of_row)
-        p.rowptr, p.inv_deg = _ptr(geom.rowptr), _ptr(geom.inv_deg)
-        p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
-        dz1 = torch.empty((B * rows, hid), device=dev, dtype=torch.float32)
-        p.dz1 = _ptr(dz1)
-        dsrc = [None] * nsrc
-        tmp2 = [None] * nsrc
-        for k in range(nsrc):
-            if not ctx.needs_input_grad[n_fixed + k]:
-                p.dmode[k] = 0
-                continue
-            mode = geom.dmode[k]
-            w = widths[k]
-            n_src_rows = ctx.src_shapes[k][-2]
-            p.dmode[k] = mode
-            if pre and k > 0 and mode == 2:
-                p.dmode[k] = 0   # gradient of a sender-gathered addend: a CSC segment sum over the dz1 rows, below
-                continue
-            if mode == 1:
-                # rows scattered through the (unique, covering) gather index, or identity
-                dsrc[k] = torch.empty((B, n_src_rows, w), device=dev, dtype=torch.float32)
-                p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), n_src_rows * w
-            elif mode == 2:
-                tmp2[k] = torch.empty((B, rows, w), device=dev, dtype=torch.float32)
-                p.dsrc[k], p.dsrc_bstride[k] = _ptr(tmp2[k]), rows * w
-            elif mode == 3:
-                alloc = torch.zeros if geom.has_split else torch.empty
-                dsrc[k] = alloc((B, geom.nseg_total, w), device=dev, dtype=torch.float32)
-                p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), geom.nseg_total * w
-        dz2, dpad = _alloc_dz2(lib, p, B * rows, dout, dev)   # (rows, dout); 32-padded columns for a ragged output width (output_map)
-        nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
-        wpack = None
-        if nwp > 0:
-            wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
-            p.wpack, p.wpack_floats = _ptr(wpack), nwp
-        elif ctx.pack is not None and PACKER is not None and ctx.pack.packed_step == PACKER.step_id:
-            p.wpack, p.wpack_floats = ctx.pack.bwd.data_ptr(), ctx.pack.bwd.numel()
-        nblk = lib.nlam_mlp_bwd_blocks(C.byref(p))
-        vs = _vec_stride(hid, dout)
-        vecp = torch.empty((nblk, 4, vs), device=dev, dtype=torch.float32)
-        p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(vecp), nblk, vs
 
-        # ---- where the launches go.  Weight gradients (needed only by the optimizer) run on a side stream when the
-        # trainer owns the parameter gradients (see _WgradOverlap); an MLP none of whose inputs needs a gradient is a
-        # dead end of backward, so its data-gradient kernel goes there as well ----
-        prm = ctx.param_refs
+def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
+    """Backward of one fused-MLP launch (FusedMLPFunction / CatMLPFunction).  ``needs`` = the needs_input_grad tuple in
+    FusedMLPFunction's argument order: (geom, W1, b1, W2, b2, ln_w, ln_b, *sources)."""
+    lib = L.load()
+    geom: MlpGeometry = ctx.geom
+    W1, W2, ln_w, z1, xhat, rstd, *bases = ctx.saved_tensors
+    B, rows, ntiles = ctx.B, ctx.rows, ctx.ntiles
+    hid, kin = W1.shape
+    dout = W2.shape[0]
+    dev = W1.device
+    nsrc = geom.nsrc
+    widths = [s[-1] for s in ctx.src_shapes]
+    n_fixed = 7
+    if g_out is None and g_aggr is None:
+        return (None,) * (n_fixed + nsrc)
+    if g_out is not None:
+        g_out = g_out.reshape(B, -1, dout).contiguous()
+    if g_aggr is not None:
+        g_aggr = g_aggr.reshape(B, -1, dout).contiguous()
 
-        def is_direct(param, shape):
-            return (
-                DIRECT_PARAM_GRADS and param is not None and param.grad is not None and param.grad.is_contiguous()
-                and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32
-            )
+    p = L.MlpBwd()
+    for k in range(nsrc):
+        b_, bstride = ctx.binfo[k]
+        _fill_src(p.src[k], bases[k], bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k])
+    p.nsrc, p.batch, p.rows, p.ntiles = nsrc, B, rows, ntiles
+    p.tiles = _ptr(geom.tiles)
+    p.W1, p.W2, p.ln_w = _ptr(W1), _ptr(W2), _ptr(ln_w) if ctx.has_ln else None
+    p.hid, p.dout, p.flags, p.nseg_total = hid, dout, geom.flags | ctx.mm_flags, geom.nseg_total
+    pre = bool(geom.flags & L.F_PRE_ADD)
+    p.ldw1 = kin if pre else 0
+    if g_out is not None:
+        p.g_out, p.out_idx, p.out_bstride = _ptr(g_out), _ptr(geom.out_idx), g_out.shape[1] * dout
+    if g_aggr is not None:
+        p.g_aggr, p.seg_of_row = _ptr(g_aggr), _ptr(geom.seg_of_row)
+    p.rowptr, p.inv_deg = _ptr(geom.rowptr), _ptr(geom.inv_deg)
+    p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
+    dz1 = torch.empty((B * rows, hid), device=dev, dtype=torch.float32)
+    p.dz1 = _ptr(dz1)
+    dsrc = [None] * nsrc
+    tmp2 = [None] * nsrc
+    for k in range(nsrc):
+        if not needs[n_fixed + k]:
+            p.dmode[k] = 0
+            continue
+        mode = geom.dmode[k]
+        w = widths[k]
+        n_src_rows = ctx.src_shapes[k][-2]
+        p.dmode[k] = mode
+        if pre and k > 0 and mode == 2:
+            p.dmode[k] = 0   # gradient of a sender-gathered addend: a CSC segment sum over the dz1 rows, below
+            continue
+        if mode == 1:
+            # rows scattered through the (unique, covering) gather index, or identity
+            dsrc[k] = torch.empty((B, n_src_rows, w), device=dev, dtype=torch.float32)
+            p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), n_src_rows * w
+        elif mode == 2:
+            tmp2[k] = torch.empty((B, rows, w), device=dev, dtype=torch.float32)
+            p.dsrc[k], p.dsrc_bstride[k] = _ptr(tmp2[k]), rows * w
+        elif mode == 3:
+            alloc = torch.zeros if geom.has_split else torch.empty
+            dsrc[k] = alloc((B, geom.nseg_total, w), device=dev, dtype=torch.float32)
+            p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), geom.nseg_total * w
+    dz2, dpad = _alloc_dz2(lib, p, B * rows, dout, dev)   # (rows, dout); 32-padded columns for a ragged output width (output_map)
+    nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
+    wpack = None
+    if nwp > 0:
+        wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+        p.wpack, p.wpack_floats = _ptr(wpack), nwp
+    elif ctx.pack is not None and PACKER is not None and ctx.pack.packed_step == PACKER.step_id:
+        p.wpack, p.wpack_floats = ctx.pack.bwd.data_ptr(), ctx.pack.bwd.numel()
+    nblk = lib.nlam_mlp_bwd_blocks(C.byref(p))
+    vs = _vec_stride(hid, dout)
+    vecp = torch.empty((nblk, 4, vs), device=dev, dtype=torch.float32)
+    p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(vecp), nblk, vs
 
-        wanted = [  # (slot, needs_grad, param, shape)
-            (0, ctx.needs_input_grad[1], prm[0], (hid, kin)), (1, ctx.needs_input_grad[2], prm[1], (hid,)),
-            (2, ctx.needs_input_grad[3], prm[2], (dout, hid)), (3, ctx.needs_input_grad[4], prm[3], (dout,)),
-            (4, ctx.has_ln and ctx.needs_input_grad[5], prm[4], (dout,)),
-            (5, ctx.has_ln and ctx.needs_input_grad[6], prm[5], (dout,)),
-        ]
-        on_side = OVERLAP.active and all(is_direct(pp, sh) for _, need, pp, sh in wanted if need)
-        whole_side = on_side and not any(ctx.needs_input_grad[n_fixed:])
-        streams = contextlib.ExitStack()
-        side = OVERLAP.stream_for(prm[0]) if on_side else None
-        if whole_side:
+    # ---- where the launches go.  Weight gradients (needed only by the optimizer) run on a side stream when the
+    # trainer owns the parameter gradients (see _WgradOverlap); an MLP none of whose inputs needs a gradient is a
+    # dead end of backward, so its data-gradient kernel goes there as well ----
+    prm = ctx.param_refs
+
+    def is_direct(param, shape):
+        return (
+            DIRECT_PARAM_GRADS and param is not None and param.grad is not None and param.grad.is_contiguous()
+            and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32
+        )
+
+    wanted = [  # (slot, needs_grad, param, shape)
+        (0, needs[1], prm[0], (hid, kin)), (1, needs[2], prm[1], (hid,)),
+        (2, needs[3], prm[2], (dout, hid)), (3, needs[4], prm[3], (dout,)),
+        (4, ctx.has_ln and needs[5], prm[4], (dout,)),
+        (5, ctx.has_ln and needs[6], prm[5], (dout,)),
+    ]
+    on_side = OVERLAP.active and all(is_direct(pp, sh) for _, need, pp, sh in wanted if need)
+    whole_side = on_side and not any(needs[n_fixed:])
+    streams = contextlib.ExitStack()
+    side = OVERLAP.stream_for(prm[0]) if on_side else None
+    if whole_side:
+        side.wait_stream(torch.cuda.current_stream())
+        OVERLAP.hold(side, g_out, g_aggr, xhat, rstd, wpack)
+        streams.enter_context(torch.cuda.stream(side))
+    key = ("mlp_bwd", rows * B, kin, hid, dout, nsrc, g_aggr is not None)
+
+    def bwd_meta():
+        nbytes = sum(t_.numel() * 4 for t_ in (g_out, g_aggr, z1, xhat, rstd, dz1, dz2) if t_ is not None)
+        nbytes += sum(t_.numel() * 4 for t_ in (*dsrc, *tmp2) if t_ is not None)
+        kin_live = sum(w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0 and not (pre and k_ > 0))
+        name, mf = _mm_executed(ctx.mm_flags, hid, dout, [w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0] or [hid],
+                                ragged_out_ok=dpad != dout)
+        return {"flops": 2.0 * rows * B * (kin_live * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
+                "what": "LayerNorm/SiLU backward + dh = dz2 W2 + dx = dz1 W1 (data gradients; writes dz1, dz2 for the weight gradients)"}
+
+    L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_bwd(C.byref(p), _stream()), bwd_meta), "nlam_mlp_bwd")
+
+    if pre:
+        for k in range(1, nsrc):
+            if needs[n_fixed + k] and geom.dmode[k] == 2:   # no (rows, w) round trip: dz1 is the data
+                dsrc[k] = segment_sum(dz1, rows * hid, geom.colptr, geom.cperm, None, geom.num_send, hid, B)
+    for k in range(nsrc):
+        if tmp2[k] is not None:  # finish scatter-by-sender as a CSC segment sum
+            tw = ctx.twin_of.get(k)
+            if tw is not None and dsrc[tw] is not None and dsrc[tw].shape == (B, geom.num_send, widths[k]):
+                # senders and receivers are the same tensor (mesh <-> mesh layers): add onto the receiver-side
+                # gradient and report nothing for this slot -- one autograd add launch less per layer
+                segment_sum(tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B,
+                            out=dsrc[tw], accumulate=True)
+                dsrc[k] = None
+            else:
+                dsrc[k] = segment_sum(
+                    tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B
+                )
+
+    # ---- weight gradients: TN GEMMs with a deterministic two-stage reduction ----
+    if on_side:
+        if not whole_side:
             side.wait_stream(torch.cuda.current_stream())
-            OVERLAP.hold(side, g_out, g_aggr, xhat, rstd, wpack)
             streams.enter_context(torch.cuda.stream(side))
-        key = ("mlp_bwd", rows * B, kin, hid, dout, nsrc, g_aggr is not None)
+        OVERLAP.hold(side, dz1, dz2, vecp, z1, *bases)
+    side_ctx = streams
 
-        def bwd_meta():
-            nbytes = sum(t_.numel() * 4 for t_ in (g_out, g_aggr, z1, xhat, rstd, dz1, dz2) if t_ is not None)
-            nbytes += sum(t_.numel() * 4 for t_ in (*dsrc, *tmp2) if t_ is not None)
-            kin_live = sum(w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0 and not (pre and k_ > 0))
-            name, mf = _mm_executed(ctx.mm_flags, hid, dout, [w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0] or [hid],
-                                    ragged_out_ok=dpad != dout)
-            return {"flops": 2.0 * rows * B * (kin_live * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
-                    "what": "LayerNorm/SiLU backward + dh = dz2 W2 + dx = dz1 W1 (data gradients; writes dz1, dz2 for the weight gradients)"}
+    def wgrad(A, m, src_list, n, flags):
+        q = L.Wgrad()
+        q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(src_list), flags | ctx.mm_flags, n
+        for k, (t, bstride, w, idx) in enumerate(src_list):
+            _fill_src(q.src[k], t, bstride, w, idx)
+        nparts = lib.nlam_wgrad_nparts(C.byref(q))
+        partials = torch.empty((nparts, m, n), device=dev, dtype=torch.float32)
+        q.partials, q.nparts = _ptr(partials), nparts
+        key = ("wgrad", rows * B, m, n)
 
-        L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_bwd(C.byref(p), _stream()), bwd_meta), "nlam_mlp_bwd")
+        def wg_meta():
+            nbytes = A.numel() * 4 + partials.numel() * 4
+            nbytes += sum(t.shape[-2] * w * 4 * (B if bstride != 0 or B == 1 else 1) for (t, bstride, w, idx) in src_list)
+            narrow = m <= 64 and all(w <= 64 for (_, _, w, _) in src_list)
+            name, mf = ("f32", 0) if narrow else _mm_executed(ctx.mm_flags, m, m, [w for (_, _, w, _) in src_list])
+            return {"flops": 2.0 * rows * B * m * n, "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
+                    "what": "weight gradient dW = A^T [gathered B], rows = MFMA K"}
 
-        if pre:
-            for k in range(1, nsrc):
-                if ctx.needs_input_grad[n_fixed + k] and geom.dmode[k] == 2:   # no (rows, w) round trip: dz1 is the data
-                    dsrc[k] = segment_sum(dz1, rows * hid, geom.colptr, geom.cperm, None, geom.num_send, hid, B)
-        for k in range(nsrc):
-            if tmp2[k] is not None:  # finish scatter-by-sender as a CSC segment sum
-                tw = ctx.twin_of.get(k)
-                if tw is not None and dsrc[tw] is not None and dsrc[tw].shape == (B, geom.num_send, widths[k]):
-                    # senders and receivers are the same tensor (mesh <-> mesh layers): add onto the receiver-side
-                    # gradient and report nothing for this slot -- one autograd add launch less per layer
-                    segment_sum(tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B,
-                                out=dsrc[tw], accumulate=True)
-                    dsrc[k] = None
-                else:
-                    dsrc[k] = segment_sum(
-                        tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B
-                    )
+        L.check(PROFILE.launch(key, lambda: lib.nlam_wgrad(C.byref(q), _stream()), wg_meta), "nlam_wgrad")
+        return partials
 
-        # ---- weight gradients: TN GEMMs with a deterministic two-stage reduction ----
+    src_list = []
+    for k in range(1 if pre else nsrc):   # factorised: W1 has columns for source 0 only (the node-level products own the rest)
+        b_, bstride = ctx.binfo[k]
+        src_list.append((bases[k], bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k]))
+    kin1 = widths[0] if pre else kin
+    results = [None] * 6   # dW1, db1, dW2, db2, dgamma, dbeta
+    with side_ctx:
+        part1 = wgrad(dz1, hid, src_list, kin1, 0) if needs[1] else None
+        part2 = wgrad(dz2, dpad, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if needs[3] else None
+
+        # ---- one launch reduces every partial sum; with DIRECT_PARAM_GRADS it accumulates into .grad ----
+        jobs = L.ReduceJobs()
+        keep = []
+
+        def add_job(slot, partials_ptr, nparts, stride, shape, param, ncols=0):
+            """``ncols`` > 0: the partials are the leading (shape[0], ncols) column block of the (shape) matrix."""
+            n = 1
+            for d_ in shape:
+                n *= d_
+            direct = is_direct(param, shape)
+            if direct:
+                out = param.grad
+            else:
+                out = (torch.zeros if ncols else torch.empty)(shape, device=dev, dtype=torch.float32)
+                results[slot] = out
+            keep.append(out)
+            j = jobs.job[jobs.njobs]
+            j.partials, j.out, j.stride, j.nparts, j.accumulate = partials_ptr, _ptr(out), stride, nparts, 1 if direct else 0
+            j.n, j.ncols, j.ld = (shape[0] * ncols, ncols, shape[1]) if ncols else (n, 0, 0)
+            jobs.njobs += 1
+
+        vbase = vecp.data_ptr()
+        if part1 is not None:
+            add_job(0, _ptr(part1), part1.shape[0], hid * kin1, (hid, kin), prm[0], ncols=kin1 if pre else 0)
+        if needs[2]:
+            add_job(1, vbase + 0 * vs * 4, nblk, 4 * vs, (hid,), prm[1])
+        if part2 is not None:   # a padded dz2 gives (dpad, hid) partials: the first dout rows are the gradient
+            add_job(2, _ptr(part2), part2.shape[0], dpad * hid, (dout, hid), prm[2])
+        if needs[4]:
+            add_job(3, vbase + 1 * vs * 4, nblk, 4 * vs, (dout,), prm[3])
+        if ctx.has_ln and needs[5]:
+            add_job(4, vbase + 2 * vs * 4, nblk, 4 * vs, (dout,), prm[4])
+        if ctx.has_ln and needs[6]:
+            add_job(5, vbase + 3 * vs * 4, nblk, 4 * vs, (dout,), prm[5])
+        if jobs.njobs > 0:
+            L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
         if on_side:
-            if not whole_side:
-                side.wait_stream(torch.cuda.current_stream())
-                streams.enter_context(torch.cuda.stream(side))
-            OVERLAP.hold(side, dz1, dz2, vecp, z1, *bases)
-        side_ctx = streams
+            OVERLAP.hold(side, part1, part2)
+        if GRAD_LISTENER is not None:   # inside the side-stream context: a collective launched from here waits on it
+            GRAD_LISTENER.note_done([pp for _, need, pp, sh in wanted if need and is_direct(pp, sh)])
+    dW1, db1, dW2, db2, dg, dbt = results
 
-        def wgrad(A, m, src_list, n, flags):
-            q = L.Wgrad()
-            q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(src_list), flags | ctx.mm_flags, n
-            for k, (t, bstride, w, idx) in enumerate(src_list):
-                _fill_src(q.src[k], t, bstride, w, idx)
-            nparts = lib.nlam_wgrad_nparts(C.byref(q))
-            partials = torch.empty((nparts, m, n), device=dev, dtype=torch.float32)
-            q.partials, q.nparts = _ptr(partials), nparts
-            key = ("wgrad", rows * B, m, n)
-
-            def wg_meta():
-                nbytes = A.numel() * 4 + partials.numel() * 4
-                nbytes += sum(t.shape[-2] * w * 4 * (B if bstride != 0 or B == 1 else 1) for (t, bstride, w, idx) in src_list)
-                narrow = m <= 64 and all(w <= 64 for (_, _, w, _) in src_list)
-                name, mf = ("f32", 0) if narrow else _mm_executed(ctx.mm_flags, m, m, [w for (_, _, w, _) in src_list])
-                return {"flops": 2.0 * rows * B * m * n, "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
-                        "what": "weight gradient dW = A^T [gathered B], rows = MFMA K"}
-
-            L.check(PROFILE.launch(key, lambda: lib.nlam_wgrad(C.byref(q), _stream()), wg_meta), "nlam_wgrad")
-            return partials
-
-        src_list = []
-        for k in range(1 if pre else nsrc):   # factorised: W1 has columns for source 0 only (the node-level products own the rest)
-            b_, bstride = ctx.binfo[k]
-            src_list.append((bases[k], bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k]))
-        kin1 = widths[0] if pre else kin
-        results = [None] * 6   # dW1, db1, dW2, db2, dgamma, dbeta
-        with side_ctx:
-            part1 = wgrad(dz1, hid, src_list, kin1, 0) if ctx.needs_input_grad[1] else None
-            part2 = wgrad(dz2, dpad, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if ctx.needs_input_grad[3] else None
-
-            # ---- one launch reduces every partial sum; with DIRECT_PARAM_GRADS it accumulates into .grad ----
-            jobs = L.ReduceJobs()
-            keep = []
-
-            def add_job(slot, partials_ptr, nparts, stride, shape, param, ncols=0):
-                """``ncols`` > 0: the partials are the leading (shape[0], ncols) column block of the (shape) matrix."""
-                n = 1
-                for d_ in shape:
-                    n *= d_
-                direct = is_direct(param, shape)
-                if direct:
-                    out = param.grad
-                else:
-                    out = (torch.zeros if ncols else torch.empty)(shape, device=dev, dtype=torch.float32)
-                    results[slot] = out
-                keep.append(out)
-                j = jobs.job[jobs.njobs]
-                j.partials, j.out, j.stride, j.nparts, j.accumulate = partials_ptr, _ptr(out), stride, nparts, 1 if direct else 0
-                j.n, j.ncols, j.ld = (shape[0] * ncols, ncols, shape[1]) if ncols else (n, 0, 0)
-                jobs.njobs += 1
-
-            vbase = vecp.data_ptr()
-            if part1 is not None:
-                add_job(0, _ptr(part1), part1.shape[0], hid * kin1, (hid, kin), prm[0], ncols=kin1 if pre else 0)
-            if ctx.needs_input_grad[2]:
-                add_job(1, vbase + 0 * vs * 4, nblk, 4 * vs, (hid,), prm[1])
-            if part2 is not None:   # a padded dz2 gives (dpad, hid) partials: the first dout rows are the gradient
-                add_job(2, _ptr(part2), part2.shape[0], dpad * hid, (dout, hid), prm[2])
-            if ctx.needs_input_grad[4]:
-                add_job(3, vbase + 1 * vs * 4, nblk, 4 * vs, (dout,), prm[3])
-            if ctx.has_ln and ctx.needs_input_grad[5]:
-                add_job(4, vbase + 2 * vs * 4, nblk, 4 * vs, (dout,), prm[4])
-            if ctx.has_ln and ctx.needs_input_grad[6]:
-                add_job(5, vbase + 3 * vs * 4, nblk, 4 * vs, (dout,), prm[5])
-            if jobs.njobs > 0:
-                L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
-            if on_side:
-                OVERLAP.hold(side, part1, part2)
-            if GRAD_LISTENER is not None:   # inside the side-stream context: a collective launched from here waits on it
-                GRAD_LISTENER.note_done([pp for _, need, pp, sh in wanted if need and is_direct(pp, sh)])
-        dW1, db1, dW2, db2, dg, dbt = results
-
-        grads_src = []
-        for k in range(nsrc):
-            g = dsrc[k]
-            if g is not None:
-                b_, _ = ctx.binfo[k]
-                shape = ctx.src_shapes[k]
-                lead_numel = 1
-                for s in shape[:-2]:
-                    lead_numel *= s
-                if lead_numel != B:  # source had no batch dim of its own
-                    g = g.sum(0) if B > 1 else g[0]
-                g = g.reshape(shape)
-            grads_src.append(g)
-        return (None, dW1, db1, dW2, db2, dg, dbt, *grads_src)
+    grads_src = []
+    for k in range(nsrc):
+        g = dsrc[k]
+        if g is not None:
+            b_, _ = ctx.binfo[k]
+            shape = ctx.src_shapes[k]
+            lead_numel = 1
+            for s in shape[:-2]:
+                lead_numel *= s
+            if lead_numel != B:  # source had no batch dim of its own
+                g = g.sum(0) if B > 1 else g[0]
+            g = g.reshape(shape)
+        grads_src.append(g)
+    return (None, dW1, db1, dW2, db2, dg, dbt, *grads_src)
 
 
 @dataclass
@@ -1670,6 +1676,122 @@ class ConcatFunction(torch.autograd.Function):
             grads.append(gk)
             off += w
         return tuple(grads)
+
+
+class CatMLPFunction(torch.autograd.Function):
+    """``mlp(torch.cat(pieces, dim=-1))`` with the concatenation folded into the MLP's first load (nlam_mlp_fwd with cat
+    pieces): the grid input features in front of ``grid_embedder`` (step_predictors/graph/base.py:275-286) -- previous
+    state, state before that, forcing window, static features -- are read straight from their own tensors (the static
+    features un-expanded), so the (B, N, 56) tensor exists only as a by-product the kernel writes in training mode for the
+    weight gradient and the backward pass.  Shapes the piece path does not serve (fp32 matrix mode, > 64 columns) fall back
+    to nlam_concat + the plain launch inside this Function.
+
+    forward(W1, b1, W2, b2, ln_w, ln_b, *pieces (B | expanded, N, w_k)) -> (B, N, dout)"""
+
+    @staticmethod
+    def forward(ctx, W1, b1, W2, b2, ln_w, ln_b, *pieces):
+        lib = L.load()
+        mm_flags = _mm_flags()
+        pieces = tuple(x if x.dtype == torch.float32 else x.float() for x in pieces)
+        _require_gpu(W1, b1, W2, b2, ln_w, ln_b, *pieces)
+        if not 1 <= len(pieces) <= L.NLAM_MAX_CAT or any(x.dim() != 3 for x in pieces):
+            raise RuntimeError("CatMLPFunction: 1..6 pieces of shape (B, N, w)")
+        hid, kin = W1.shape
+        dout = W2.shape[0]
+        binfo = [as_batched(x) for x in pieces]
+        B = max(bi[1] for bi in binfo)
+        N = pieces[0].shape[-2]
+        widths = [x.shape[-1] for x in pieces]
+        if sum(widths) != kin or any(x.shape[-2] != N for x in pieces) or any(bi[1] not in (1, B) for bi in binfo):
+            raise RuntimeError(f"CatMLPFunction: pieces {[tuple(x.shape) for x in pieces]} do not concatenate to (B, N, {kin})")
+        dev = pieces[0].device
+        need_grad = any(ctx.needs_input_grad)
+        p = L.MlpFwd()
+        p.nsrc, p.batch, p.rows, p.ntiles = 1, B, N, (N + 31) // 32
+        p.src[0].width, p.src[0].bstride = kin, N * kin
+        p.ncat = len(pieces)
+        for k, (t, b_, bstride, _) in enumerate(binfo):
+            p.cat_ptr[k], p.cat_bstride[k], p.cat_width[k] = t.data_ptr(), (bstride if b_ == B and B > 1 else 0), widths[k]
+        W1c, b1c, W2c, b2c = W1.contiguous(), b1.contiguous(), W2.contiguous(), b2.contiguous()
+        p.W1, p.b1, p.W2, p.b2, p.ln_w, p.ln_b = _ptr(W1c), _ptr(b1c), _ptr(W2c), _ptr(b2c), _ptr(ln_w), _ptr(ln_b)
+        p.eps, p.hid, p.dout, p.flags = 1e-5, hid, dout, mm_flags
+        out = torch.empty((B, N, dout), device=dev, dtype=torch.float32)
+        p.out, p.out_bstride = _ptr(out), N * dout
+        catbuf = z1 = xhat = rstd = None
+        if need_grad:
+            catbuf = torch.empty((B, N, kin), device=dev, dtype=torch.float32)
+            p.cat_out = _ptr(catbuf)
+            z1 = torch.empty((B, N, hid), device=dev, dtype=torch.float32)
+            p.z1 = _ptr(z1)
+            if ln_w is not None:
+                xhat = torch.empty((B, N, dout), device=dev, dtype=torch.float32)
+                rstd = torch.empty((B, N), device=dev, dtype=torch.float32)
+                p.xhat, p.rstd = _ptr(xhat), _ptr(rstd)
+        pack = None
+        wide = lib.nlam_mlp_fwd_wpack_floats(C.byref(p)) > 0
+        if not wide and PACKER is not None:
+            pack = PACKER.get(W1c, W2c, [kin], hid, dout, False, 0, mm_flags)
+            if pack is not None:
+                p.wpack, p.wpack_floats = pack.fwd.data_ptr(), pack.fwd.numel()
+        key = ("mlp_fwd", N * B, kin, hid, dout, 1, False, need_grad)
+
+        def meta():
+            nbytes = sum(x.shape[-2] * w * 4 * (B if bi[2] != 0 or B == 1 else 1) for x, w, bi in zip(pieces, widths, binfo)) + out.numel() * 4
+            nbytes += sum(t_.numel() * 4 for t_ in (catbuf, z1, xhat, rstd) if t_ is not None)
+            name, mf = _mm_executed(mm_flags, hid, dout, [kin])
+            return {"flops": 2.0 * N * B * (kin * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
+                    "what": f"concat of {len(pieces)} pieces folded into Linear-SiLU-Linear" + ("-LayerNorm" if ln_w is not None else "")}
+
+        rc = -2 if wide else PROFILE.launch(key, lambda: lib.nlam_mlp_fwd(C.byref(p), _stream()), meta)
+        if rc == -2:   # NLAM_EUNSUP: materialise the concatenation (one launch) and run the plain single-source MLP on it
+            q = L.Cat()
+            for k, (t, b_, bstride, _) in enumerate(binfo):
+                q.ptr[k], q.bstride[k], q.width[k] = t.data_ptr(), (bstride if b_ == B and B > 1 else 0), widths[k]
+            if catbuf is None:
+                catbuf = torch.empty((B, N, kin), device=dev, dtype=torch.float32)
+            q.nsrc, q.batch, q.nodes, q.out = len(pieces), B, N, _ptr(catbuf)
+            L.check(lib.nlam_concat(C.byref(q), _stream()), "nlam_concat")
+            p.ncat, p.cat_out = 0, None
+            _fill_src(p.src[0], catbuf, N * kin, kin, None)
+            nwp = lib.nlam_mlp_fwd_wpack_floats(C.byref(p))
+            if nwp > 0:
+                wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+                p.wpack, p.wpack_floats = _ptr(wpack), nwp
+            rc = lib.nlam_mlp_fwd(C.byref(p), _stream())
+        L.check(rc, "nlam_mlp_fwd (concatenated pieces)")
+        if need_grad:
+            ctx.geom, ctx.B, ctx.rows, ctx.ntiles = MlpGeometry(nsrc=1), B, N, (N + 31) // 32
+            ctx.binfo = [(B, N * kin)]
+            ctx.src_shapes = [(B, N, kin)]
+            ctx.twin_of = {}
+            ctx.has_ln = ln_w is not None
+            ctx.param_refs = (W1, b1, W2, b2, ln_w, ln_b)
+            ctx.mm_flags, ctx.pack = mm_flags, pack
+            ctx.widths, ctx.piece_shapes = widths, [tuple(x.shape) for x in pieces]
+            if GRAD_LISTENER is not None:
+                GRAD_LISTENER.note_use([q_ for q_ in ctx.param_refs if q_ is not None and q_.requires_grad])
+            ctx.save_for_backward(W1c, W2c, ln_w, z1, xhat, rstd, catbuf)
+            ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        npieces = len(ctx.widths)
+        if g_out is None:
+            return (None,) * (6 + npieces)
+        needs = (False, *ctx.needs_input_grad[0:6], any(ctx.needs_input_grad[6:]))
+        res = _fused_mlp_backward(ctx, g_out, None, needs)
+        g_cat = res[7]
+        grads, off = [], 0
+        for k, w in enumerate(ctx.widths):
+            gk = None
+            if ctx.needs_input_grad[6 + k] and g_cat is not None:
+                gk = g_cat[..., off : off + w]
+                if gk.shape != ctx.piece_shapes[k]:   # a piece shared by the batch (expand_to_batch)
+                    gk = gk.sum(0, keepdim=True).expand(ctx.piece_shapes[k])
+            grads.append(gk)
+            off += w
+        return (*res[1:7], *grads)
 
 
 def standardize(items, outs=None):

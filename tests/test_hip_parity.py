@@ -286,6 +286,54 @@ def test_plain_mlp_matches_oracle(dev, kin, hid, dout, ln, wide_family):
         assert rel_err(p.grad.cpu(), q.grad) < TOL, k
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16", "f32"])
+@pytest.mark.parametrize("widths,hid,B,shared_last", [
+    ([17, 17, 18, 4], 64, 2, True),    # the grid input features of the MEPS configuration (graph/base.py:275-283): 56 columns
+    ([5, 5, 6, 1], 16, 3, True),       # the reference's dummy datastore: 17 columns -> not a multiple of 4: the concat fallback
+    ([5, 5, 6], 32, 1, False),         # 16 columns, three pieces, hid = 32
+    ([40, 24], 64, 2, False),          # a piece boundary inside the second 32-column unit
+    ([64], 64, 2, False),              # a single piece
+    ([60, 60, 12], 128, 2, False),     # 132 columns: wide kernels -> the fallback
+])
+def test_concat_folded_into_mlp_matches_oracle(dev, mode, widths, hid, B, shared_last):
+    """ops.CatMLPFunction = ``make_mlp(...)(torch.cat(pieces, -1))`` (graph/base.py:275-286) with the concatenation folded into
+    the kernel's first load: outputs, gradients of every piece that takes one (a batch-shared piece gets the batch sum) and all
+    parameter gradients against the oracle; the fp32 matrix mode and shapes the piece path does not serve take the in-Function
+    fallback (nlam_concat + the plain launch) and must agree just the same."""
+    from neural_lam_amd import ops
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    kin, N = sum(widths), 777
+    torch.manual_seed(kin + hid)
+    ref = og.make_mlp([kin, hid, hid])
+    net = hl.make_mlp([kin, hid, hid])
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    pieces = [torch.randn(B, N, w) for w in widths]
+    if shared_last:   # expand_to_batch: the static features, one copy for the whole batch
+        pieces[-1] = pieces[-1][:1].expand(B, N, widths[-1])
+    p1 = [x.clone().requires_grad_() for x in pieces[:-1]] + [pieces[-1]]
+    p2 = [x.to(dev).requires_grad_() for x in pieces[:-1]] + [pieces[-1][:1].to(dev).expand(B, N, widths[-1]) if shared_last else pieces[-1].to(dev)]
+    old = ops.MATMUL_MODE
+    ops.set_matmul_mode(mode)
+    try:
+        y1 = ref(torch.cat(p1, dim=-1))
+        y2 = ops.CatMLPFunction.apply(*net.params(), *p2)
+        tol = 3e-2 if mode == "bf16" else TOL
+        assert rel_err(y2.cpu(), y1) < tol
+        with torch.no_grad():   # inference: nothing is materialised, same result
+            assert torch.equal(ops.CatMLPFunction.apply(*net.params(), *[t.detach() for t in p2]), y2.detach())
+        y1.sin().sum().backward()
+        y2.sin().sum().backward()
+    finally:
+        ops.set_matmul_mode(old)
+    for a, b in zip(p2[:-1], p1[:-1]):
+        assert rel_err(a.grad.cpu(), b.grad) < tol
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < tol, k
+
+
 def test_prepacked_weights_give_identical_steps(dev, tmp_path):
     """``nlam_mlp_pack``: under a trainer the narrow kernels fetch their weights as images packed once per step instead of
     splitting the fp32 matrices in every workgroup.  Same bf16 terms, same LDS layout -> the step must be BIT-identical with
