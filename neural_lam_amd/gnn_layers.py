@@ -49,6 +49,9 @@ FACTORISE_MIN_WORK_WIDE = int(os.environ.get("NLAM_FACTORISE_MIN_WORK_WIDE", "14
 FACTORISE_MIN_WIDTH_WIDE = int(os.environ.get("NLAM_FACTORISE_MIN_WIDTH_WIDE", "256"))
 
 
+_DEVICE_LAYOUTS: dict = {}   # (id of the host EdgeCSR, device) -> device EdgeCSR (+ tiles): shared by every layer built on that edge set
+
+
 class FusedMLP(nn.Sequential):
     """``[Linear -> SiLU] * hidden_layers -> Linear [-> LayerNorm]`` with the reference's child names
     (``0``, ``2``, ..: Linear; last: LayerNorm; utils/networks.py:8-40).
@@ -272,16 +275,22 @@ class InteractionNet(nn.Module):
             if num_send <= int(self._edge_index_local[0].max()):
                 raise RuntimeError("send_rep has fewer rows than the largest sender index in edge_index")
             host, tiles, has_split = self._host_csr if num_send == self._num_send_default else self._build_host_csr(num_send)
-            csr = host.to(device)
-            csr.tiles = tiles.to(device)
-            csr.has_split = has_split
+            dkey = (id(host), str(device))   # layers on the same edge set (content-cached host layout) share ONE device copy
+            csr = _DEVICE_LAYOUTS.get(dkey)
+            if csr is None or csr._host is not host:
+                csr = host.to(device)
+                csr.tiles = tiles.to(device)
+                csr.has_split = has_split
+                csr._host = host   # keeps the host object alive: its id() is the key
+                _DEVICE_LAYOUTS[dkey] = csr
             self._csr_cache[key] = csr
         return self._csr_cache[key]
 
     def _build_host_csr(self, num_send: int):
-        csr = build_edge_csr(self._edge_index_local, num_send=num_send, num_rec=int(self.num_rec))
-        tiles, has_split = build_tile_schedule(csr.rowptr)
-        return csr, tiles, has_split
+        # content-cached: the processor layers share one edge set, and load_graph may have brought the layout along
+        from .graph import edge_layout
+
+        return edge_layout(self._edge_index_local, num_send=num_send, num_rec=int(self.num_rec))
 
     def _edge_geom(self, csr: EdgeCSR, want_out: bool, add_edge: bool, key, pre: bool = False) -> MlpGeometry:
         gkey = (key, want_out, add_edge, pre)

@@ -4,10 +4,12 @@ Host-side logic (numpy/scipy/torch CPU); nothing here touches the GPU.
 
 * ``create_regular_grid_graph`` restates the *algorithm* of the reference's
   offline generator ``neural_lam/create_graph.py:356-862`` for regular grids in
-  vectorised numpy (the reference walks networkx graphs edge by edge); the edge
-  *sets* and features are identical, the edge *order* is sender-major with
-  ascending receivers (the reference's order is networkx insertion order; the
-  model is invariant to a consistent permutation of edges).
+  vectorised numpy (the reference walks networkx graphs edge by edge and queries
+  three KD-trees; here the neighbour searches are closed-form index windows on
+  the lattices, ``knn_lattice`` / ``ball_lattice``); the edge *sets* and features
+  are identical, the edge *order* is sender-major with ascending receivers (the
+  reference's order is networkx insertion order; the model is invariant to a
+  consistent permutation of edges).
 * ``save_graph`` / ``load_graph`` speak the reference's graph storage spec
   v0.1.0 (``docs/graph_storage_spec.md``; loader semantics of
   ``neural_lam/utils/graph.py:146-422``): int64 ``[2,E]`` edge indices that are
@@ -28,7 +30,7 @@ from pathlib import Path
 import numpy as np
 import torch
 import yaml
-from scipy.spatial import KDTree  # same class + leafsize as the reference: 4-NN ties break alike
+from scipy.spatial import KDTree  # the reference's class: decides what the closed-form lattice searches cannot (ties, irregular coordinates)
 
 GRAPH_SPEC_VERSION = "0.1.0"  # create_graph.py:24
 METAINFO_FILENAME = "metainfo.yaml"  # create_graph.py:23
@@ -73,6 +75,109 @@ def _level_edges(pos: np.ndarray):
     vdiff = pos[send[:, 0], send[:, 1]] - pos[rec[:, 0], rec[:, 1]]
     length = np.sqrt(np.sum(vdiff**2, axis=1))
     return send, rec, length, vdiff
+
+
+# --------------------------------------------------------------------------
+# neighbour searches on regular lattices (no KD-tree)
+#
+# The reference builds three KD-trees per graph (create_graph.py:488, 731, 777).  On a regular grid / mesh lattice the
+# candidates of a query point are known in closed form -- the lattice cells around it -- so the searches below evaluate a
+# small index window per query, vectorised, with the same distance arithmetic as the tree ((dx*dx + dy*dy) in float64).
+# Whatever the window cannot decide EXACTLY like the tree is handed to the tree for that query only: a k-th / (k+1)-th
+# distance tie (the tree's traversal order breaks those), a point within rounding distance of the ball radius, a window
+# that might be too small, coordinates that are not a lattice.  The edge sets therefore equal the reference's bit for bit;
+# tests/test_graph.py compares against scipy.spatial.KDTree on anisotropic, offset and tie-rich lattices.
+# --------------------------------------------------------------------------
+def _lattice_axes(pts: np.ndarray, shape, rtol=1e-9):
+    """(x0, dx, y0, dy) if ``pts`` ((n0 * n1, 2), index i * n1 + j) is a regular lattice pts[i, j] = (x0 + i dx, y0 + j dy)
+    to within ``rtol`` of its extent (mesh positions carry linspace rounding, coarser-level overrides differ in the last
+    bits), else None."""
+    n0, n1 = shape
+    if n0 < 2 or n1 < 2 or pts.shape[0] != n0 * n1:
+        return None
+    P = pts.reshape(n0, n1, 2)
+    x0, y0 = P[0, 0]
+    dx, dy = (P[-1, 0, 0] - x0) / (n0 - 1), (P[0, -1, 1] - y0) / (n1 - 1)
+    if dx <= 0 or dy <= 0:
+        return None
+    ii, jj = np.meshgrid(np.arange(n0), np.arange(n1), indexing="ij")
+    tol = rtol * max(abs(dx) * n0, abs(dy) * n1)
+    if np.abs(P[..., 0] - (x0 + ii * dx)).max() > tol or np.abs(P[..., 1] - (y0 + jj * dy)).max() > tol:
+        return None
+    return float(x0), float(dx), float(y0), float(dy)
+
+
+def _window_candidates(query, axes, shape, half):
+    """Lattice indices (flat, -1 where outside) of the (2 half + 2)^2 window around each query point."""
+    x0, dx, y0, dy = axes
+    n0, n1 = shape
+    a0 = np.floor((query[:, 0] - x0) / dx).astype(np.int64)
+    b0 = np.floor((query[:, 1] - y0) / dy).astype(np.int64)
+    off = np.arange(-half, half + 2)
+    a = a0[:, None, None] + off[None, :, None]
+    b = b0[:, None, None] + off[None, None, :]
+    ok = (a >= 0) & (a < n0) & (b >= 0) & (b < n1)
+    flat = np.where(ok, a * n1 + b, -1).reshape(query.shape[0], -1)
+    # distance from the query to the nearest point NOT covered by the window (outside lattice bounds nothing is missing)
+    lo_a, hi_a = a0 - half, a0 + half + 1
+    lo_b, hi_b = b0 - half, b0 + half + 1
+    big = np.inf
+    gap = np.minimum.reduce([
+        np.where(lo_a > 0, query[:, 0] - (x0 + (lo_a - 1) * dx), big), np.where(hi_a < n0 - 1, (x0 + (hi_a + 1) * dx) - query[:, 0], big),
+        np.where(lo_b > 0, query[:, 1] - (y0 + (lo_b - 1) * dy), big), np.where(hi_b < n1 - 1, (y0 + (hi_b + 1) * dy) - query[:, 1], big),
+    ])
+    return flat, gap
+
+
+def knn_lattice(points: np.ndarray, shape, query: np.ndarray, k: int, half: int = 1):
+    """Indices (n_query, k) of the k nearest ``points`` (a regular lattice of ``shape``) of every query point: the set
+    scipy's ``KDTree(points).query(query, k)`` returns.  Falls back to the tree for queries it cannot decide identically."""
+    axes = _lattice_axes(points, shape)
+    if axes is None or points.shape[0] < k:
+        return KDTree(points).query(query, k)[1].reshape(query.shape[0], k)
+    flat, gap = _window_candidates(query, axes, shape, half)
+    cand = points[np.maximum(flat, 0)]
+    d0, d1 = cand[..., 0] - query[:, None, 0], cand[..., 1] - query[:, None, 1]
+    dist2 = np.where(flat >= 0, d0 * d0 + d1 * d1, np.inf)
+    kk = min(k + 1, dist2.shape[1])
+    part = np.argpartition(dist2, kk - 1, axis=1)[:, :kk]                       # the k + 1 smallest, unordered
+    order = np.take_along_axis(part, np.argsort(np.take_along_axis(dist2, part, axis=1), axis=1, kind="stable"), axis=1)
+    dsort = np.take_along_axis(dist2, order, axis=1)
+    out = np.take_along_axis(flat, order[:, :k], axis=1)
+    # undecidable here: fewer than k candidates, a tie between the k-th and the (k+1)-th, or a k-th neighbour farther away than
+    # the nearest lattice line outside the window (relative slack: the tree's distances carry their own rounding)
+    kth = dsort[:, k - 1]
+    nxt = dsort[:, k] if dsort.shape[1] > k else np.full_like(kth, np.inf)
+    with np.errstate(invalid="ignore"):   # inf - inf where a window holds fewer than k + 1 lattice points
+        bad = ~np.isfinite(kth) | ~(nxt - kth > 1e-9 * np.maximum(kth, 1e-300)) | (np.sqrt(kth) * (1 + 1e-9) >= gap)
+    if bad.any():
+        out[bad] = KDTree(points).query(query[bad], k)[1].reshape(int(bad.sum()), k)
+    return out
+
+
+def ball_lattice(points: np.ndarray, shape, query: np.ndarray, radius: float):
+    """(query index, point index) pairs with |point - query| <= radius for lattice ``points``: the pairs scipy's
+    ``KDTree(points).query_ball_point(query, radius)`` lists.  Queries with a point within rounding distance of the sphere
+    are decided by the tree."""
+    axes = _lattice_axes(points, shape)
+    if axes is None:
+        neigh = KDTree(points).query_ball_point(query, radius)
+        return np.repeat(np.arange(query.shape[0]), [len(x) for x in neigh]), np.concatenate([np.asarray(x, dtype=np.int64) for x in neigh])
+    half = int(math.ceil(radius / min(axes[1], axes[3]))) + 1
+    flat, _ = _window_candidates(query, axes, shape, half)
+    cand = points[np.maximum(flat, 0)]
+    d0, d1 = cand[..., 0] - query[:, None, 0], cand[..., 1] - query[:, None, 1]
+    dist = np.sqrt(np.where(flat >= 0, d0 * d0 + d1 * d1, np.inf))
+    inside = dist <= radius
+    edge_case = (np.abs(dist - radius) <= 1e-9 * radius).any(axis=1)
+    qi, ci = np.nonzero(inside & ~edge_case[:, None])
+    q_all, p_all = [qi], [flat[qi, ci]]
+    if edge_case.any():
+        rows = np.nonzero(edge_case)[0]
+        neigh = KDTree(points).query_ball_point(query[rows], radius)
+        q_all.append(np.repeat(rows, [len(x) for x in neigh]))
+        p_all.append(np.concatenate([np.asarray(x, dtype=np.int64) for x in neigh]) if len(rows) else np.zeros(0, np.int64))
+    return np.concatenate(q_all), np.concatenate(p_all).astype(np.int64)
 
 
 def _sender_major(send_idx, rec_idx, length, vdiff):
@@ -124,7 +229,7 @@ def create_regular_grid_graph(
             lo = lower.reshape(-1, 2)
             up = upper.reshape(-1, 2)
             # each lower node -> its single nearest upper node (create_graph.py:488-509)
-            _, nearest = KDTree(up).query(lo, 1)
+            nearest = knn_lattice(up, upper.shape[:2], lo, 1)[:, 0]
             vd = lo - up[nearest]
             length = np.sqrt(np.sum(vd**2, axis=1))
             ei, feat = _sender_major(np.arange(lo.shape[0]), nearest, length, vd)
@@ -176,17 +281,14 @@ def create_regular_grid_graph(
     p10 = bottom_pos[n0]  # node (0, 1, 0)
     dm = np.sqrt(np.sum((p10 - p00) ** 2))
     grid_pos = xy.reshape(-1, 2)  # flat index i * Ny + j
-    kdt_g = KDTree(grid_pos)
-    neigh = kdt_g.query_ball_point(bottom_pos, dm * DM_SCALE)
-    rec = np.repeat(np.arange(bottom_pos.shape[0]), [len(x) for x in neigh])
-    send = np.concatenate([np.asarray(x, dtype=np.int64) for x in neigh])
+    rec, send = ball_lattice(grid_pos, (Nx, Ny), bottom_pos, dm * DM_SCALE)
     vd = grid_pos[send] - bottom_pos[rec]
     out["g2m_edge_index"], out["g2m_features"] = _sender_major(
         send, rec, np.sqrt(np.sum(vd**2, axis=1)), vd
     )
 
     # ---- mesh2grid: 4 nearest bottom mesh nodes of each grid node (:780-793)
-    _, nn4 = KDTree(bottom_pos).query(grid_pos, 4)
+    nn4 = knn_lattice(bottom_pos, (n0, n0), grid_pos, 4)
     rec = np.repeat(np.arange(grid_pos.shape[0]), 4)
     send = nn4.reshape(-1)
     vd = bottom_pos[send] - grid_pos[rec]
@@ -208,8 +310,9 @@ def regular_grid_xy(nx_grid: int, ny_grid: int, spacing: float = 2500.0) -> np.n
 _LIST_KEYS = ("m2m", "mesh_up", "mesh_down")
 
 
-def save_graph(graph_dir: str | os.PathLike, raw: dict) -> None:
-    """Write the reference's file set (create_graph.py:132-166, 688-690, 857-862)."""
+def save_graph(graph_dir: str | os.PathLike, raw: dict, with_layouts: bool = False) -> None:
+    """Write the reference's file set (create_graph.py:132-166, 688-690, 857-862); ``with_layouts`` adds ``edge_layouts.pt``
+    (the MI355X-side CSR / CSC / tile layouts of every edge set, see ``write_edge_layouts``)."""
     graph_dir = Path(graph_dir)
     graph_dir.mkdir(parents=True, exist_ok=True)
     for name in ("g2m", "m2g"):
@@ -222,6 +325,8 @@ def save_graph(graph_dir: str | os.PathLike, raw: dict) -> None:
     torch.save(list(raw["mesh_features"]), graph_dir / "mesh_features.pt")
     with open(graph_dir / METAINFO_FILENAME, "w", encoding="utf-8") as fp:
         yaml.dump({"spec_version": GRAPH_SPEC_VERSION}, fp)
+    if with_layouts:
+        write_edge_layouts(graph_dir)
 
 
 def read_graph_files(graph_dir: str | os.PathLike) -> dict:
@@ -349,8 +454,12 @@ def normalise_graph(raw: dict, mesh_node_features_scaling: float):
 
 def load_graph(graph_dir, mesh_node_features_scaling: float):
     """Mirror of ``utils.load_graph`` (utils/graph.py:146-422): spec-0.1.0 graphs and, with a RuntimeWarning, the legacy
-    pre-spec format (no metainfo file: offset node labels, pre-normalised mesh coordinates)."""
-    return normalise_graph(read_graph_files(graph_dir), mesh_node_features_scaling)
+    pre-spec format (no metainfo file: offset node labels, pre-normalised mesh coordinates).  If the directory also holds
+    ``edge_layouts.pt`` (``save_graph(..., with_layouts=True)`` / ``write_edge_layouts``), the int32 CSR / CSC views and tile
+    schedules of its edge sets are loaded with it, so the layers built on this graph skip the host-side sorting."""
+    out = normalise_graph(read_graph_files(graph_dir), mesh_node_features_scaling)
+    preload_edge_layouts(graph_dir)
+    return out
 
 
 # --------------------------------------------------------------------------
@@ -489,3 +598,101 @@ def build_tile_schedule(rowptr: torch.Tensor, tile_rows: int = TILE_ROWS):
     flush()
     t = torch.tensor(tiles, dtype=torch.int64).reshape(-1, 4).to(torch.int32)
     return t.contiguous(), has_split
+
+
+# --------------------------------------------------------------------------
+# edge layouts: built once per distinct edge set, optionally stored beside the graph files
+#
+# Every InteractionNet needs the CSR / CSC views and the tile schedule of its edge set.  A model builds many layers on the
+# same edge index (the 4-8 processor layers on m2m, Hi-LAM's per-level stacks), and a training run re-reads the same graph
+# directory every time: the layout is therefore cached by CONTENT (sha1 of the int64 edge index + the node counts) and can be
+# written next to the reference's files (``edge_layouts.pt``: a file the reference's loader does not look for, so the
+# directory stays a valid spec-v0.1.0 graph) -- ``load_graph`` then hands the layers ready-made int32 CSR / CSC / tiles.
+# --------------------------------------------------------------------------
+EDGE_LAYOUT_FILENAME = "edge_layouts.pt"
+_LAYOUT_CACHE: dict = {}
+_LAYOUT_FIELDS = ("perm", "send", "rec", "rowptr", "colptr", "cperm", "inv_deg")
+
+
+def edge_layout_key(edge_index: torch.Tensor, num_send: int, num_rec: int) -> str:
+    import hashlib
+
+    ei = edge_index.detach().cpu().to(torch.int64).contiguous()
+    h = hashlib.sha1(ei.numpy().tobytes())
+    h.update(f"{tuple(ei.shape)}|{int(num_send)}|{int(num_rec)}|{TILE_ROWS}".encode())
+    return h.hexdigest()
+
+
+def edge_layout(edge_index: torch.Tensor, num_send: int | None = None, num_rec: int | None = None):
+    """(EdgeCSR on the host, tiles (ntiles, 4) int32, has_split) of an edge set: from the content cache (filled by earlier
+    layers on the same edges or by ``load_graph`` from ``edge_layouts.pt``) or built now."""
+    ei = edge_index.detach().cpu().to(torch.int64)
+    if num_rec is None:
+        num_rec = int(ei[1].max()) + 1
+    if num_send is None:
+        num_send = int(ei[0].max()) + 1
+    key = edge_layout_key(ei, num_send, num_rec)
+    hit = _LAYOUT_CACHE.get(key)
+    if hit is None:
+        csr = build_edge_csr(ei, num_send=num_send, num_rec=num_rec)
+        tiles, has_split = build_tile_schedule(csr.rowptr)
+        hit = _LAYOUT_CACHE[key] = (csr, tiles, has_split)
+    return hit
+
+
+def _layout_to_record(csr: EdgeCSR, tiles: torch.Tensor, has_split: bool) -> dict:
+    rec = {f: getattr(csr, f) for f in _LAYOUT_FIELDS}
+    rec.update(tiles=tiles, has_split=bool(has_split), num_send=csr.num_send, num_rec=csr.num_rec, num_edges=csr.num_edges,
+               max_in_degree=csr.max_in_degree)
+    return rec
+
+
+def _record_to_layout(rec: dict):
+    csr = EdgeCSR(num_send=int(rec["num_send"]), num_rec=int(rec["num_rec"]), num_edges=int(rec["num_edges"]),
+                  max_in_degree=int(rec["max_in_degree"]), **{f: rec[f] for f in _LAYOUT_FIELDS})
+    return csr, rec["tiles"], bool(rec["has_split"])
+
+
+def _graph_edge_sets(tensors: dict):
+    """(edge index, num_send, num_rec) of every edge set of a loaded graph, with the node counts the model's layers use
+    (InteractionNet: num_rec = max receiver + 1, senders = rows of the sender tensor = max sender + 1 for these graphs)."""
+    out = []
+    for name in ("g2m_edge_index", "m2g_edge_index", "m2m_edge_index", "mesh_up_edge_index", "mesh_down_edge_index"):
+        v = tensors.get(name)
+        if v is None:
+            continue
+        for ei in (v if isinstance(v, (list, tuple)) else [v]):
+            if torch.is_tensor(ei) and ei.numel() > 0:
+                out.append((ei, int(ei[0].max()) + 1, int(ei[1].max()) + 1))
+    return out
+
+
+def write_edge_layouts(graph_dir, mesh_node_features_scaling: float = 1.0) -> Path:
+    """Build the layout of every edge set of the graph stored in ``graph_dir`` and write them to ``edge_layouts.pt``."""
+    graph_dir = Path(graph_dir)
+    _, tensors = normalise_graph(read_graph_files(graph_dir), mesh_node_features_scaling)
+    records = {}
+    for ei, ns, nr in _graph_edge_sets(tensors):
+        key = edge_layout_key(ei, ns, nr)
+        if key not in records:
+            records[key] = _layout_to_record(*edge_layout(ei, ns, nr))
+    path = graph_dir / EDGE_LAYOUT_FILENAME
+    torch.save({"tile_rows": TILE_ROWS, "layouts": records}, path)
+    return path
+
+
+def preload_edge_layouts(graph_dir) -> int:
+    """Put the layouts stored beside a graph into the content cache (they are looked up by the hash of the edge index a layer
+    is built with, so a stale or foreign file is simply never hit).  Returns the number of layouts read."""
+    path = Path(graph_dir) / EDGE_LAYOUT_FILENAME
+    if not path.exists():
+        return 0
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    if int(blob.get("tile_rows", -1)) != TILE_ROWS:
+        return 0
+    n = 0
+    for key, rec in blob["layouts"].items():
+        if key not in _LAYOUT_CACHE:
+            _LAYOUT_CACHE[key] = _record_to_layout(rec)
+            n += 1
+    return n

@@ -133,3 +133,70 @@ def test_edge_csr_structure():
         assert torch.all(seg == s)
     deg = torch.bincount(ei[1], minlength=csr.num_rec).clamp(min=1).float()
     assert torch.allclose(csr.inv_deg, 1.0 / deg)
+
+
+@pytest.mark.parametrize("n0,n1,dx,dy", [(81, 81, 7315.0, 8241.0), (9, 9, 1.0, 1.0), (30, 27, 2.0, 0.7), (5, 40, 3.0, 1.0), (2, 2, 1.0, 1.0)])
+def test_lattice_neighbour_searches_equal_the_kd_tree(n0, n1, dx, dy):
+    """graph.knn_lattice / graph.ball_lattice (closed-form index windows, no KD-tree) return exactly the neighbour SETS of
+    scipy.spatial.KDTree -- the class create_graph.py:488, 731, 777 queries -- on anisotropic and offset lattices, for
+    queries outside the lattice and for queries that sit exactly between lattice points (ties go to the tree)."""
+    import numpy as np
+    from scipy.spatial import KDTree
+
+    from neural_lam_amd import graph as G
+
+    def lattice(m0, m1, ddx, ddy):
+        ii, jj = np.meshgrid(np.arange(m0), np.arange(m1), indexing="ij")
+        return np.stack([0.3 + ii * ddx, -1.0 + jj * ddy], -1).reshape(-1, 2)
+
+    rng = np.random.default_rng(n0 * 100 + n1)
+    pts = lattice(n0, n1, dx, dy)
+    q = np.concatenate([rng.uniform([-2 * dx, -2 * dy], [(n0 + 1) * dx, (n1 + 1) * dy], size=(3000, 2)),
+                        lattice(2 * n0, 2 * n1, dx / 2, dy / 2)[:3000]])   # half-cell points: exact distance ties
+    tree = KDTree(pts)
+    for k in (1, 4):
+        if k > pts.shape[0]:
+            continue
+        a, b = G.knn_lattice(pts, (n0, n1), q, k), tree.query(q, k)[1].reshape(len(q), k)
+        assert (np.sort(a, 1) == np.sort(b, 1)).all()
+    for r in (0.67 * dx, 1.5 * max(dx, dy), 0.5 * dx):   # 0.5 dx: lattice points exactly on the sphere
+        qi, pi = G.ball_lattice(pts, (n0, n1), q, r)
+        ref = tree.query_ball_point(q, r)
+        assert set(zip(qi.tolist(), pi.tolist())) == {(i, j) for i, x in enumerate(ref) for j in x}
+    # a non-lattice point set takes the tree itself
+    jit = pts + rng.normal(size=pts.shape) * 0.2 * min(dx, dy)
+    assert G._lattice_axes(jit, (n0, n1)) is None
+    if jit.shape[0] >= 4:
+        assert (np.sort(G.knn_lattice(jit, (n0, n1), q[:200], 4), 1) == np.sort(KDTree(jit).query(q[:200], 4)[1], 1)).all()
+
+
+def test_edge_layouts_travel_with_the_graph_directory(tmp_path):
+    """``save_graph(..., with_layouts=True)`` writes edge_layouts.pt beside the reference's files (the reference's loader,
+    utils/graph.py:146-422, reads its own file names only, so the directory stays a valid spec-v0.1.0 graph); ``load_graph``
+    preloads the int32 CSR / CSC views + tile schedules, and layers built on the loaded edge sets take them from the content
+    cache instead of sorting on the host -- bit-identical to a fresh build."""
+    from neural_lam_amd import gnn_layers as hl
+
+    raw = G.create_regular_grid_graph(G.regular_grid_xy(40, 36), n_max_levels=3, hierarchical=True)
+    G.save_graph(tmp_path, raw, with_layouts=True)
+    assert (tmp_path / G.EDGE_LAYOUT_FILENAME).exists() and (tmp_path / G.METAINFO_FILENAME).exists()
+    G._LAYOUT_CACHE.clear()
+    _, tensors = G.load_graph(tmp_path, 100.0)
+    sets = G._graph_edge_sets(tensors)
+    assert len(G._LAYOUT_CACHE) == len({G.edge_layout_key(*s) for s in sets}) > 0
+    before = dict(G._LAYOUT_CACHE)
+    for ei, ns, nr in sets:
+        layer = hl.InteractionNet(ei, 8)
+        csr, tiles, has_split = layer._host_csr
+        assert G._LAYOUT_CACHE == before                      # nothing was rebuilt
+        ref = G.build_edge_csr(ei, num_send=ns, num_rec=nr)
+        ref_tiles, ref_split = G.build_tile_schedule(ref.rowptr)
+        assert all(torch.equal(getattr(csr, f), getattr(ref, f)) for f in G._LAYOUT_FIELDS)
+        assert torch.equal(tiles, ref_tiles) and has_split == ref_split and csr.max_in_degree == ref.max_in_degree
+    # layers on the same edge set share the host layout object (and with it one device copy)
+    a, b = hl.InteractionNet(sets[0][0], 8), hl.InteractionNet(sets[0][0].clone(), 16)
+    assert a._host_csr[0] is b._host_csr[0]
+    # a different edge set is not served by a stale entry
+    other = sets[0][0].clone()
+    other[1, 0] = (other[1, 0] + 1) % (int(other[1].max()) + 1)
+    assert G.edge_layout_key(other, sets[0][1], sets[0][2]) not in before
