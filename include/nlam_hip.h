@@ -79,6 +79,10 @@ extern "C" {
  * `dz1` is unused, `vec_partials` has SEVEN rows per workgroup: db1, db2, dgamma, dbeta, dW1[:, 0], dW1[:, 1], dW1[:, 2].
  * z1 may be NULL (then `b1` is required): the forward of such an MLP need not save its pre-activation. */
 #define NLAM_F_LEAF_WGRAD 32u
+/* wide launches (a width above 64) of nlam_mlp_fwd / nlam_mlp_bwd: `wpack` already holds the packed weights of exactly this
+ * launch -- written by nlam_pack_records from the records nlam_mlp_*_pack_records gave for it, since the weights last
+ * changed -- so the pack launch in front of the kernel is skipped. */
+#define NLAM_F_WPACK_READY 64u
 /* matrix path of the GEMMs (bits 8-9): 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains);
  * n = 1..3: operands split into n bf16 terms on the bf16 matrix cores, fp32 accumulate
  * (1 = plain bf16 operands, 2 = ~2^-16 product error, 3 = fp32-class ~2^-24).  Shapes the
@@ -270,6 +274,19 @@ typedef struct {
     uint32_t flags;        /* NLAM_F_PRE_ADD | NLAM_F_MM_BF16X1..3 */
 } nlam_pack_job_t;
 int64_t nlam_mlp_pack_floats(const nlam_pack_job_t* job, int32_t which);
+/* The same idea for the WIDE kernels, whose `wpack` scratch is packed per launch by default (a pack kernel in front of every
+ * wide forward / backward launch: 184 + 147 launches per Hi-LAM d = 128 step).  nlam_mlp_fwd_pack_records /
+ * nlam_mlp_bwd_pack_records describe, as opaque 64-byte records, the pack jobs that fill p->wpack for exactly the launch `p`
+ * (same shapes, rows, tiles, batch, flags, dmode: they select the kernel family and with it the layout); they return the
+ * number of records (<= 4; 0 for a narrow launch) and the record kind (0: fp32 A-fragment order, 1 / 3: one / three bf16
+ * terms).  nlam_pack_records runs a table of records of ONE kind (device memory) in one launch.  A launch whose wpack was
+ * filled this way passes NLAM_F_WPACK_READY. */
+typedef struct {
+    unsigned char bytes[64];
+} nlam_pack_rec_t;
+int32_t nlam_mlp_fwd_pack_records(const nlam_mlp_fwd_t* p, nlam_pack_rec_t* out, int32_t cap, int32_t* kind);
+int32_t nlam_mlp_bwd_pack_records(const nlam_mlp_bwd_t* p, nlam_pack_rec_t* out, int32_t cap, int32_t* kind);
+int32_t nlam_pack_records(const nlam_pack_rec_t* recs_device, int32_t n, int32_t kind, void* hip_stream);
 /* `jobs_device`: the job table in DEVICE memory (addresses are stable, so it is uploaded once); one launch packs all */
 int32_t nlam_mlp_pack(const nlam_pack_job_t* jobs_device, int32_t njobs, void* hip_stream);
 

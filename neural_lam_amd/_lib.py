@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ["NLAM_LIB"]) if os.environ.get("NLAM_LIB") else HERE 
 NLAM_MAX_SRC = 3
 NLAM_MAX_CAT = 6
 NLAM_MAX_GROUP = 8
-F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD, F_LEAF_WGRAD = 1, 2, 4, 8, 16, 32
+F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD, F_LEAF_WGRAD, F_WPACK_READY = 1, 2, 4, 8, 16, 32, 64
 TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning keys (include/nlam_hip.h)
 TUNE_WGRAD_CHUNKS = 2
 TUNE_LIN_WGS = 3
@@ -39,6 +39,9 @@ EXPORTS = [
     "nlam_mlp_bwd",
     "nlam_mlp_pack_floats",
     "nlam_mlp_pack",
+    "nlam_mlp_fwd_pack_records",
+    "nlam_mlp_bwd_pack_records",
+    "nlam_pack_records",
     "nlam_wgrad",
     "nlam_segment_sum",
     "nlam_segment_sum_acc",
@@ -274,6 +277,10 @@ class PackJob(C.Structure):
     ]
 
 
+class PackRec(C.Structure):
+    _fields_ = [("bytes", C.c_ubyte * 64)]
+
+
 ABI_VERSION = 4
 _lib = None
 
@@ -323,6 +330,12 @@ def load():
     lib.nlam_mlp_pack_floats.restype = i64
     lib.nlam_mlp_pack.argtypes = [vp, i32, vp]
     lib.nlam_mlp_pack.restype = i32
+    lib.nlam_mlp_fwd_pack_records.argtypes = [C.POINTER(MlpFwd), C.POINTER(PackRec), i32, C.POINTER(C.c_int32)]
+    lib.nlam_mlp_fwd_pack_records.restype = i32
+    lib.nlam_mlp_bwd_pack_records.argtypes = [C.POINTER(MlpBwd), C.POINTER(PackRec), i32, C.POINTER(C.c_int32)]
+    lib.nlam_mlp_bwd_pack_records.restype = i32
+    lib.nlam_pack_records.argtypes = [vp, i32, i32, vp]
+    lib.nlam_pack_records.restype = i32
     lib.nlam_mlp_fwd.argtypes = [C.POINTER(MlpFwd), vp]
     lib.nlam_mlp_fwd.restype = i32
     lib.nlam_mlp_bwd.argtypes = [C.POINTER(MlpBwd), vp]

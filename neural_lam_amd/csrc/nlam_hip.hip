@@ -32,6 +32,9 @@
 #include <type_traits>
 
 #include "../../include/nlam_hip.h"
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
 
 // ---------------------------------------------------------------------------
 // Translation-unit slices.  Every kernel here is a template that is instantiated only where a launcher names it, so
@@ -100,6 +103,40 @@ __device__ unsigned long long g_phase_cycles[16];
 #endif
 
 namespace {
+
+// ---------------------------------------------------------------------------
+// roctx ranges around every launching entry point (the reference has no tracing of its own; rocprofv3
+// --marker-trace shows these next to the kernels).  The marker library is looked up at run time -- the product does not link
+// against the profiler -- and only when NLAM_ROCTX=1: otherwise a range is one predictable branch.
+// ---------------------------------------------------------------------------
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* on = getenv("NLAM_ROCTX");
+        if (on == nullptr || on[0] != '1') return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h == nullptr) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h == nullptr) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push == nullptr || pop == nullptr) push = nullptr, pop = nullptr;
+    }
+};
+inline const Roctx& roctx() {
+    static const Roctx r;
+    return r;
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(roctx().push != nullptr) {
+        if (on) roctx().push(name);
+    }
+    ~RoctxRange() {
+        if (on) roctx().pop();
+    }
+};
+#define NLAM_RANGE(name) RoctxRange nlam_range_(name)
 
 constexpr int kWavesPerBlock = 8;                  // backward kernels: 512 threads, two waves per SIMD
 #ifndef NLAM_FWD_WAVES
@@ -3611,6 +3648,149 @@ void group_blocks(const long* tiles, int n, int* blocks) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// pack jobs of the wide launches (weights -> MFMA A-fragment order in `wpack`): built here so that the launchers (slices 3 / 4)
+// and the pre-pack API (nlam_mlp_*_pack_records, slice 1) describe one launch's scratch identically.
+// ---------------------------------------------------------------------------
+long build_fwd_wbf_jobs(const nlam_mlp_fwd_t* p, int wns, packbf_jobs_t& jobs) {
+    const WbfPlan pl = fwd_wbf_choose(p, wns);
+    const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
+    const int TK1 = fwd_wbf_tk1(p, pl.kg);
+    const bool pre = (p->flags & NLAM_F_PRE_ADD) != 0;
+    const int ngemm = pre ? 1 : p->nsrc;
+    int kin = 0;
+    for (int s = 0; s < ngemm; ++s) kin += p->src[s].width;
+    if (pre && p->ldw1 > 0) kin = p->ldw1;   // floats between rows of W1
+    u32x4* A1 = reinterpret_cast<u32x4*>(p->wpack);
+    jobs.njobs = 0;
+    int off = 0, g0 = 0;
+    long most = 0;
+    for (int s = 0; s < ngemm; ++s) {
+        const int w = p->src[s].width;
+        const int ng = ((w + 16 * pl.kg - 1) / (16 * pl.kg)) * pl.kg;
+        jobs.job[jobs.njobs++] = {p->W1 + off, (long)kin, 1L, p->hid, HBT, w, TK1, g0, ng, 0, A1};
+        off += w;
+        g0 += ng;
+        if ((long)HBT * ng * 64 > most) most = (long)HBT * ng * 64;
+    }
+    jobs.job[jobs.njobs++] = {p->W2, (long)p->hid, 1L, p->dout, OBT, p->hid, 2 * HBT, 0, 2 * HBT, 1,
+                              A1 + (size_t)HBT * TK1 * wns * 64};
+    if ((long)OBT * 2 * HBT * 64 > most) most = (long)OBT * 2 * HBT * 64;
+    return most;
+}
+
+long build_bwd_wbf_jobs(const nlam_mlp_bwd_t* p, int wns, packbf_jobs_t& jobs) {
+    const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
+    const bool pre = (p->flags & NLAM_F_PRE_ADD) != 0;
+    int kin = 0;
+    for (int s = 0; s < (pre ? 1 : p->nsrc); ++s) kin += p->src[s].width;
+    if (pre && p->ldw1 > 0) kin = p->ldw1;
+    const int TKA = 2 * OBT, TKB = 2 * HBT;
+    u32x4* base = reinterpret_cast<u32x4*>(p->wpack);
+    jobs.njobs = 0;
+    long most = (long)HBT * TKA * 64;
+    // A[m = hidden][k = out] = W2[k][m]; K in slot order (the B fragments come straight from accumulator layout)
+    jobs.job[jobs.njobs++] = {p->W2, 1L, (long)p->hid, p->hid, HBT, p->dout, TKA, 0, TKA, 1, base};
+    size_t woff = (size_t)HBT * TKA * wns * 64;
+    int off = 0;
+    for (int s = 0; s < p->nsrc; ++s) {
+        const int w = p->src[s].width;
+        if (p->dmode[s] != 0 && (s == 0 || !pre)) {
+            const int SB = (w + 31) / 32;
+            // A[m = source column][k = hidden] = W1[k][off + m]
+            jobs.job[jobs.njobs++] = {p->W1 + off, 1L, (long)kin, w, SB, p->hid, TKB, 0, TKB, 1, base + woff};
+            woff += (size_t)SB * TKB * wns * 64;
+            if ((long)SB * TKB * 64 > most) most = (long)SB * TKB * 64;
+        }
+        off += w;
+    }
+    return most;
+}
+
+void build_fwd_wide_jobs(const nlam_mlp_fwd_t* p, pack_jobs_t& jobs) {
+    const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32, NQ1 = fwd_nq1(p);
+    int kin = 0;
+    for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
+    jobs.njobs = 0;
+    int off = 0, q0 = 0;
+    for (int s = 0; s < p->nsrc; ++s) {
+        const int w = p->src[s].width;
+        jobs.job[jobs.njobs++] = {p->W1 + off, (long)kin, 1L, p->hid, HBT, w, NQ1 * 4, q0 * 4, p->wpack};
+        off += w;
+        q0 += (w + 31) / 32;
+    }
+    jobs.job[jobs.njobs++] = {p->W2, (long)p->hid, 1L, p->dout, OBT, p->hid, HBT * 4, 0, p->wpack + (size_t)HBT * NQ1 * 1024};
+}
+
+void build_bwd_wide_jobs(const nlam_mlp_bwd_t* p, pack_jobs_t& jobs) {
+    const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
+    int kin = 0;
+    for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
+    jobs.njobs = 0;
+    // A[m = hidden][k = out] = W2[k][m]
+    jobs.job[jobs.njobs++] = {p->W2, 1L, (long)p->hid, p->hid, HBT, p->dout, OBT * 4, 0, p->wpack};
+    size_t woff = (size_t)HBT * OBT * 1024;
+    int off = 0;
+    for (int s = 0; s < p->nsrc; ++s) {
+        const int w = p->src[s].width;
+        if (p->dmode[s] != 0) {
+            const int SB = (w + 31) / 32;
+            // A[m = source column][k = hidden] = W1[k][off + m]
+            jobs.job[jobs.njobs++] = {p->W1 + off, 1L, (long)kin, w, SB, p->hid, HBT * 4, 0, p->wpack + woff};
+            woff += (size_t)SB * HBT * 1024;
+        }
+        off += w;
+    }
+}
+
+// the same pack kernels driven by a job TABLE in device memory (one 64-byte record per job): every wide MLP of a model packed
+// by ONE launch per step (nlam_pack_records) instead of a pack launch in front of each of its forward / backward launches
+static_assert(sizeof(pack_job_t) <= 64 && sizeof(packbf_job_t) <= 64, "pack records are 64 bytes");
+
+__global__ void pack_a_table_kernel(const nlam_pack_rec_t* recs) {
+    const pack_job_t jb = *reinterpret_cast<const pack_job_t*>(recs + blockIdx.y);
+    const int ng = round_up((jb.Kw + 7) >> 3, 4);
+    const long total = (long)jb.MB * ng * 64;
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(s & 63);
+        const long rest = s >> 6;
+        const int t = (int)(rest % ng);
+        const int mb = (int)(rest / ng);
+        const int m = mb * 32 + (lane & 31);
+        const int kb = 8 * t + 4 * (lane >> 5);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < jb.M) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (kb + c < jb.Kw) v[c] = jb.W[(long)m * jb.ldm + (long)(kb + c) * jb.ldk];
+        }
+        *reinterpret_cast<f32x4*>(&jb.dst[(((size_t)mb * jb.T + jb.t0 + t) * 64 + lane) * 4]) = v;
+    }
+}
+
+template <int NS>
+__global__ void pack_bf_table_kernel(const nlam_pack_rec_t* recs) {
+    const packbf_job_t jb = *reinterpret_cast<const packbf_job_t*>(recs + blockIdx.y);
+    const long total = (long)jb.MB * jb.ng * 64;
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(s & 63);
+        const long rest = s >> 6;
+        const int g = (int)(rest % jb.ng);
+        const int mb = (int)(rest / jb.ng);
+        const int m = mb * 32 + (lane & 31);
+        const int hi = lane >> 5;
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = jb.perm2 ? 32 * (g >> 1) + 16 * (g & 1) + (q & 3) + 8 * (q >> 2) + 4 * hi : 16 * g + 8 * hi + q;
+            x[q] = (m < jb.M && k < jb.Kw) ? jb.W[(long)m * jb.ldm + (long)k * jb.ldk] : 0.f;
+        }
+        const BfFrag<NS> f = split8<NS>(x);
+#pragma unroll
+        for (int pa = 0; pa < NS; ++pa) jb.dst[(((size_t)mb * jb.TK + jb.g0 + g) * NS + pa) * 64 + lane] = f.t[pa];
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -3668,10 +3848,82 @@ int64_t nlam_mlp_pack_floats(const nlam_pack_job_t* job, int32_t which) {
 }
 
 int32_t nlam_mlp_pack(const nlam_pack_job_t* jobs_device, int32_t njobs, void* hip_stream) {
+    NLAM_RANGE("nlam_mlp_pack");
     if (jobs_device == nullptr || njobs < 0 || njobs > 65535) return NLAM_EINVAL;
     if (njobs == 0) return 0;
     // the largest piece (a 64 x 192 first layer) is 1 536 lane items: four 256-thread blocks per job
     hipLaunchKernelGGL(mlp_pack_kernel, dim3(4, njobs), dim3(256), 0, (hipStream_t)hip_stream, jobs_device);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_mlp_fwd_pack_records(const nlam_mlp_fwd_t* p, nlam_pack_rec_t* out, int32_t cap, int32_t* kind) {
+    if (p == nullptr || out == nullptr || kind == nullptr || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
+    if (!fwd_is_wide(p)) return 0;
+    if (p->wpack == nullptr || p->wpack_floats < nlam_mlp_fwd_wpack_floats(p)) return NLAM_EINVAL;
+    int n = 0;
+    const int wns = fwd_wbf_ns(p);
+    if (wns > 0) {
+        packbf_jobs_t jobs;
+        build_fwd_wbf_jobs(p, wns, jobs);
+        if (jobs.njobs > cap) return NLAM_EINVAL;
+        for (; n < jobs.njobs; ++n) {
+            memset(out + n, 0, sizeof(nlam_pack_rec_t));
+            memcpy(out + n, &jobs.job[n], sizeof(packbf_job_t));
+        }
+        *kind = wns;
+    } else {
+        if ((p->flags & NLAM_F_PRE_ADD) || wide_cfg(p->hid > p->dout ? p->hid : p->dout).nwv == 0) return NLAM_EUNSUP;
+        pack_jobs_t jobs;
+        build_fwd_wide_jobs(p, jobs);
+        if (jobs.njobs > cap) return NLAM_EINVAL;
+        for (; n < jobs.njobs; ++n) {
+            memset(out + n, 0, sizeof(nlam_pack_rec_t));
+            memcpy(out + n, &jobs.job[n], sizeof(pack_job_t));
+        }
+        *kind = 0;
+    }
+    return n;
+}
+
+int32_t nlam_mlp_bwd_pack_records(const nlam_mlp_bwd_t* p, nlam_pack_rec_t* out, int32_t cap, int32_t* kind) {
+    if (p == nullptr || out == nullptr || kind == nullptr || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
+    if (!bwd_is_wide(p)) return 0;
+    if (p->wpack == nullptr || p->wpack_floats < nlam_mlp_bwd_wpack_floats(p)) return NLAM_EINVAL;
+    int n = 0;
+    const int wns = bwd_wbf_ns(p);
+    if (wns > 0) {
+        packbf_jobs_t jobs;
+        build_bwd_wbf_jobs(p, wns, jobs);
+        if (jobs.njobs > cap) return NLAM_EINVAL;
+        for (; n < jobs.njobs; ++n) {
+            memset(out + n, 0, sizeof(nlam_pack_rec_t));
+            memcpy(out + n, &jobs.job[n], sizeof(packbf_job_t));
+        }
+        *kind = wns;
+    } else {
+        if ((p->flags & NLAM_F_PRE_ADD) || wide_cfg(bwd_wide_maxw(p)).nwv == 0) return NLAM_EUNSUP;
+        pack_jobs_t jobs;
+        build_bwd_wide_jobs(p, jobs);
+        if (jobs.njobs > cap) return NLAM_EINVAL;
+        for (; n < jobs.njobs; ++n) {
+            memset(out + n, 0, sizeof(nlam_pack_rec_t));
+            memcpy(out + n, &jobs.job[n], sizeof(pack_job_t));
+        }
+        *kind = 0;
+    }
+    return n;
+}
+
+int32_t nlam_pack_records(const nlam_pack_rec_t* recs_device, int32_t n, int32_t kind, void* hip_stream) {
+    NLAM_RANGE("nlam_pack_records");
+    if (recs_device == nullptr || n < 0 || n > 65535 || (kind != 0 && kind != 1 && kind != 3)) return NLAM_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    // the largest job (a 512 x 1536 first layer in A-fragment order) has 16 x 96 x 64 lane items: 16 blocks of 256 threads walk it
+    const dim3 grid(16, n), block(256);
+    if (kind == 0) hipLaunchKernelGGL(pack_a_table_kernel, grid, block, 0, stream, recs_device);
+    else if (kind == 1) hipLaunchKernelGGL(pack_bf_table_kernel<1>, grid, block, 0, stream, recs_device);
+    else hipLaunchKernelGGL(pack_bf_table_kernel<3>, grid, block, 0, stream, recs_device);
     return (int32_t)hipGetLastError();
 }
 
@@ -3695,6 +3947,8 @@ int64_t nlam_mlp_bwd_wpack_floats(const nlam_mlp_bwd_t* p) {
 
 int32_t nlam_mlp_bwd_dz2_ld(const nlam_mlp_bwd_t* p) {
     if (p == nullptr) return 0;
+    if (bwd_is_wide(p))   // split-bf16 wide kernel with a ragged output width: padded so that the W2 gradient has m % 4 == 0
+        return (p->dout % 4 != 0 && bwd_wbf_ns(p) > 0) ? ((p->dout + 31) / 32) * 32 : 0;
     return bwd_ragged_out(p) ? ((p->dout + 31) / 32) * 32 : 0;
 }
 
@@ -3775,6 +4029,7 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     } while (0)
 
 int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
+    NLAM_RANGE("nlam_mlp_fwd");
     if (p == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
     if (p->batch < 1 || p->rows < 0 || p->hid < 1 || p->dout < 1) return NLAM_EINVAL;
     if (p->aggr != nullptr && (p->rowptr == nullptr || p->tiles == nullptr)) return NLAM_EINVAL;
@@ -3816,33 +4071,14 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
     const int wns = fwd_wbf_ns(p);
     {
             const WbfPlan pl = fwd_wbf_choose(p, wns);
-            const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
-            const int TK1 = fwd_wbf_tk1(p, pl.kg);
-            const bool pre = (p->flags & NLAM_F_PRE_ADD) != 0;
-            const int ngemm = pre ? 1 : p->nsrc;
-            int kin = 0;
-            for (int s = 0; s < ngemm; ++s) kin += p->src[s].width;
-            if (pre && p->ldw1 > 0) kin = p->ldw1;   // floats between rows of W1
-            u32x4* A1 = reinterpret_cast<u32x4*>(p->wpack);
-            packbf_jobs_t jobs;
-            jobs.njobs = 0;
-            int off = 0, g0 = 0;
-            long most = 0;
-            for (int s = 0; s < ngemm; ++s) {
-                const int w = p->src[s].width;
-                const int ng = ((w + 16 * pl.kg - 1) / (16 * pl.kg)) * pl.kg;
-                jobs.job[jobs.njobs++] = {p->W1 + off, (long)kin, 1L, p->hid, HBT, w, TK1, g0, ng, 0, A1};
-                off += w;
-                g0 += ng;
-                if ((long)HBT * ng * 64 > most) most = (long)HBT * ng * 64;
+            if ((p->flags & NLAM_F_WPACK_READY) == 0) {   // else: `wpack` was filled for this step already (nlam_pack_records)
+                packbf_jobs_t jobs;
+                const long most = build_fwd_wbf_jobs(p, wns, jobs);
+                long pblocks = (most + 255) / 256;
+                if (pblocks > 1024) pblocks = 1024;
+                if (wns == 1) hipLaunchKernelGGL(pack_bf_kernel<1>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
+                else hipLaunchKernelGGL(pack_bf_kernel<3>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
             }
-            jobs.job[jobs.njobs++] = {p->W2, (long)p->hid, 1L, p->dout, OBT, p->hid, 2 * HBT, 0, 2 * HBT, 1,
-                                      A1 + (size_t)HBT * TK1 * wns * 64};
-            if ((long)OBT * 2 * HBT * 64 > most) most = (long)OBT * 2 * HBT * 64;
-            long pblocks = (most + 255) / 256;
-            if (pblocks > 1024) pblocks = 1024;
-            if (wns == 1) hipLaunchKernelGGL(pack_bf_kernel<1>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
-            else hipLaunchKernelGGL(pack_bf_kernel<3>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
             const size_t lds = fwd_wbf_lds(p, wns, pl);
             const long nsuper = (long)((p->ntiles + pl.nrt - 1) / pl.nrt) * p->batch;
             const long wcap = kNumCUs;   // one 8-wave workgroup per CU
@@ -3873,21 +4109,11 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
 int32_t nlam_detail::fwd_wide(const nlam_mlp_fwd_t* p, hipStream_t stream) {
     const WideCfg cfg = wide_cfg(p->hid > p->dout ? p->hid : p->dout);
     {
-        const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32, NQ1 = fwd_nq1(p);
-        int kin = 0;
-        for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
-        pack_jobs_t jobs;
-        jobs.njobs = 0;
-        int off = 0, q0 = 0;
-        for (int s = 0; s < p->nsrc; ++s) {
-            const int w = p->src[s].width;
-            jobs.job[jobs.njobs++] = {p->W1 + off, (long)kin, 1L, p->hid, HBT, w, NQ1 * 4, q0 * 4, p->wpack};
-            off += w;
-            q0 += (w + 31) / 32;
+        if ((p->flags & NLAM_F_WPACK_READY) == 0) {
+            pack_jobs_t jobs;
+            build_fwd_wide_jobs(p, jobs);
+            launch_pack(jobs, stream);
         }
-        jobs.job[jobs.njobs++] = {p->W2, (long)p->hid, 1L, p->dout, OBT, p->hid, HBT * 4, 0,
-                                  p->wpack + (size_t)HBT * NQ1 * 1024};
-        launch_pack(jobs, stream);
         const size_t lds = fwd_wide_lds(p, cfg.nwv);
         const int wblocks = wide_grid((long)p->ntiles * p->batch, lds, cfg.nwv);
 #define NLAM_LAUNCH_FWD_WIDE(NWV_, FB_)                                                                       \
@@ -3984,6 +4210,7 @@ extern "C" {
 
 
 int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
+    NLAM_RANGE("nlam_mlp_bwd");
     if (p == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
     if (p->z1 == nullptr) return NLAM_EINVAL;
     if (p->ln_w != nullptr && (p->xhat == nullptr || p->rstd == nullptr)) return NLAM_EINVAL;
@@ -4006,6 +4233,7 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
         if (cfg.nwv == 0) return NLAM_EUNSUP;
         const int64_t need = nlam_mlp_bwd_wpack_floats(p);
         if (p->wpack == nullptr || p->wpack_floats < need) return NLAM_EINVAL;
+        if (p->dz2_ld != nlam_mlp_bwd_dz2_ld(p)) return NLAM_EINVAL;   // the caller sized dz2 with nlam_mlp_bwd_dz2_ld
         if (bwd_wbf_ns(p) > 0) return nlam_detail::bwd_wbf(p, stream);   // split-bf16 matrix path (nlam_wbf.inc)
         return nlam_detail::bwd_wide(p, stream);
     }
@@ -4017,38 +4245,17 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
 
 #if NLAM_IN_TU(4)
 int32_t nlam_detail::bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream) {
-    const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
-    const bool pre = (p->flags & NLAM_F_PRE_ADD) != 0;
-    int kin = 0;
-    for (int s = 0; s < (pre ? 1 : p->nsrc); ++s) kin += p->src[s].width;
-    if (pre && p->ldw1 > 0) kin = p->ldw1;
     const int wns = bwd_wbf_ns(p);
     {
             const WbfBwdPlan pl = wbf_bwd_plan(bwd_wide_maxw(p));
-            const int TKA = 2 * OBT, TKB = 2 * HBT;
-            u32x4* base = reinterpret_cast<u32x4*>(p->wpack);
-            packbf_jobs_t jobs;
-            jobs.njobs = 0;
-            long most = (long)HBT * TKA * 64;
-            // A[m = hidden][k = out] = W2[k][m]; K in slot order (the B fragments come straight from accumulator layout)
-            jobs.job[jobs.njobs++] = {p->W2, 1L, (long)p->hid, p->hid, HBT, p->dout, TKA, 0, TKA, 1, base};
-            size_t woff = (size_t)HBT * TKA * wns * 64;
-            int off = 0;
-            for (int s = 0; s < p->nsrc; ++s) {
-                const int w = p->src[s].width;
-                if (p->dmode[s] != 0 && (s == 0 || !pre)) {
-                    const int SB = (w + 31) / 32;
-                    // A[m = source column][k = hidden] = W1[k][off + m]
-                    jobs.job[jobs.njobs++] = {p->W1 + off, 1L, (long)kin, w, SB, p->hid, TKB, 0, TKB, 1, base + woff};
-                    woff += (size_t)SB * TKB * wns * 64;
-                    if ((long)SB * TKB * 64 > most) most = (long)SB * TKB * 64;
-                }
-                off += w;
+            if ((p->flags & NLAM_F_WPACK_READY) == 0) {
+                packbf_jobs_t jobs;
+                const long most = build_bwd_wbf_jobs(p, wns, jobs);
+                long pblocks = (most + 255) / 256;
+                if (pblocks > 1024) pblocks = 1024;
+                if (wns == 1) hipLaunchKernelGGL(pack_bf_kernel<1>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
+                else hipLaunchKernelGGL(pack_bf_kernel<3>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
             }
-            long pblocks = (most + 255) / 256;
-            if (pblocks > 1024) pblocks = 1024;
-            if (wns == 1) hipLaunchKernelGGL(pack_bf_kernel<1>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
-            else hipLaunchKernelGGL(pack_bf_kernel<3>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
             const size_t lds = bwd_wbf_lds(p, wns, pl);
             const int wblocks = nlam_mlp_bwd_blocks(p) / pl.rg;
 #define NLAM_LAUNCH_BWD_WBF(NS_, FG_, FB_, RT_)                                                                   \
@@ -4074,27 +4281,12 @@ int32_t nlam_detail::bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream) {
 #if NLAM_IN_TU(3)
 int32_t nlam_detail::bwd_wide(const nlam_mlp_bwd_t* p, hipStream_t stream) {
     const WideCfg cfg = wide_cfg(bwd_wide_maxw(p));
-    const int HBT = (p->hid + 31) / 32, OBT = (p->dout + 31) / 32;
-    int kin = 0;
-    for (int s = 0; s < p->nsrc; ++s) kin += p->src[s].width;
     {
-        pack_jobs_t jobs;
-        jobs.njobs = 0;
-        // A[m = hidden][k = out] = W2[k][m]
-        jobs.job[jobs.njobs++] = {p->W2, 1L, (long)p->hid, p->hid, HBT, p->dout, OBT * 4, 0, p->wpack};
-        size_t woff = (size_t)HBT * OBT * 1024;
-        int off = 0;
-        for (int s = 0; s < p->nsrc; ++s) {
-            const int w = p->src[s].width;
-            if (p->dmode[s] != 0) {
-                const int SB = (w + 31) / 32;
-                // A[m = source column][k = hidden] = W1[k][off + m]
-                jobs.job[jobs.njobs++] = {p->W1 + off, 1L, (long)kin, w, SB, p->hid, HBT * 4, 0, p->wpack + woff};
-                woff += (size_t)SB * HBT * 1024;
-            }
-            off += w;
+        if ((p->flags & NLAM_F_WPACK_READY) == 0) {
+            pack_jobs_t jobs;
+            build_bwd_wide_jobs(p, jobs);
+            launch_pack(jobs, stream);
         }
-        launch_pack(jobs, stream);
         const size_t lds = bwd_wide_lds(p, cfg.nwv);
         const int wblocks = nlam_mlp_bwd_blocks(p);
 #define NLAM_LAUNCH_BWD_WIDE(NWV_, FB_)                                                                       \
@@ -4123,6 +4315,7 @@ int32_t nlam_mlp_group_blocks(const int64_t* tiles, int32_t n, int32_t* blocks) 
 }
 
 int32_t nlam_mlp_fwd_group(const nlam_mlp_fwd_t* ps, int32_t n, void* hip_stream) {
+    NLAM_RANGE("nlam_mlp_fwd_group");
     if (ps == nullptr || n < 1 || n > NLAM_MAX_GROUP) return NLAM_EINVAL;
     const int HB = (ps[0].hid + 31) / 32, OB = (ps[0].dout + 31) / 32;
     const int ns = (int)((ps[0].flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
@@ -4174,6 +4367,7 @@ int32_t nlam_mlp_fwd_group(const nlam_mlp_fwd_t* ps, int32_t n, void* hip_stream
 
 #if NLAM_IN_TU(2)
 extern "C" int32_t nlam_mlp_bwd_group(const nlam_mlp_bwd_t* ps, int32_t n, void* hip_stream) {
+    NLAM_RANGE("nlam_mlp_bwd_group");
     if (ps == nullptr || n < 1 || n > NLAM_MAX_GROUP) return NLAM_EINVAL;
     const int HB = (ps[0].hid + 31) / 32, OB = (ps[0].dout + 31) / 32;
     const int ns = (int)((ps[0].flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
@@ -4307,6 +4501,7 @@ int32_t nlam_detail::bwd_narrow(const nlam_mlp_bwd_t* p, hipStream_t stream) {
 extern "C" {
 
 int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
+    NLAM_RANGE("nlam_wgrad");
     if (p == nullptr || p->A == nullptr || p->partials == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC) return NLAM_EINVAL;
     int n = 0;
     for (int s = 0; s < p->nsrc; ++s) n += p->src[s].width;
@@ -4426,6 +4621,7 @@ int64_t nlam_window_len(int64_t n_state_times, int64_t n_forcing_times, int32_t 
 }
 
 int32_t nlam_window_batch(const nlam_window_t* p, void* hip_stream) {
+    NLAM_RANGE("nlam_window_batch");
     if (p == nullptr || p->state == nullptr || p->sample_idx == nullptr || p->init_states == nullptr || p->target_states == nullptr)
         return NLAM_EINVAL;
     if (p->batch < 0 || p->nodes < 0 || p->d_state < 1 || p->d_forcing < 0 || p->ar_steps < 1 || p->ar_steps > 256 ||
@@ -4472,6 +4668,7 @@ int32_t nlam_pre_add_supported(const nlam_mlp_fwd_t* p) {
 }
 
 int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream) {
+    NLAM_RANGE("nlam_linear");
     if (p == nullptr || p->x == nullptr || p->W == nullptr || p->out == nullptr || p->rows < 0 || p->k < 1 || p->n < 1) return NLAM_EINVAL;
     if (p->rows == 0) return 0;
     const int ns = (int)((p->flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
@@ -4562,16 +4759,19 @@ static int32_t segment_sum_launch(const float* in, int64_t in_bstride, const int
 
 int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
                          float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream) {
+    NLAM_RANGE("nlam_segment_sum");
     return segment_sum_launch(in, in_bstride, ptr, order, scale, out, nseg, width, batch, 0, hip_stream);
 }
 
 int32_t nlam_segment_sum_acc(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
                              float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream) {
+    NLAM_RANGE("nlam_segment_sum_acc");
     return segment_sum_launch(in, in_bstride, ptr, order, scale, out, nseg, width, batch, 1, hip_stream);
 }
 
 int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stride, int32_t n, float* out,
                              int32_t accumulate, void* hip_stream) {
+    NLAM_RANGE("nlam_reduce_partials");
     if (partials == nullptr || out == nullptr || nparts < 1 || n < 1) return NLAM_EINVAL;
     int blocks = (n + 63) / 64;
     if (blocks > 2048) blocks = 2048;
@@ -4581,6 +4781,7 @@ int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stri
 }
 
 int32_t nlam_reduce_jobs(const nlam_reduce_jobs_t* jobs, void* hip_stream) {
+    NLAM_RANGE("nlam_reduce_jobs");
     if (jobs == nullptr || jobs->njobs < 1 || jobs->njobs > NLAM_MAX_REDUCE_JOBS) return NLAM_EINVAL;
     int nmax = 0;
     for (int k = 0; k < jobs->njobs; ++k) {
@@ -4597,6 +4798,7 @@ int32_t nlam_reduce_jobs(const nlam_reduce_jobs_t* jobs, void* hip_stream) {
 
 int32_t nlam_wmse_fwd(const float* pred, const float* target, const float* inv_var, const float* row_weight, int64_t rows,
                       int32_t nodes, int32_t nvars, float scale, float* partials, int32_t nparts, void* hip_stream) {
+    NLAM_RANGE("nlam_wmse_fwd");
     if (pred == nullptr || target == nullptr || inv_var == nullptr || row_weight == nullptr || partials == nullptr) return NLAM_EINVAL;
     if (rows < 1 || nodes < 1 || nvars < 1 || nparts < 1) return NLAM_EINVAL;
     hipLaunchKernelGGL(wmse_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)hip_stream, pred, target, inv_var, row_weight,
@@ -4606,6 +4808,7 @@ int32_t nlam_wmse_fwd(const float* pred, const float* target, const float* inv_v
 
 int32_t nlam_wmse_bwd(const float* pred, const float* target, const float* inv_var, const float* row_weight, const float* gscalar,
                       int64_t rows, int32_t nodes, int32_t nvars, float scale, float* dpred, void* hip_stream) {
+    NLAM_RANGE("nlam_wmse_bwd");
     if (pred == nullptr || target == nullptr || inv_var == nullptr || row_weight == nullptr || gscalar == nullptr || dpred == nullptr)
         return NLAM_EINVAL;
     if (rows < 1 || nodes < 1 || nvars < 1) return NLAM_EINVAL;
@@ -4619,6 +4822,7 @@ int32_t nlam_wmse_bwd(const float* pred, const float* target, const float* inv_v
 
 int32_t nlam_affine_mix(const float* x, const float* a, const float* y, const float* c, const float* z, const float* s,
                         const float* m, float* out, int64_t rows, int32_t nodes, int32_t width, void* hip_stream) {
+    NLAM_RANGE("nlam_affine_mix");
     if (out == nullptr || rows < 1 || nodes < 1 || width < 1) return NLAM_EINVAL;
     if ((x == nullptr) != (a == nullptr) || (z == nullptr) != (s == nullptr)) return NLAM_EINVAL;
     if (x == nullptr && y == nullptr && z == nullptr && m == nullptr) return NLAM_EINVAL;
@@ -4634,6 +4838,7 @@ int32_t nlam_step_tail_fwd(const float* delta, const float* prev, const float* t
                            const float* dmean, const float* bmask, const float* inv_var, const float* row_weight, float scale,
                            float* pred, float* partials, int32_t nparts, int64_t rows, int32_t nodes, int32_t width,
                            void* hip_stream) {
+    NLAM_RANGE("nlam_step_tail_fwd");
     if (delta == nullptr || prev == nullptr || truth == nullptr || target == nullptr || bmask == nullptr || inv_var == nullptr ||
         row_weight == nullptr || pred == nullptr || partials == nullptr)
         return NLAM_EINVAL;
@@ -4646,6 +4851,7 @@ int32_t nlam_step_tail_fwd(const float* delta, const float* prev, const float* t
 int32_t nlam_step_tail_bwd(const float* g_pred, const float* gloss, const float* pred, const float* target, const float* dstd,
                            const float* bmask, const float* inv_var, const float* row_weight, float scale, float* d_delta,
                            float* d_prev, int64_t rows, int32_t nodes, int32_t width, void* hip_stream) {
+    NLAM_RANGE("nlam_step_tail_bwd");
     if (gloss == nullptr || pred == nullptr || target == nullptr || bmask == nullptr || inv_var == nullptr || row_weight == nullptr)
         return NLAM_EINVAL;
     if ((d_delta == nullptr && d_prev == nullptr) || rows < 1 || nodes < 1 || width < 1) return NLAM_EINVAL;
@@ -4658,6 +4864,7 @@ int32_t nlam_step_tail_bwd(const float* g_pred, const float* gloss, const float*
 }
 
 int32_t nlam_concat(const nlam_cat_t* p, void* hip_stream) {
+    NLAM_RANGE("nlam_concat");
     if (p == nullptr || p->out == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_CAT || p->batch < 1 || p->nodes < 0) return NLAM_EINVAL;
     int wtot = 0;
     for (int k = 0; k < p->nsrc; ++k) {
@@ -4673,6 +4880,7 @@ int32_t nlam_concat(const nlam_cat_t* p, void* hip_stream) {
 }
 
 int32_t nlam_standardize(const nlam_std_jobs_t* jobs, void* hip_stream) {
+    NLAM_RANGE("nlam_standardize");
     if (jobs == nullptr || jobs->njobs < 1 || jobs->njobs > NLAM_MAX_STD_JOBS) return NLAM_EINVAL;
     long most = 0;
     for (int k = 0; k < jobs->njobs; ++k) {
@@ -4691,6 +4899,7 @@ int32_t nlam_standardize(const nlam_std_jobs_t* jobs, void* hip_stream) {
 int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                         float beta1, float beta2, float eps, float weight_decay, int32_t step_count, float grad_scale,
                         void* hip_stream) {
+    NLAM_RANGE("nlam_adamw_step");
     if (param == nullptr || grad == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || n < 0 || step_count < 1)
         return NLAM_EINVAL;
     if (n == 0) return 0;

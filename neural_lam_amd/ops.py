@@ -179,9 +179,19 @@ class WeightPacker:
         self.table_entries = []    # the entries it describes, in table order
         self.dirty = False
         self.step_id = 0
+        # wide launches (a width above 64): their `wpack` scratch, normally packed by a launch in front of every forward /
+        # backward launch, lives in a persistent buffer per (MLP, launch geometry, direction) that nlam_pack_records fills
+        # once per step from a table of pack records (one launch per record kind)
+        self.wide_enabled = os.environ.get("NLAM_PACK_WIDE", "1") == "1"
+        self.wide = {}
+        self.wide_tables = {}      # kind -> (device table, [entries])
+        self.wide_dirty = False
 
     class Entry:
         __slots__ = ("job", "fwd", "bwd", "packed_step")
+
+    class WideEntry:
+        __slots__ = ("buf", "recs", "kind", "packed_step")
 
     def get(self, W1, W2, widths, hid, dout, pre, ldw1, mm_flags):
         """The entry whose images are valid for THIS step, or None (not served / registered only now)."""
@@ -207,6 +217,31 @@ class WeightPacker:
             self.entries[key] = e
         return e if (e.fwd is not None and e.packed_step == self.step_id) else None
 
+    def get_wide(self, which, p, nwp, key):
+        """Persistent, already packed ``wpack`` buffer of the wide launch described by ``p`` (an MlpFwd for which = "f", an
+        MlpBwd for "b"; every field but wpack filled), or None: not registered before this step (it is now), not served."""
+        if not (self.enabled and self.wide_enabled):
+            return None
+        e = self.wide.get(key)
+        if e is None:
+            lib = L.load()
+            e = WeightPacker.WideEntry()
+            e.buf, e.recs, e.kind, e.packed_step = None, b"", -1, -1
+            dev = torch.device("cuda", torch.cuda.current_device())
+            buf = torch.empty((int(nwp),), device=dev, dtype=torch.float32)
+            old = (p.wpack, p.wpack_floats)
+            p.wpack, p.wpack_floats = buf.data_ptr(), int(nwp)
+            recs, kind = (L.PackRec * 4)(), C.c_int32(-1)
+            fn = lib.nlam_mlp_fwd_pack_records if which == "f" else lib.nlam_mlp_bwd_pack_records
+            n = int(fn(C.byref(p), recs, 4, C.byref(kind)))
+            p.wpack, p.wpack_floats = old
+            if n > 0:
+                e.buf, e.kind = buf, int(kind.value)
+                e.recs = b"".join(bytes(recs[k]) for k in range(n))
+                self.wide_dirty = True
+            self.wide[key] = e
+        return e.buf if (e.buf is not None and e.packed_step == self.step_id) else None
+
     def begin_step(self):
         """Rewrite every registered image from the current weights: one launch, first thing in the step (inside a captured
         step it is the first kernel of the graph).  Entries registered since the last call join the table here -- except
@@ -221,11 +256,24 @@ class WeightPacker:
             self.table = host.to(live[0].fwd.device)
             self.table_entries = live
             self.dirty = False
-        if self.table is None:
-            return
-        L.check(L.load().nlam_mlp_pack(C.c_void_p(self.table.data_ptr()), len(self.table_entries), _stream()), "nlam_mlp_pack")
-        for e in self.table_entries:
-            e.packed_step = self.step_id
+        if self.table is not None:
+            L.check(L.load().nlam_mlp_pack(C.c_void_p(self.table.data_ptr()), len(self.table_entries), _stream()), "nlam_mlp_pack")
+            for e in self.table_entries:
+                e.packed_step = self.step_id
+        if self.wide_dirty and not torch.cuda.is_current_stream_capturing():
+            by_kind = {}
+            for e in self.wide.values():
+                if e.buf is not None:
+                    by_kind.setdefault(e.kind, []).append(e)
+            self.wide_tables = {}
+            for kind, ents in by_kind.items():
+                host = torch.frombuffer(bytearray(b"".join(e.recs for e in ents)), dtype=torch.uint8)
+                self.wide_tables[kind] = (host.to(ents[0].buf.device), ents)
+            self.wide_dirty = False
+        for kind, (table, ents) in self.wide_tables.items():
+            L.check(L.load().nlam_pack_records(C.c_void_p(table.data_ptr()), table.numel() // 64, kind, _stream()), "nlam_pack_records")
+            for e in ents:
+                e.packed_step = self.step_id
 
 
 # Installed by a trainer for the duration of its own forward + backward (direct_param_grads)
@@ -440,9 +488,16 @@ class FusedMLPFunction(torch.autograd.Function):
                 p.xhat, p.rstd = _ptr(xhat), _ptr(rstd)
         nwp = lib.nlam_mlp_fwd_wpack_floats(C.byref(p))
         pack = None
-        if nwp > 0:  # wide kernels: scratch for the weights in MFMA A-operand order
-            wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
-            p.wpack, p.wpack_floats = _ptr(wpack), nwp
+        if nwp > 0:  # wide kernels: the weights in MFMA A-operand order -- packed once per step under a trainer, else scratch the launch fills
+            wbuf = None
+            if PACKER is not None:
+                wbuf = PACKER.get_wide("f", p, nwp, ("f", W1c.data_ptr(), W2c.data_ptr(), tuple(widths), hid, dout, int(p.flags), int(p.ldw1),
+                                                      rows, ntiles, B))
+            if wbuf is not None:
+                p.wpack, p.wpack_floats, p.flags = wbuf.data_ptr(), nwp, int(p.flags) | L.F_WPACK_READY
+            else:
+                wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+                p.wpack, p.wpack_floats = _ptr(wpack), nwp
         elif PACKER is not None:   # narrow kernels under a trainer: the image packed once for this step
             pack = PACKER.get(W1c, W2c, widths, hid, dout, pre, kin if pre else 0, mm_flags)
             if pack is not None:
@@ -564,8 +619,15 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
     wpack = None
     if nwp > 0:
-        wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
-        p.wpack, p.wpack_floats = _ptr(wpack), nwp
+        wbuf = None
+        if PACKER is not None:
+            wbuf = PACKER.get_wide("b", p, nwp, ("b", W1.data_ptr(), W2.data_ptr(), tuple(widths), hid, dout, int(p.flags), int(p.ldw1),
+                                                  rows, ntiles, B, tuple(int(p.dmode[k]) for k in range(nsrc)), int(p.dz2_ld)))
+        if wbuf is not None:
+            p.wpack, p.wpack_floats, p.flags = wbuf.data_ptr(), nwp, int(p.flags) | L.F_WPACK_READY
+        else:
+            wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+            p.wpack, p.wpack_floats = _ptr(wpack), nwp
     elif ctx.pack is not None and PACKER is not None and ctx.pack.packed_step == PACKER.step_id:
         p.wpack, p.wpack_floats = ctx.pack.bwd.data_ptr(), ctx.pack.bwd.numel()
     nblk = lib.nlam_mlp_bwd_blocks(C.byref(p))
@@ -1030,7 +1092,9 @@ def _alloc_dz2(lib, p, nrows, dout, dev):
     split-bf16 kernels (``nlam_mlp_bwd_dz2_ld``).  Call once every field of ``p`` that decides the kernel is set."""
     ld = int(lib.nlam_mlp_bwd_dz2_ld(C.byref(p)))
     dpad = ld if ld > 0 else dout
-    dz2 = torch.empty((nrows, dpad), device=dev, dtype=torch.float32)
+    # the wide kernels write the real columns only: the padding must read as zeros in the weight gradient
+    alloc = torch.zeros if (ld > 0 and lib.nlam_mlp_bwd_wpack_floats(C.byref(p)) > 0) else torch.empty
+    dz2 = alloc((nrows, dpad), device=dev, dtype=torch.float32)
     p.dz2, p.dz2_ld = _ptr(dz2), ld
     return dz2, dpad
 

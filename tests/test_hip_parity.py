@@ -334,16 +334,24 @@ def test_concat_folded_into_mlp_matches_oracle(dev, mode, widths, hid, B, shared
         assert rel_err(p.grad.cpu(), q.grad) < tol, k
 
 
-def test_prepacked_weights_give_identical_steps(dev, tmp_path):
-    """``nlam_mlp_pack``: under a trainer the narrow kernels fetch their weights as images packed once per step instead of
-    splitting the fp32 matrices in every workgroup.  Same bf16 terms, same LDS layout -> the step must be BIT-identical with
-    the packer on and off (loss, every gradient, the weights after AdamW), eager and captured, over a rollout of two steps."""
+@pytest.mark.parametrize("d,family,autocast", [(64, "auto", False), (128, "auto", False), (128, "wbf", False), (128, "wbf", True), (256, "wbf", False)])
+def test_prepacked_weights_give_identical_steps(dev, tmp_path, d, family, autocast):
+    """Weights packed ONCE per optimizer step (ops.WeightPacker): the narrow kernels fetch LDS images written by nlam_mlp_pack
+    instead of splitting the fp32 matrices in every workgroup; the wide kernels read persistent ``wpack`` buffers filled by
+    nlam_pack_records (NLAM_F_WPACK_READY) instead of running a pack launch in front of every forward / backward launch.
+    Same terms, same layouts -> the step must be BIT-identical with the packer on and off (losses, every gradient, the weights
+    after AdamW), eager and captured, over a rollout of two AR steps -- for the fp32-MFMA wide family ("auto" at this size),
+    the split-bf16 one ("wbf") and bf16 autocast."""
+    import contextlib
+
+    from neural_lam_amd import _lib as L
     from neural_lam_amd import graph as G
     from neural_lam_amd import models as hm
     from neural_lam_amd import ops
     from neural_lam_amd.datastore import SyntheticDatastore
     from neural_lam_amd.trainer import Trainer
 
+    lib = L.load()
     ds = SyntheticDatastore(30, 27, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
     ext = ds.get_xy_extent("state")
     graph = G.normalise_graph(G.create_regular_grid_graph(ds.get_xy("state")), max(ext[1] - ext[0], ext[3] - ext[2]))
@@ -353,21 +361,34 @@ def test_prepacked_weights_give_identical_steps(dev, tmp_path):
 
     def run(packed, use_graph):
         torch.manual_seed(11)
-        fc = hm.ARForecaster(hm.GraphLAM(ds, graph=graph, hidden_dim=64, processor_layers=2), ds)
+        fc = hm.ARForecaster(hm.GraphLAM(ds, graph=graph, hidden_dim=d, processor_layers=2), ds)
         tr = Trainer(hm.ForecasterStep(fc, ds).to(dev), lr=1e-3, use_graph=use_graph)
         tr._packer = ops.WeightPacker()
         tr._packer.enabled = packed
-        losses = [float(tr.step(*batch)) for _ in range(4)]
+        amp = torch.autocast("cuda", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()
+        with amp:
+            losses = [float(tr.step(*batch)) for _ in range(4)]
         torch.cuda.synchronize()
         return losses, tr.fp.grad.clone(), tr.fp.flat.clone(), tr._packer
 
-    for use_graph in (False, True):
-        l0, g0, w0, _ = run(False, use_graph)
-        l1, g1, w1, pk = run(True, use_graph)
-        assert pk.table is not None and len(pk.table_entries) >= 10          # edge / node / grid MLPs + the embedders registered
-        assert all(e.packed_step == pk.step_id for e in pk.table_entries)       # ... and were rewritten for the last step
-        assert l0 == l1, (use_graph, l0, l1)
-        assert torch.equal(g0, g1) and torch.equal(w0, w1), use_graph
+    if family == "wbf":
+        assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 0) == 0
+    try:
+        for use_graph in (False, True):
+            l0, g0, w0, _ = run(False, use_graph)
+            l1, g1, w1, pk = run(True, use_graph)
+            if d <= 64:
+                assert pk.table is not None and len(pk.table_entries) >= 10      # edge / node / grid MLPs + the embedders registered
+                assert all(e.packed_step == pk.step_id for e in pk.table_entries)   # ... and were rewritten for the last step
+            else:
+                wide = [e for e in pk.wide.values() if e.buf is not None]
+                assert len(wide) >= 10 and all(e.packed_step == pk.step_id for e in wide)
+                kinds = {e.kind for e in wide}
+                assert (1 in kinds) if autocast else ((3 in kinds) if family == "wbf" else kinds == {0})
+            assert l0 == l1, (use_graph, l0, l1)
+            assert torch.equal(g0, g1) and torch.equal(w0, w1), use_graph
+    finally:
+        assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
 
 
 # ---------------------------------------------------------------------------
