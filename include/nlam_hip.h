@@ -321,7 +321,7 @@ int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stri
 /* Up to NLAM_MAX_REDUCE_JOBS reductions of the nlam_reduce_partials kind in ONE launch: the dW1, dW2,
  * db1, db2, dgamma, dbeta of one fused-MLP backward (autograd's AccumulateGrad `grad += new`, folded in
  * when accumulate != 0 and out points into the gradient buffer). */
-#define NLAM_MAX_REDUCE_JOBS 8
+#define NLAM_MAX_REDUCE_JOBS 40   /* e.g. the 4 x 9 reductions of the four static-feature embedders of one grouped backward */
 typedef struct {
     const float* partials;
     float* out;

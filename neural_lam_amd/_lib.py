@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ["NLAM_LIB"]) if os.environ.get("NLAM_LIB") else HERE 
 
 NLAM_MAX_SRC = 3
 NLAM_MAX_CAT = 6
+NLAM_MAX_REDUCE_JOBS = 40
 NLAM_MAX_GROUP = 8
 F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD, F_LEAF_WGRAD, F_WPACK_READY = 1, 2, 4, 8, 16, 32, 64
 TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning keys (include/nlam_hip.h)
@@ -187,7 +188,7 @@ class ReduceJob(C.Structure):
 
 
 class ReduceJobs(C.Structure):
-    _fields_ = [("job", ReduceJob * 8), ("njobs", C.c_int32), ("_pad", C.c_int32)]
+    _fields_ = [("job", ReduceJob * NLAM_MAX_REDUCE_JOBS), ("njobs", C.c_int32), ("_pad", C.c_int32)]
 
 
 class Linear(C.Structure):

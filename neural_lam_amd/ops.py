@@ -1352,13 +1352,21 @@ def _grouped_backward_fused(ctx, g_outs, live, grads):
                 and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32)
 
     keep = []
+    jobs = L.ReduceJobs()   # ONE reduction launch for all members (<= 9 jobs each): they were four serial launches at the very end of the step
+
+    def flush():
+        if jobs.njobs > 0:
+            L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
+            jobs.njobs = 0
+
     for (k, g, dw2p, vecp, nblk, vs, _b1c) in work:
         prm = params[k]
         hid, kin = prm[0].shape
         dout = prm[2].shape[0]
         needs = [ctx.needs_input_grad[1 + 6 * k + q] for q in range(6)]
         has_ln = prm[4] is not None
-        jobs = L.ReduceJobs()
+        if jobs.njobs + 9 > L.NLAM_MAX_REDUCE_JOBS:
+            flush()
         res = [None] * 6
         vbase = vecp.data_ptr()
 
@@ -1392,11 +1400,12 @@ def _grouped_backward_fused(ctx, g_outs, live, grads):
             add(4, vbase + 2 * vs * 4, 7 * vs, (dout,), prm[4])
         if has_ln and needs[5]:
             add(5, vbase + 3 * vs * 4, 7 * vs, (dout,), prm[5])
-        if jobs.njobs > 0:
-            L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
-        if GRAD_LISTENER is not None:
-            GRAD_LISTENER.note_done([q for q, nd in zip(prm, needs) if nd and q is not None and is_direct(q, q.shape)])
         grads[6 * k : 6 * k + 6] = res
+    flush()
+    if GRAD_LISTENER is not None:
+        for (k, *_rest) in work:
+            needs = [ctx.needs_input_grad[1 + 6 * k + q] for q in range(6)]
+            GRAD_LISTENER.note_done([q for q, nd in zip(params[k], needs) if nd and q is not None and is_direct(q, q.shape)])
     return True
 
 
