@@ -475,6 +475,12 @@ int32_t nlam_window_batch(const nlam_window_t* p, void* hip_stream);
 int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step_count,
                         float grad_scale, void* hip_stream);
+/* the same update with the step count RESIDENT on the device: a one-thread launch advances *step_count_dev (int32, starts at
+ * 0) and leaves the bias corrections 1 - beta1^t, sqrt(1 - beta2^t) in bias_corr_dev[0..1] for the update launch behind it.
+ * No launch argument depends on the step, so the optimizer can be part of a captured HIP graph that is replayed per step. */
+int32_t nlam_adamw_step_resident(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int32_t* step_count_dev,
+                                 float* bias_corr_dev, float grad_scale, void* hip_stream);
 
 #ifdef __cplusplus
 }

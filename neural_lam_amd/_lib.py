@@ -51,6 +51,7 @@ EXPORTS = [
     "nlam_wmse_fwd",
     "nlam_wmse_bwd",
     "nlam_adamw_step",
+    "nlam_adamw_step_resident",
     "nlam_standardize",
     "nlam_mlp_group_blocks",
     "nlam_mlp_fwd_group",
@@ -357,6 +358,8 @@ def load():
     lib.nlam_wmse_bwd.restype = i32
     lib.nlam_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]
     lib.nlam_adamw_step.restype = i32
+    lib.nlam_adamw_step_resident.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, f32, vp]
+    lib.nlam_adamw_step_resident.restype = i32
     lib.nlam_step_tail_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i64, i32, i32, vp]
     lib.nlam_step_tail_fwd.restype = i32
     lib.nlam_step_tail_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i64, i32, i32, vp]

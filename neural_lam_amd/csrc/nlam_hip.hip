@@ -3172,8 +3172,23 @@ __global__ void wmse_bwd_kernel(const float* pred, const float* target, const fl
     }
 }
 
+// resident step counter (nlam_adamw_step_resident): one thread advances it and leaves the two bias corrections for the update
+// kernel behind it -- nothing about the step count is a launch argument, so the pair can live inside a captured HIP graph
+__global__ void adamw_prep_kernel(int32_t* step_count, float* bias_corr, float b1, float b2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int t = *step_count + 1;
+        *step_count = t;
+        bias_corr[0] = 1.f - powf(b1, (float)t);
+        bias_corr[1] = sqrtf(1.f - powf(b2, (float)t));
+    }
+}
+
 __global__ void adamw_kernel(float* param, const float* grad, float* m, float* v, long n, float lr, float b1, float b2,
-                             float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                             float eps, float wd, float bc1, float bc2_sqrt, float gscale, const float* bias_corr) {
+    if (bias_corr != nullptr) {
+        bc1 = bias_corr[0];
+        bc2_sqrt = bias_corr[1];
+    }
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
         const float g = grad[idx] * gscale;
         float pv = param[idx];
@@ -3404,38 +3419,69 @@ __host__ __device__ inline PackShape pack_shape(const nlam_pack_job_t& j) {
     return r;
 }
 
+// one (matrix piece -> image) staging call of stage_split_impl, as data
+struct PackPiece {
+    u32x4* dst;
+    const float* W;
+    long ldm, ldk;
+    int S, s0, M, MB, K, Kpad, perm2, items;
+};
+
+// All pieces of a job are walked as ONE index space (thread -> (piece, lane item)): a thread converts at most a couple of
+// 8-float slots, so the launch is one load latency deep instead of one per piece (ten dependent passes made it 15 us at the
+// head of every cfg2 step).
 template <int NS>
 __device__ void pack_job(const nlam_pack_job_t& j, const PackShape& sh, int tid, int nthr) {
     const int DPH = sh.HB * 32, OP = sh.OB * 32;
     int kin = 0;
     for (int s = 0; s < sh.ngemm; ++s) kin += j.width[s];
     const int ldw1 = j.ldw1 > 0 ? j.ldw1 : kin;
+    PackPiece pc[2 * (NLAM_MAX_SRC + 1)];
+    int np = 0;
+    auto add = [&](u32x4* dst, int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2, long ldk, int Kpad) {
+        PackPiece q;
+        q.dst = dst; q.W = W; q.ldm = ldm; q.ldk = ldk; q.S = S; q.s0 = s0; q.M = M; q.MB = MB; q.K = K; q.Kpad = Kpad; q.perm2 = perm2 ? 1 : 0;
+        q.items = MB * ((Kpad > 0 ? Kpad : K) >> 4) * 64;
+        pc[np++] = q;
+    };
     if (j.fwd_image != nullptr) {
         u32x4* W1s = reinterpret_cast<u32x4*>(j.fwd_image);
         u32x4* W2s = W1s + (size_t)NS * sh.HB * sh.S1 * 64;
         int s0 = 0, off = 0;
         for (int s = 0; s < sh.ngemm; ++s) {
             const int w = j.width[s];
-            stage_split_impl<NS>(W1s, sh.S1, s0, j.W1 + off, ldw1, j.hid, sh.HB, w, false, 1, ((w + 31) >> 5) * 32, tid, nthr);
+            add(W1s, sh.S1, s0, j.W1 + off, ldw1, j.hid, sh.HB, w, false, 1, ((w + 31) >> 5) * 32);
             off += w;
             s0 += 2 * ((w + 31) >> 5);
         }
-        stage_split_impl<NS>(W2s, DPH / 16, 0, j.W2, j.hid, j.dout, sh.OB, j.hid, true, 1, 0, tid, nthr);
+        add(W2s, DPH / 16, 0, j.W2, j.hid, j.dout, sh.OB, j.hid, true, 1, 0);
     }
     if (j.bwd_image != nullptr) {
         float* W2t = j.bwd_image;
         // A[m = hidden][k = out (slot-permuted)] = W2[k][m]
-        stage_split_impl<NS>(reinterpret_cast<u32x4*>(W2t), OP / 16, 0, j.W2, 1, j.hid, sh.HB, j.dout, true, j.hid, OP, tid, nthr);
+        add(reinterpret_cast<u32x4*>(W2t), OP / 16, 0, j.W2, 1, j.hid, sh.HB, j.dout, true, j.hid, OP);
         size_t ioff = (size_t)NS * DPH * OP / 2;
         int off = 0;
         for (int s = 0; s < sh.ngemm; ++s) {
             const int w = j.width[s];
             if ((w & 31) == 0) {   // A[m = source column][k = hidden (slot-permuted)] = W1[k][off + m]
-                stage_split_impl<NS>(reinterpret_cast<u32x4*>(W2t + ioff), DPH / 16, 0, j.W1 + off, 1, w, w >> 5, j.hid, true, ldw1, 0, tid, nthr);
+                add(reinterpret_cast<u32x4*>(W2t + ioff), DPH / 16, 0, j.W1 + off, 1, w, w >> 5, j.hid, true, ldw1, 0);
                 ioff += (size_t)NS * w * DPH / 2;
             }
             off += w;
         }
+    }
+    int total = 0;
+    for (int k = 0; k < np; ++k) total += pc[k].items;
+    for (int g = tid; g < total; g += nthr) {
+        int k = 0, local = g;
+        while (local >= pc[k].items) {
+            local -= pc[k].items;
+            ++k;
+        }
+        const PackPiece& q = pc[k];
+        // exactly one item of stage_split_impl: thread index `local` of a pass whose stride covers the piece
+        stage_split_impl<NS>(q.dst, q.S, q.s0, q.W, q.ldm, q.M, q.MB, q.K, q.perm2 != 0, q.ldk, q.Kpad, local, q.items);
     }
 }
 
@@ -3851,8 +3897,8 @@ int32_t nlam_mlp_pack(const nlam_pack_job_t* jobs_device, int32_t njobs, void* h
     NLAM_RANGE("nlam_mlp_pack");
     if (jobs_device == nullptr || njobs < 0 || njobs > 65535) return NLAM_EINVAL;
     if (njobs == 0) return 0;
-    // the largest piece (a 64 x 192 first layer) is 1 536 lane items: four 256-thread blocks per job
-    hipLaunchKernelGGL(mlp_pack_kernel, dim3(4, njobs), dim3(256), 0, (hipStream_t)hip_stream, jobs_device);
+    // the largest job (a 64 x 192 -> 64 edge MLP, forward + backward image) is 4 096 lane items: one per thread of 16 blocks
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(16, njobs), dim3(256), 0, (hipStream_t)hip_stream, jobs_device);
     return (int32_t)hipGetLastError();
 }
 
@@ -4908,7 +4954,24 @@ int32_t nlam_adamw_step(float* param, const float* grad, float* exp_avg, float* 
     long blocks = (n + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, param, grad, exp_avg,
-                       exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+                       exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, (const float*)nullptr);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_adamw_step_resident(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int32_t* step_count_dev,
+                                 float* bias_corr_dev, float grad_scale, void* hip_stream) {
+    NLAM_RANGE("nlam_adamw_step_resident");
+    if (param == nullptr || grad == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || n < 0 || step_count_dev == nullptr ||
+        bias_corr_dev == nullptr)
+        return NLAM_EINVAL;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(adamw_prep_kernel, dim3(1), dim3(64), 0, stream, step_count_dev, bias_corr_dev, beta1, beta2);
+    if (n == 0) return (int32_t)hipGetLastError();
+    long blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (long)n, lr, beta1,
+                       beta2, eps, weight_decay, 1.f, 1.f, grad_scale, (const float*)bias_corr_dev);
     return (int32_t)hipGetLastError();
 }
 

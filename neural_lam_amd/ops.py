@@ -1905,12 +1905,22 @@ class AdamWFlat:
         self.m = torch.zeros_like(flat_param)
         self.v = torch.zeros_like(flat_param)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        # the step count lives on the device (nlam_adamw_step_resident): no launch argument changes from step to step, so the
+        # update can be captured into the trainer's HIP graph; ``t`` is the host's mirror of it
         self.t = 0
+        self.t_dev = torch.zeros((1,), device=flat_param.device, dtype=torch.int32)
+        self.bc_dev = torch.zeros((2,), device=flat_param.device, dtype=torch.float32)
 
     def step(self, grad_scale: float = 1.0):
+        """One update (eager or inside a stream capture).  A caller that REPLAYS a captured step calls ``note_replayed``."""
         self.t += 1
-        rc = L.load().nlam_adamw_step(
+        rc = L.load().nlam_adamw_step_resident(
             _ptr(self.p), _ptr(self.g), _ptr(self.m), _ptr(self.v), self.p.numel(), self.lr, self.betas[0],
-            self.betas[1], self.eps, self.wd, self.t, grad_scale, _stream(),
+            self.betas[1], self.eps, self.wd, _ptr(self.t_dev), _ptr(self.bc_dev), grad_scale, _stream(),
         )
-        L.check(rc, "nlam_adamw_step")
+        L.check(rc, "nlam_adamw_step_resident")
+
+    capturable = True
+
+    def note_replayed(self):
+        self.t += 1
