@@ -239,6 +239,9 @@ int32_t nlam_max_width(void);
 /*   NLAM_TUNE_LIN_WGS: workgroups of an nlam_linear launch with k <= 256 on the wide kernel, whose weight strip stays in
  *   LDS for the whole launch (default 256 = one per CU; 0 = stream the strip through two LDS buffers as for k > 256). */
 #define NLAM_TUNE_LIN_WGS 3
+/*   NLAM_TUNE_WGRAD_MIN_PARTS: least number of row slices (= partial sums per element) a weight gradient over more than that
+ *   many 32-row chunks is cut into (default 128: launch width for the mid-size problems; smaller = less partial-sum traffic). */
+#define NLAM_TUNE_WGRAD_MIN_PARTS 4
 int32_t nlam_set_tuning(int32_t key, int32_t value);
 /* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this
  * call; 0 when the call runs on the narrow (weights-in-LDS) kernels. */

@@ -22,6 +22,7 @@ F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD, F_LEAF_WGRAD, F_WPACK_READY
 TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning keys (include/nlam_hip.h)
 TUNE_WGRAD_CHUNKS = 2
 TUNE_LIN_WGS = 3
+TUNE_WGRAD_MIN_PARTS = 4
 TILE_SPLIT = 1 << 30
 
 EXPORTS = [
@@ -386,6 +387,8 @@ def load():
         raise RuntimeError("libnlam_hip.so ABI version mismatch")
     if os.environ.get("NLAM_LIN_WGS"):
         lib.nlam_set_tuning(TUNE_LIN_WGS, int(os.environ["NLAM_LIN_WGS"]))
+    if os.environ.get("NLAM_WGRAD_MIN_PARTS"):
+        lib.nlam_set_tuning(TUNE_WGRAD_MIN_PARTS, int(os.environ["NLAM_WGRAD_MIN_PARTS"]))
     if os.environ.get("NLAM_WGRAD_CHUNKS"):
         lib.nlam_set_tuning(TUNE_WGRAD_CHUNKS, int(os.environ["NLAM_WGRAD_CHUNKS"]))
     _lib = lib
@@ -406,7 +409,7 @@ SLICES = (1, 2, 3, 4, 5)   # -DNLAM_TU=k translation-unit slices of csrc/nlam_hi
 def build(verbose: bool = False, out: Path | None = None, defines=(), single_tu: bool | None = None) -> Path:
     """Compile csrc/nlam_hip.hip for gfx950 into the in-tree shared library.
 
-    Default: the four -DNLAM_TU=k slices are compiled in parallel (objects under csrc/_obj/, re-used when neither the
+    Default: the five -DNLAM_TU=k slices are compiled in parallel (objects under csrc/_obj/, re-used when neither the
     sources nor the flags changed) and linked.  ``single_tu=True`` (and any build with extra ``defines``, e.g. the
     NLAM_TIMING instrumentation) is the one-command build: one hipcc invocation, everything in one translation unit."""
     import hashlib

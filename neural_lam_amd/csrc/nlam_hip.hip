@@ -69,6 +69,7 @@ int32_t bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream);      // slice 4
 int32_t wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream);      // slice 4
 extern int wbf_min_supertiles;                                     // nlam_set_tuning (defined in slice 1)
 extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
+extern int wgrad_min_parts;                                        // nlam_set_tuning (defined in slice 1)
 extern int lin_resident_wgs;                                       // workgroups of a resident-weight nlam_linear launch (slice 1)
 }  // namespace nlam_detail
 
@@ -3419,69 +3420,107 @@ __host__ __device__ inline PackShape pack_shape(const nlam_pack_job_t& j) {
     return r;
 }
 
-// one (matrix piece -> image) staging call of stage_split_impl, as data
-struct PackPiece {
-    u32x4* dst;
-    const float* W;
-    long ldm, ldk;
-    int S, s0, M, MB, K, Kpad, perm2, items;
+// One lane item of stage_split_impl in two halves, so that a thread can have the loads of ALL pieces of a job in flight before
+// the first store: on gfx950 a load issued behind a store waits for that store's acknowledgement, and the piece-by-piece
+// version (load, convert, store, next piece) was ten such round trips deep -- 15 us at the head of every cfg2 step.
+struct PackItem {
+    float x[8];
+    int slot;      // destination index (in u32x4 units, term 0), -1 = this thread has no item in the piece
+    int tstride;   // u32x4 units between bf16 terms
 };
 
-// All pieces of a job are walked as ONE index space (thread -> (piece, lane item)): a thread converts at most a couple of
-// 8-float slots, so the launch is one load latency deep instead of one per piece (ten dependent passes made it 15 us at the
-// head of every cfg2 step).
+__device__ __forceinline__ PackItem pack_item_load(int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2, long ldk,
+                                                   int Kpad, int idx) {
+    PackItem it;
+    const int nst = (Kpad > 0 ? Kpad : K) >> 4;
+    it.slot = -1;
+    it.tstride = MB * S * 64;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) it.x[q] = 0.f;
+    if (idx >= MB * nst * 64) return it;
+    const int lane = idx & 63;
+    const int rest = idx >> 6;
+    const int st = rest % nst, mb = rest / nst;
+    const int i = lane & 31, hi = lane >> 5;
+    const int m = mb * 32 + i;
+    const int kA = perm2 ? 32 * (st >> 1) + 16 * (st & 1) + 4 * hi : 16 * st + 8 * hi;
+    const int kB = perm2 ? kA + 8 : kA + 4;
+    it.slot = (mb * S + s0 + st) * 64 + lane;
+    const float* rowp = W + (long)m * ldm;
+    if (ldk == 1 && m < M && kB + 4 <= K && ((ldm & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0)) {
+        const f32x4 va = *reinterpret_cast<const f32x4*>(rowp + kA);
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(rowp + kB);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            it.x[c] = va[c];
+            it.x[4 + c] = vb[c];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = min((q < 4 ? kA : kB) + (q & 3), K - 1);   // clamped: unconditional loads
+            const float v = W[(long)min(m, M - 1) * ldm + (long)k * ldk];
+            it.x[q] = (m < M && (q < 4 ? kA : kB) + (q & 3) < K) ? v : 0.f;
+        }
+    }
+    return it;
+}
+
+template <int NS>
+__device__ __forceinline__ void pack_item_store(u32x4* dst, const PackItem& it) {
+    if (it.slot < 0) return;
+    const BfFrag<NS> f = split8<NS>(it.x);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) dst[(size_t)p * it.tstride + it.slot] = f.t[p];
+}
+
+// thread `tid` of the job's grid takes lane item `tid` of every piece (<= 512 items each; nlam_mlp_pack launches 512 threads per job, as eight single-wave workgroups)
 template <int NS>
 __device__ void pack_job(const nlam_pack_job_t& j, const PackShape& sh, int tid, int nthr) {
     const int DPH = sh.HB * 32, OP = sh.OB * 32;
     int kin = 0;
     for (int s = 0; s < sh.ngemm; ++s) kin += j.width[s];
     const int ldw1 = j.ldw1 > 0 ? j.ldw1 : kin;
-    PackPiece pc[2 * (NLAM_MAX_SRC + 1)];
-    int np = 0;
-    auto add = [&](u32x4* dst, int S, int s0, const float* W, long ldm, int M, int MB, int K, bool perm2, long ldk, int Kpad) {
-        PackPiece q;
-        q.dst = dst; q.W = W; q.ldm = ldm; q.ldk = ldk; q.S = S; q.s0 = s0; q.M = M; q.MB = MB; q.K = K; q.Kpad = Kpad; q.perm2 = perm2 ? 1 : 0;
-        q.items = MB * ((Kpad > 0 ? Kpad : K) >> 4) * 64;
-        pc[np++] = q;
-    };
-    if (j.fwd_image != nullptr) {
-        u32x4* W1s = reinterpret_cast<u32x4*>(j.fwd_image);
-        u32x4* W2s = W1s + (size_t)NS * sh.HB * sh.S1 * 64;
-        int s0 = 0, off = 0;
-        for (int s = 0; s < sh.ngemm; ++s) {
-            const int w = j.width[s];
-            add(W1s, sh.S1, s0, j.W1 + off, ldw1, j.hid, sh.HB, w, false, 1, ((w + 31) >> 5) * 32);
-            off += w;
-            s0 += 2 * ((w + 31) >> 5);
-        }
-        add(W2s, DPH / 16, 0, j.W2, j.hid, j.dout, sh.OB, j.hid, true, 1, 0);
-    }
-    if (j.bwd_image != nullptr) {
-        float* W2t = j.bwd_image;
-        // A[m = hidden][k = out (slot-permuted)] = W2[k][m]
-        add(reinterpret_cast<u32x4*>(W2t), OP / 16, 0, j.W2, 1, j.hid, sh.HB, j.dout, true, j.hid, OP);
-        size_t ioff = (size_t)NS * DPH * OP / 2;
-        int off = 0;
-        for (int s = 0; s < sh.ngemm; ++s) {
-            const int w = j.width[s];
-            if ((w & 31) == 0) {   // A[m = source column][k = hidden (slot-permuted)] = W1[k][off + m]
-                add(reinterpret_cast<u32x4*>(W2t + ioff), DPH / 16, 0, j.W1 + off, 1, w, w >> 5, j.hid, true, ldw1, 0);
-                ioff += (size_t)NS * w * DPH / 2;
+    const bool fwd = j.fwd_image != nullptr, bwd = j.bwd_image != nullptr;
+    u32x4* W1s = reinterpret_cast<u32x4*>(j.fwd_image);
+    u32x4* W2s = W1s + (size_t)NS * sh.HB * sh.S1 * 64;
+    for (int base = 0; base < 512; base += nthr) {   // a piece has at most 2 blocks x 4 steps x 64 lanes = 512 items (widths <= 64)
+        const int idx = base + tid;
+        PackItem f1[NLAM_MAX_SRC], f2, b2, b1[NLAM_MAX_SRC];
+        u32x4* b1dst[NLAM_MAX_SRC];
+        // ---- all loads ----
+        {
+            int s0 = 0, off = 0;
+#pragma unroll
+            for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+                const int w = s < sh.ngemm ? j.width[s] : 0;
+                f1[s] = pack_item_load(sh.S1, s0, j.W1 + off, ldw1, j.hid, sh.HB, w > 0 ? w : 16, false, 1, ((w + 31) >> 5) * 32,
+                                       (fwd && w > 0) ? idx : (1 << 30));
+                off += w;
+                s0 += 2 * ((w + 31) >> 5);
             }
-            off += w;
+            f2 = pack_item_load(DPH / 16, 0, j.W2, j.hid, j.dout, sh.OB, j.hid, true, 1, 0, fwd ? idx : (1 << 30));
+            // backward: A[m = hidden][k = out (slot-permuted)] = W2[k][m];  A[m = source column][k = hidden] = W1[k][off + m]
+            b2 = pack_item_load(OP / 16, 0, j.W2, 1, j.hid, sh.HB, j.dout, true, j.hid, OP, bwd ? idx : (1 << 30));
+            size_t ioff = (size_t)NS * DPH * OP / 2;
+            off = 0;
+#pragma unroll
+            for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+                const int w = s < sh.ngemm ? j.width[s] : 0;
+                const bool on = bwd && w > 0 && (w & 31) == 0;
+                b1dst[s] = reinterpret_cast<u32x4*>(j.bwd_image + ioff);
+                b1[s] = pack_item_load(DPH / 16, 0, j.W1 + off, 1, on ? w : 32, on ? (w >> 5) : 1, j.hid, true, ldw1, 0, on ? idx : (1 << 30));
+                if (on) ioff += (size_t)NS * w * DPH / 2;
+                off += w;
+            }
         }
-    }
-    int total = 0;
-    for (int k = 0; k < np; ++k) total += pc[k].items;
-    for (int g = tid; g < total; g += nthr) {
-        int k = 0, local = g;
-        while (local >= pc[k].items) {
-            local -= pc[k].items;
-            ++k;
-        }
-        const PackPiece& q = pc[k];
-        // exactly one item of stage_split_impl: thread index `local` of a pass whose stride covers the piece
-        stage_split_impl<NS>(q.dst, q.S, q.s0, q.W, q.ldm, q.M, q.MB, q.K, q.perm2 != 0, q.ldk, q.Kpad, local, q.items);
+        // ---- all conversions + stores ----
+#pragma unroll
+        for (int s = 0; s < NLAM_MAX_SRC; ++s) pack_item_store<NS>(W1s, f1[s]);
+        pack_item_store<NS>(W2s, f2);
+        pack_item_store<NS>(reinterpret_cast<u32x4*>(j.bwd_image), b2);
+#pragma unroll
+        for (int s = 0; s < NLAM_MAX_SRC; ++s) pack_item_store<NS>(b1dst[s], b1[s]);
     }
 }
 
@@ -3845,6 +3884,7 @@ __global__ void pack_bf_table_kernel(const nlam_pack_rec_t* recs) {
 #if NLAM_IN_TU(1)
 int nlam_detail::wbf_min_supertiles = 192;
 int nlam_detail::lin_resident_wgs = 256;    // NLAM_LIN_WGS (experiments): one per CU
+int nlam_detail::wgrad_min_parts = 128;     // row slices a weight gradient of more than that many 32-row chunks is cut into at least
 int nlam_detail::wgrad_chunks_per_wg = 8;   // A/B at cfg2 (tools/ab_bench.sh): 2.13 -> 2.06 ms per step against one chunk per workgroup
 #endif
 
@@ -3878,6 +3918,11 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
         nlam_detail::lin_resident_wgs = value;
         return 0;
     }
+    if (key == NLAM_TUNE_WGRAD_MIN_PARTS) {
+        if (value < 1) return NLAM_EINVAL;
+        nlam_detail::wgrad_min_parts = value;
+        return 0;
+    }
     if (key == NLAM_TUNE_WGRAD_CHUNKS) {
         if (value < 1) return NLAM_EINVAL;
         nlam_detail::wgrad_chunks_per_wg = value;
@@ -3897,8 +3942,11 @@ int32_t nlam_mlp_pack(const nlam_pack_job_t* jobs_device, int32_t njobs, void* h
     NLAM_RANGE("nlam_mlp_pack");
     if (jobs_device == nullptr || njobs < 0 || njobs > 65535) return NLAM_EINVAL;
     if (njobs == 0) return 0;
-    // the largest job (a 64 x 192 -> 64 edge MLP, forward + backward image) is 4 096 lane items: one per thread of 16 blocks
-    hipLaunchKernelGGL(mlp_pack_kernel, dim3(16, njobs), dim3(256), 0, (hipStream_t)hip_stream, jobs_device);
+    // every piece of a job (<= 8: three W1 sources + W2, forward and backward) has <= 512 lane items: thread t of the job's two
+    // blocks takes item t of each piece, all loads in flight before the first store
+    // (eight one-wave workgroups per job rather than two of four waves: the ~200 KB of images a job writes then drain through
+    // eight CUs' store paths instead of two)
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(8, njobs), dim3(64), 0, (hipStream_t)hip_stream, jobs_device);
     return (int32_t)hipGetLastError();
 }
 
@@ -4020,7 +4068,8 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     // with 512 partials per weight matrix those were ~0.7 GB of traffic per cfg2 step (reduce_jobs: 290 us of 3.7 ms of kernel time)
     const long cpw = nlam_detail::wgrad_chunks_per_wg < 1 ? 1 : nlam_detail::wgrad_chunks_per_wg;   // nlam_set_tuning
     long np = total_chunks <= 128 ? total_chunks : (total_chunks + cpw - 1) / cpw;
-    if (np < 128 && total_chunks > 128) np = 128;
+    const long minp = nlam_detail::wgrad_min_parts < 1 ? 1 : nlam_detail::wgrad_min_parts;   // nlam_set_tuning (default 128)
+    if (np < minp && total_chunks > minp) np = minp;
     long cap = 512;
     if (p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) np = (total_chunks + 3) / 4;   // streaming kernel: >= 128 rows per workgroup
     if (wgrad_is_wide(p)) {
