@@ -25,7 +25,7 @@ Extra objects on the JSON line:
                 instruction, algorithmic bytes / 8 TB/s).  The top-level fields are the
                 dominant launch (largest share of the step); "kernels" lists the top
                 six, "step" the whole-step totals; "traffic" = PMC-measured HBM bytes
-                per launch (profiles/round2/pmc_traffic.json, tools/pmc_collect.py).
+                per launch (profiles/round3/pmc_traffic.json, tools/pmc_collect.py).
   cpu_baseline  the oracle (pure-torch restatement of the reference) timed on this
                 box's host cores on the same workload (median of >= 10 steps).
   gpu_reference_equivalent
@@ -434,8 +434,8 @@ def main():
         trainer.use_graph = not args.eager
         trainer.overlap_wgrad = overlap_was
         traffic = None
-        for tfile in (ROOT / "profiles" / "round2" / "pmc_traffic.json", ):
-            if tfile.exists() and args.config == "cfg2" and args.precision == "fp32":
+        for tfile in (ROOT / "profiles" / "round3" / "pmc_traffic.json", ROOT / "profiles" / "round2" / "pmc_traffic.json"):
+            if traffic is None and tfile.exists() and args.config == "cfg2" and args.precision == "fp32":
                 try:
                     traffic = json.loads(tfile.read_text()).get("bytes_per_launch")
                 except Exception:

@@ -1,8 +1,8 @@
-"""profiles/round2/pmc_traffic.json from the per-kernel PMC averages of tools/pmc_collect.py.
+"""profiles/roundN/pmc_traffic.json from the per-kernel PMC averages of tools/pmc_collect.py.
 
     python tools/pmc_collect.py m2g_edge fetch write wave insts -- python tools/kernel_bench.py m2g 3 64 edge
     python tools/pmc_collect.py m2m_edge fetch write wave insts -- python tools/kernel_bench.py m2m 3 64 edge
-    python tools/make_pmc_traffic.py gpurun_out/pmc_m2g_edge.json:255136 gpurun_out/pmc_m2m_edge.json:57616 > profiles/round2/pmc_traffic.json
+    python tools/make_pmc_traffic.py gpurun_out/pmc_m2g_edge.json:255136 gpurun_out/pmc_m2m_edge.json:57616 > profiles/round3/pmc_traffic.json
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB): on gfx950 rocprofv3's FETCH_SIZE tallies 128-byte read requests
 at 64 bytes (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is taken as reported (uncalibrated).  Keys are the launch keys
@@ -12,9 +12,9 @@ import sys
 
 d = 64
 NAMES = {   # kernel name prefix -> (kind, k, n) of the launch key at hidden_dim 64
-    "mlp_fwd_bf_kernel<2, 2, 3, false, false, false>": ("mlp_fwd", 3 * d, d),
-    "mlp_fwd_bf_kernel<2, 2, 3, false, true, false>": ("mlp_fwd", 3 * d, d),
-    "mlp_bwd_fast_kernel<2, 2, 3>": ("mlp_bwd", 3 * d, d),
+    "mlp_fwd_bf_kernel<2, 2, 3, false, false, false": ("mlp_fwd", 3 * d, d),   # prefixes: later template arguments (CAT, RO) follow
+    "mlp_fwd_bf_kernel<2, 2, 3, false, true, false": ("mlp_fwd", 3 * d, d),
+    "mlp_bwd_fast_kernel<2, 2, 3": ("mlp_bwd", 3 * d, d),
     "wgrad_dma_kernel<3, false>": ("wgrad", d, 3 * d),
     "wgrad_dma_kernel<1, true>": ("wgrad", d, d),
 }
