@@ -242,6 +242,9 @@ int32_t nlam_max_width(void);
 /*   NLAM_TUNE_WGRAD_MIN_PARTS: least number of row slices (= partial sums per element) a weight gradient over more than that
  *   many 32-row chunks is cut into (default 128: launch width for the mid-size problems; smaller = less partial-sum traffic). */
 #define NLAM_TUNE_WGRAD_MIN_PARTS 4
+/*   NLAM_TUNE_WGRAD_BIG_MIN_ROWS: rows (x batch) from which a split-bf16 weight gradient with more than 128 output rows uses
+ *   256 x 256 windows; below it 128 x 128 windows (same launch width, a quarter of the row slices and partial sums). */
+#define NLAM_TUNE_WGRAD_BIG_MIN_ROWS 5
 int32_t nlam_set_tuning(int32_t key, int32_t value);
 /* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this
  * call; 0 when the call runs on the narrow (weights-in-LDS) kernels. */

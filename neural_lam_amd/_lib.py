@@ -23,6 +23,7 @@ TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning keys (include/nlam_hip.h)
 TUNE_WGRAD_CHUNKS = 2
 TUNE_LIN_WGS = 3
 TUNE_WGRAD_MIN_PARTS = 4
+TUNE_WGRAD_BIG_MIN_ROWS = 5
 TILE_SPLIT = 1 << 30
 
 EXPORTS = [
@@ -387,6 +388,8 @@ def load():
         raise RuntimeError("libnlam_hip.so ABI version mismatch")
     if os.environ.get("NLAM_LIN_WGS"):
         lib.nlam_set_tuning(TUNE_LIN_WGS, int(os.environ["NLAM_LIN_WGS"]))
+    if os.environ.get("NLAM_WGRAD_BIG_MIN_ROWS"):
+        lib.nlam_set_tuning(TUNE_WGRAD_BIG_MIN_ROWS, int(os.environ["NLAM_WGRAD_BIG_MIN_ROWS"]))
     if os.environ.get("NLAM_WGRAD_MIN_PARTS"):
         lib.nlam_set_tuning(TUNE_WGRAD_MIN_PARTS, int(os.environ["NLAM_WGRAD_MIN_PARTS"]))
     if os.environ.get("NLAM_WGRAD_CHUNKS"):

@@ -70,6 +70,7 @@ int32_t wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream);      // slice 4
 extern int wbf_min_supertiles;                                     // nlam_set_tuning (defined in slice 1)
 extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
 extern int wgrad_min_parts;                                        // nlam_set_tuning (defined in slice 1)
+extern int wgrad_big_min_rows;                                     // nlam_set_tuning (defined in slice 1)
 extern int lin_resident_wgs;                                       // workgroups of a resident-weight nlam_linear launch (slice 1)
 }  // namespace nlam_detail
 
@@ -3719,6 +3720,14 @@ int wgrad_windows_of(const nlam_wgrad_t* p, int winm, int winn) {
 
 int wgrad_windows(const nlam_wgrad_t* p) { return wgrad_windows_of(p, kWWin, kWWin); }
 
+// split-bf16 weight gradient with more than 128 output rows: 256 x 256 windows (every operand row read once per 256 output
+// columns: the big edge sets are HBM-bound) -- unless the problem has few rows (nlam_set_tuning NLAM_TUNE_WGRAD_BIG_MIN_ROWS):
+// then the operands are L2-resident anyway and 128 x 128 windows give the same launch width with a quarter of the row slices,
+// i.e. a quarter of the partial-sum traffic (128 x 512 KB written and read back for a 20 MB node-level problem at d = 256)
+bool wgrad_wbf_big(const nlam_wgrad_t* p) {
+    return p->m > 128 && (long)p->rows * p->batch >= (long)nlam_detail::wgrad_big_min_rows;
+}
+
 // workgroups of a grouped launch: kMaxGridBlocks dealt in proportion to the members' tiles, at least one each and never
 // more than a member has tiles
 void group_blocks(const long* tiles, int n, int* blocks) {
@@ -3884,6 +3893,7 @@ __global__ void pack_bf_table_kernel(const nlam_pack_rec_t* recs) {
 #if NLAM_IN_TU(1)
 int nlam_detail::wbf_min_supertiles = 192;
 int nlam_detail::lin_resident_wgs = 256;    // NLAM_LIN_WGS (experiments): one per CU
+int nlam_detail::wgrad_big_min_rows = 0;    // rows from which a wide weight gradient uses 256 x 256 windows (0 = always, the round-2 behaviour)
 int nlam_detail::wgrad_min_parts = 128;     // row slices a weight gradient of more than that many 32-row chunks is cut into at least
 int nlam_detail::wgrad_chunks_per_wg = 8;   // A/B at cfg2 (tools/ab_bench.sh): 2.13 -> 2.06 ms per step against one chunk per workgroup
 #endif
@@ -3916,6 +3926,11 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_LIN_WGS) {
         if (value < 0) return NLAM_EINVAL;
         nlam_detail::lin_resident_wgs = value;
+        return 0;
+    }
+    if (key == NLAM_TUNE_WGRAD_BIG_MIN_ROWS) {
+        if (value < 0) return NLAM_EINVAL;
+        nlam_detail::wgrad_big_min_rows = value;
         return 0;
     }
     if (key == NLAM_TUNE_WGRAD_MIN_PARTS) {
@@ -4074,7 +4089,7 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     if (p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) np = (total_chunks + 3) / 4;   // streaming kernel: >= 128 rows per workgroup
     if (wgrad_is_wide(p)) {
         cap = 1024 / wgrad_windows(p);
-        if (wgrad_wbf_ns(p) > 0 && p->m > 128) cap = 256 / wgrad_windows_of(p, 256, 256);   // one 8-wave workgroup per CU
+        if (wgrad_wbf_ns(p) > 0 && wgrad_wbf_big(p)) cap = 256 / wgrad_windows_of(p, 256, 256);   // one 8-wave workgroup per CU
         if (cap < 4) cap = 4;
     }
     if (np > cap) np = cap;
@@ -4616,7 +4631,7 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
 int32_t nlam_detail::wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream) {
         const int wns = wgrad_wbf_ns(p);
         // 256 x 256 windows (8 waves) when the output has more than 128 rows, 128 x 128 windows (4 waves) otherwise
-        const bool big = p->m > 128;
+        const bool big = wgrad_wbf_big(p);
         const int winm = big ? 256 : 128, winn = big ? 256 : 128;
         const size_t lds = (size_t)2 * ((winm + winn) / 32) * wns * 1024;
         const dim3 grid(p->nparts, wgrad_windows_of(p, winm, winn));

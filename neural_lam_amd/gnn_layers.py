@@ -346,6 +346,17 @@ class InteractionNet(nn.Module):
         if isinstance(self.edge_mlp, SplitMLPs) or not self.edge_mlp.fully_fused:
             return self._messages_generic(csr, send_rep, rec_rep, edge_rep, want_out, add_edge)
         key = (str(send_rep.device), send_rep.shape[-2])
+        if csr.has_split and torch.are_deterministic_algorithms_enabled():
+            # receivers with more than 32 in-edges are cut over several tiles whose partial sums meet through atomic adds: the
+            # one place of the fused path whose summation order is not fixed (train_model.py:566 trains with deterministic=True)
+            msg = (f"this edge set has receivers with in-degree > 32 (max {csr.max_in_degree}): their aggregation and receiver "
+                   "gradients use atomic adds and are not bit-reproducible")
+            if torch.is_deterministic_algorithms_warn_only_enabled():
+                import warnings
+
+                warnings.warn(msg)
+            else:
+                raise RuntimeError(msg + "; torch.use_deterministic_algorithms(True) is set")
         if self._factorise(csr, send_rep, rec_rep, edge_rep):
             W1 = self.edge_mlp[0].weight
             d = edge_rep.shape[-1]

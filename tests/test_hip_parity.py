@@ -1012,3 +1012,27 @@ def test_segment_sum_long_and_short_segments_match_index_add(width, nseg, avg, b
     assert torch.equal(got, again)
     assert rel_err(got.cpu().double(), ref) < 1e-5
     assert float(got[:, ::7].cpu().sub(base[:, ::7] if accumulate else 0.0).abs().max()) == 0.0   # empty segments: zero contribution
+
+
+def test_split_receivers_refuse_deterministic_mode(dev):
+    """Receivers with in-degree > 32 are the one place of the fused path that uses atomic adds (NLAM_TILE_SPLIT): under
+    ``torch.use_deterministic_algorithms(True)`` -- what the reference's trainer sets, train_model.py:566 -- such a layer raises
+    (warns in warn-only mode) instead of differing silently from run to run; graphs without split receivers are unaffected."""
+    hl = _hl()
+    ei_split = torch.stack([torch.arange(200) % 50, torch.zeros(200, dtype=torch.int64)])   # receiver 0: in-degree 200
+    ei_split[1, -1] = 3
+    ei_ok = _rand_ei(50, 40, 300, 1)
+    bad, good = hl.InteractionNet(ei_split, 8).to(dev), hl.InteractionNet(ei_ok, 8).to(dev)
+    args_bad = (torch.randn(50, 8, device=dev), torch.randn(4, 8, device=dev), torch.randn(200, 8, device=dev))
+    args_ok = (torch.randn(50, 8, device=dev), torch.randn(40, 8, device=dev), torch.randn(300, 8, device=dev))
+    bad(*args_bad)   # fine without the switch
+    try:
+        torch.use_deterministic_algorithms(True)
+        good(*args_ok)
+        with pytest.raises(RuntimeError, match="in-degree > 32"):
+            bad(*args_bad)
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        with pytest.warns(UserWarning, match="in-degree > 32"):
+            bad(*args_bad)
+    finally:
+        torch.use_deterministic_algorithms(False)
