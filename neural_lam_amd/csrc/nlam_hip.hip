@@ -1063,6 +1063,8 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cq = c0 + (q & 1) * 4 + (q >> 1) * 16;
+                xu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ucol[u] + (q & 1) * 4 + (q >> 1) * 16 >= w) continue;   // wave-uniform: the whole quad lies past the row's end for both lane halves
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int col = min(cq + c, w - 1);   // clamped: the load is unconditional (a predicated load is a branch + a full wait per element)
@@ -1070,7 +1072,6 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
                     const float v = src[col];
                     xu[q][c] = cq + c < w ? v : 0.f;
                 }
-                __builtin_amdgcn_sched_barrier(0);   // one quad's compare masks at a time (all 48 at once spill the scalar file)
             }
             (void)kCatPieces;
             return;
@@ -1087,6 +1088,9 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cq = c0 + (q & 1) * 4 + (q >> 1) * 16;
+                xu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ucol[u] + (q & 1) * 4 + (q >> 1) * 16 >= w) continue;   // wave-uniform: a quad past the row's end for both lane halves costs no loads
+                                                  // (the 2- / 3-column embedder inputs: 4 loads per lane instead of 16)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float v = row[min(cq + c, w - 1)];
