@@ -273,3 +273,61 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.nlam_affine_mix(None, None, None, None, None, None, None, None, 1, 1, 1, None) == EINVAL
     assert lib.nlam_segment_sum(None, 0, None, None, None, None, 1, 1, 1, None) == EINVAL
     assert lib.nlam_segment_sum_acc(None, 0, None, None, None, None, 1, 1, 1, None) == EINVAL
+
+
+def test_pack_and_layout_queries_are_host_logic():
+    """The shape queries behind the round-3 entry points run without a GPU: image sizes of nlam_mlp_pack, the dz2 row stride of a
+    ragged output width, the pack records of a wide launch."""
+    lib = L.load()
+    job = L.PackJob()
+    w1 = torch.zeros(64, 192)
+    w2 = torch.zeros(64, 64)
+    job.W1, job.W2, job.hid, job.dout, job.nsrc = w1.data_ptr(), w2.data_ptr(), 64, 64, 3
+    for k in range(3):
+        job.width[k] = 64
+    job.flags = 3 << 8   # bf16x3
+    # forward image [W1s | W2s]: 3 terms x (64 x 192 + 64 x 64) bf16 = 6 B per weight; backward image the same weights transposed
+    assert lib.nlam_mlp_pack_floats(C.byref(job), 0) == 3 * (64 * 192 + 64 * 64) // 2
+    assert lib.nlam_mlp_pack_floats(C.byref(job), 1) == 3 * (64 * 64 + 3 * 64 * 64) // 2
+    job.flags = 0            # fp32 MFMA mode: no images
+    assert lib.nlam_mlp_pack_floats(C.byref(job), 0) == 0
+    job.flags, job.hid = 3 << 8, 128   # wide: the images are a narrow-kernel format
+    assert lib.nlam_mlp_pack_floats(C.byref(job), 0) == 0
+    job.hid, job.nsrc, job.dout = 64, 1, 17   # output_map: one output block, W2 zero-padded to 32 rows
+    job.width[0] = 64
+    assert lib.nlam_mlp_pack_floats(C.byref(job), 0) == 3 * (64 * 64 + 32 * 64) // 2
+    job.flags |= L.F_PRE_ADD   # factorised: only source 0 has columns in W1
+    job.nsrc, job.dout = 3, 64
+    assert lib.nlam_mlp_pack_floats(C.byref(job), 1) == 3 * (64 * 64 + 64 * 64) // 2
+
+    p = L.MlpBwd()
+    g = torch.zeros(4)
+    p.nsrc, p.batch, p.rows, p.ntiles, p.hid, p.dout, p.flags = 1, 1, 1000, 32, 64, 17, 3 << 8
+    p.src[0].width, p.dmode[0], p.g_out = 64, 1, g.data_ptr()
+    assert lib.nlam_mlp_bwd_dz2_ld(C.byref(p)) == 32          # split-bf16 fast kernel: dz2 padded to the output block
+    p.flags = 0
+    assert lib.nlam_mlp_bwd_dz2_ld(C.byref(p)) == 0           # fp32 matrix mode: the generic kernel, rows of dout floats
+    p.flags, p.dout = 3 << 8, 64
+    assert lib.nlam_mlp_bwd_dz2_ld(C.byref(p)) == 0
+    p.dout, p.ln_w = 17, g.data_ptr()                         # with a LayerNorm the ragged width stays on the generic kernel
+    assert lib.nlam_mlp_bwd_dz2_ld(C.byref(p)) == 0
+
+    f = L.MlpFwd()
+    w1w, w2w = torch.zeros(256, 768), torch.zeros(256, 256)
+    f.nsrc, f.batch, f.rows, f.ntiles, f.hid, f.dout, f.flags = 3, 1, 57616, 1801, 256, 256, 3 << 8
+    for k in range(3):
+        f.src[k].width = 256
+    f.W1, f.W2 = w1w.data_ptr(), w2w.data_ptr()
+    nwp = lib.nlam_mlp_fwd_wpack_floats(C.byref(f))
+    assert nwp > 0
+    buf = torch.zeros(8)
+    f.wpack, f.wpack_floats = buf.data_ptr(), nwp     # only the address goes into the records
+    recs, kind = (L.PackRec * 4)(), C.c_int32(-1)
+    assert lib.nlam_mlp_fwd_pack_records(C.byref(f), recs, 4, C.byref(kind)) == 4 and kind.value == 3   # three W1 sources + W2, three bf16 terms
+    assert lib.nlam_mlp_fwd_pack_records(C.byref(f), recs, 2, C.byref(kind)) == -1                      # capacity
+    f.hid = f.dout = 64
+    for k in range(3):
+        f.src[k].width = 64
+    assert lib.nlam_mlp_fwd_pack_records(C.byref(f), recs, 4, C.byref(kind)) == 0                       # a narrow launch has no wide scratch
+    assert lib.nlam_set_tuning(L.TUNE_WGRAD_MIN_PARTS, 0) == -1 and lib.nlam_set_tuning(L.TUNE_WGRAD_MIN_PARTS, 128) == 0
+    assert lib.nlam_set_tuning(L.TUNE_WGRAD_BIG_MIN_ROWS, -1) == -1 and lib.nlam_set_tuning(L.TUNE_WGRAD_BIG_MIN_ROWS, 0) == 0
