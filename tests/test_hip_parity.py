@@ -853,6 +853,44 @@ def test_rollout_gradients_identical_with_and_without_wgrad_side_streams(dev, tm
     assert (t_par._graph is not None) == use_graph
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("family", ["graph_lam", "hi_lam"])
+def test_early_leaf_backward_gives_the_same_step(dev, tmp_path, family, use_graph):
+    """``Trainer(early_leaf_backward=True)`` (NLAM_EARLY_LEAF=1, off by default) cuts the autograd graph behind the
+    embedders of input data / static features and runs their backward from a post-accumulate hook (a nested
+    backward, ops.early_backward_leaf).  It requires exactly one backward per forward, which is what a Trainer step
+    is.  Only the order of launches changes: the step must equal the default one bit for bit, over a rollout (each
+    embedder is back-propagated once per AR step and accumulates into the same .grad), eager and captured."""
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import models as hm
+    from neural_lam_amd.datastore import SyntheticDatastore
+    from neural_lam_amd.trainer import Trainer
+
+    hier = family != "graph_lam"
+    ds = SyntheticDatastore(81 if hier else 40, 30 if hier else 36, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+    ext = ds.get_xy_extent("state")
+    raw = G.create_regular_grid_graph(ds.get_xy("state"), n_max_levels=3 if hier else None, hierarchical=hier)
+    graph = G.normalise_graph(raw, max(ext[1] - ext[0], ext[3] - ext[2]))
+    build = lambda: hm.MODELS[family](ds, graph=graph, hidden_dim=64, processor_layers=2)
+
+    def make(early):
+        torch.manual_seed(1)
+        fc = hm.ARForecaster(build(), ds)
+        return Trainer(hm.ForecasterStep(fc, ds).to(dev), lr=1e-3, use_graph=use_graph, early_leaf_backward=early)
+
+    t_early, t_base = make(True), make(False)
+    assert t_early.early_leaf_backward and not t_base.early_leaf_backward
+    N, T = ds.num_grid_points, 3
+    g = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        batch = [torch.randn(2, 2, N, 5, generator=g).to(dev), torch.randn(2, T, N, 5, generator=g).to(dev),
+                 torch.randn(2, T, N, 6, generator=g).to(dev)]
+        le, lb = float(t_early.step(*batch)), float(t_base.step(*batch))
+        assert le == lb
+        assert torch.equal(t_early.fp.grad, t_base.fp.grad) and torch.equal(t_early.fp.flat, t_base.fp.flat)
+    assert (t_early._graph is not None) == use_graph
+
+
 def test_graph_step_falls_back_to_eager_for_another_batch_shape(dev, tmp_path):
     """A HIP graph is one shape: a batch of a different shape must not be copied (broadcast) into the captured
     buffers; it takes the eager step, and each returned loss is its own tensor."""
