@@ -14,6 +14,9 @@ from neural_lam_amd import ops  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "m2g"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda:0")
+import os  # noqa: E402
+if os.environ.get("NLAM_KB_AUTOCAST", "0") == "1":   # the one-term (plain bf16) kernels, as under --precision bf16
+    torch.autocast("cuda", dtype=torch.bfloat16).__enter__()
 raw = G.create_regular_grid_graph(G.regular_grid_xy(238, 268))
 ei = raw[f"{which}_edge_index"] if which != "m2m" else raw["m2m_edge_index"][0]
 ns, nr, E = int(ei[0].max()) + 1, int(ei[1].max()) + 1, ei.shape[1]

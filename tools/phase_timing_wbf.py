@@ -1,7 +1,8 @@
 """Per-phase wave cycles of the wide split-bf16 forward (instrumented build, see tools/phase_timing.py).
 
   python tools/phase_timing.py build
-  NLAM_LIB=neural_lam_amd/libnlam_hip_timing.so python tools/phase_timing_wbf.py m2g 256
+  NLAM_LIB=neural_lam_amd/libnlam_hip_timing.so python tools/phase_timing_wbf.py m2g 256 [bf16]
+(third argument "bf16": under torch.autocast, i.e. the one-term kernels)
 """
 import ctypes as C
 import os
@@ -20,6 +21,9 @@ from neural_lam_amd import graph as G  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "m2g"
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = torch.device("cuda:0")
+if len(sys.argv) > 3 and sys.argv[3] == "bf16":
+    _ac = torch.autocast("cuda", dtype=torch.bfloat16)
+    _ac.__enter__()   # for the whole script
 lib = L.load()
 lib.nlam_debug_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
 raw = G.create_regular_grid_graph(G.regular_grid_xy(238, 268))
