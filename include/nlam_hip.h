@@ -196,8 +196,8 @@ typedef struct {
     int32_t vec_stride;    /* row stride of vec_partials: multiple of 64, >= max(hid, dout) */
     float* wpack;          /* >= nlam_mlp_bwd_wpack_floats(p) floats, or NULL when that is 0 */
     int64_t wpack_floats;
-    const float* b1;       /* NLAM_F_LEAF_WGRAD only: first-layer bias; with z1 == NULL the kernel recomputes the pre-activation
-                              z1 = W1 x + b1 from the (<= 4-column) input instead of reading a saved copy */
+    const float* b1;       /* NLAM_F_LEAF_WGRAD only (required there): first-layer bias; that kernel recomputes the pre-activation
+                              z1 = W1 x + b1 from the (<= 4-column) input row and never reads `z1` (which may be NULL) */
     int32_t dz2_ld;        /* floats between rows of dz2: MUST equal nlam_mlp_bwd_dz2_ld(p) -- 0 = dout, except for an output width
                               that is not a multiple of 32 on the split-bf16 kernel (output_map, dout = 17): then 32-padded, the
                               columns past dout are written as zeros, and nlam_wgrad takes dz2 with m = that stride */

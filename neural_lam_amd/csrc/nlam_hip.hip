@@ -1826,8 +1826,10 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         }
     }
     stage_vec(gml, p.ln_w, p.dout, OP, 1.f);
-    const bool recompute_z = LW && p.z1 == nullptr;
-    if (LW && recompute_z) {
+    // LW always recomputes z1 = W1 x + b1 from the tile's input row (the grouped forward does not save it); a run-time choice
+    // between that and a load would put a full wait for every outstanding request -- the next tile's rows -- behind the branch
+    constexpr bool recompute_z = LW;
+    if constexpr (LW) {
         const int kw = p.src[0].width;
         for (int e = threadIdx.x; e < DPH * 4; e += blockDim.x) {
             const int f_ = e >> 2, k_ = e & 3;
@@ -1853,6 +1855,19 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
     enum { kDb1 = 0, kDb2 = 2, kDg = 4, kDbt = 6 };
 #pragma unroll
     for (int k = 0; k < 8; ++k) colacc[k * 64] = 0.f;
+    float creg[LW ? 8 : 1];   // LW (512 registers per lane): the same accumulators in registers
+#pragma unroll
+    for (int k = 0; k < (LW ? 8 : 1); ++k) creg[k] = 0.f;
+    constexpr bool kColRegs = false;   // LW with the accumulators in registers: 12 VGPRs spilled (the scratch traffic then shares the
+                                       // load counter with the prefetch) -- they stay in LDS
+    auto cadd = [&](int k, float v) {   // k is a compile-time constant at every (unrolled) call site
+        if constexpr (LW && kColRegs) creg[k] += v;
+        else colacc[k * 64] += v;
+    };
+    auto cget = [&](int k) -> float {
+        if constexpr (LW && kColRegs) return creg[k];
+        else return colacc[k * 64];
+    };
     float* xs = xs_all + (size_t)wave * 32 * 4;
     f32x16 dw2[LW ? OB : 1][LW ? HB : 1];   // LW: this wave's share of dW2 (block (ob, hb): rows = output features, lane & 31 = hidden feature)
     float dw1c[LW ? HB : 1][3];             // LW: this lane's share of dW1[32 hb + (lane & 31)][k]
@@ -1868,14 +1883,57 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
     }
 
     const long total_tiles = (long)p.ntiles * p.batch;
-    // LW (one wave per SIMD: nothing else hides a load): the g_out rows of the NEXT tile are fetched while this tile is worked
-    // on, when the next tile's rows are known without loads (plain 32-row tiles, identity row order: the embedders)
-    const bool lw_prefetch = LW && p.tiles == nullptr && p.out_idx == nullptr && p.g_aggr == nullptr && p.g_out != nullptr;
+    // LW (one wave per SIMD: nothing else hides a load, and 512 registers per lane to itself): every global row of a tile --
+    // g_out, xhat, rstd, the input row -- is requested a whole tile ahead.  The launcher admits plain 32-row tiles in identity
+    // row order only (nlam_mlp_bwd_group), so the next tile's rows are known without loads; the requests are unconditional
+    // (a wave's last tile asks for the last tile again): with a conditional request the compiler has to merge the wait
+    // counters of both paths and waits for the fresh requests at the next use of ANY loaded value.
     f32x4 gpre[LW ? OB : 1][4];
-    bool gpre_ready = false;
+    f32x4 xpre[LW ? OB : 1][4];
+    float rpre = 0.f;
+    float xipre[4] = {0.f, 0.f, 0.f, 0.f};
+    auto lw_row = [&](long gn, int& bn, long& rown) {
+        gn = gn < total_tiles ? gn : total_tiles - 1;
+        bn = (int)(gn / p.ntiles);
+        rown = min((long)(gn % p.ntiles) * 32 + j, (long)p.rows - 1);
+    };
+    auto lw_request_g = [&](long gn) {
+        int bn;
+        long rown;
+        lw_row(gn, bn, rown);
+        const float* gnrow = p.g_out + (long)bn * p.out_bstride + rown * p.dout;
+#pragma unroll
+        for (int o2 = 0; o2 < (LW ? OB : 1); ++o2)
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) gpre[o2][t2] = *reinterpret_cast<const f32x4*>(gnrow + 8 * (o2 * 4 + t2) + 4 * hi);
+    };
+    auto lw_request_x = [&](long gn) {
+        int bn;
+        long rown;
+        lw_row(gn, bn, rown);
+        const size_t srn = (size_t)bn * p.rows + rown;
+        {   // without a LayerNorm the same requests read g_out again (values unused): unconditional, see above
+            const float* xn = has_ln ? p.xhat + srn * p.dout : p.g_out + (long)bn * p.out_bstride + rown * p.dout;
+#pragma unroll
+            for (int o2 = 0; o2 < (LW ? OB : 1); ++o2)
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) xpre[o2][t2] = *reinterpret_cast<const f32x4*>(xn + 8 * (o2 * 4 + t2) + 4 * hi);
+            rpre = *(has_ln ? p.rstd + srn : xn);
+        }
+        const int kw = p.src[0].width;
+        const float* xr = p.src[0].ptr + (long)bn * p.src[0].bstride + rown * kw;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xipre[k] = xr[k < kw ? k : 0];   // <= 4 columns: clamp, select below
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xipre[k] = k < kw ? xipre[k] : 0.f;
+    };
+    if constexpr (LW) {
+        lw_request_g((long)wave * wg_count + wg_id);
+        lw_request_x((long)wave * wg_count + wg_id);
+    }
     for (long gt = (long)wave * wg_count + wg_id; gt < total_tiles; gt += (long)wg_count * NWV) {
         const int b = (int)(gt / p.ntiles);
-        const TileInfo tl = get_tile(p.tiles, (int)(gt % p.ntiles), p.rows);
+        const TileInfo tl = get_tile(LW ? nullptr : p.tiles, (int)(gt % p.ntiles), p.rows);
         const bool valid = j < tl.nrows;
         const int prow = tl.row0 + j;
         const int prow_c = min(tl.row0 + max(min(j, tl.nrows - 1), 0), p.rows - 1);   // clamped: loads never fault
@@ -1886,31 +1944,54 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         ++t_ntiles_;
 #endif
         // ---- indices ----
+        // (LW: the launcher admits plain row-ordered leaf MLPs only -- no output index, no aggregated gradient, no gathered source,
+        // no receivers; none of these conditional loads may exist in its tile loop, see the prefetch above)
         int oidx = prow_c;
-        if (p.g_out != nullptr && p.out_idx != nullptr) oidx = p.out_idx[prow_c];
         int sg = 0;
         float gscale = 1.f;
-        if (p.g_aggr != nullptr) {
-            sg = p.seg_of_row[prow_c];
-            if (p.flags & NLAM_F_MEAN) gscale = p.inv_deg[sg];
-        }
         int sidx[NLAM_MAX_SRC] = {prow_c, prow_c, prow_c};
-#pragma unroll
-        for (int s = 0; s < NLAM_MAX_SRC; ++s)
-            if (s < p.nsrc && p.dmode[s] == 1 && p.src[s].idx != nullptr) sidx[s] = p.src[s].idx[prow_c];
         int raw_ptr = 0;
-        if (p.rowptr != nullptr && !tl.split && lane <= tl.nseg) raw_ptr = p.rowptr[tl.seg0 + lane];
-        const float rstd = has_ln ? p.rstd[srow_c] : 0.f;
+        if constexpr (!LW) {
+            if (p.g_out != nullptr && p.out_idx != nullptr) oidx = p.out_idx[prow_c];
+            if (p.g_aggr != nullptr) {
+                sg = p.seg_of_row[prow_c];
+                if (p.flags & NLAM_F_MEAN) gscale = p.inv_deg[sg];
+            }
+#pragma unroll
+            for (int s = 0; s < NLAM_MAX_SRC; ++s)
+                if (s < p.nsrc && p.dmode[s] == 1 && p.src[s].idx != nullptr) sidx[s] = p.src[s].idx[prow_c];
+            if (p.rowptr != nullptr && !tl.split && lane <= tl.nseg) raw_ptr = p.rowptr[tl.seg0 + lane];
+        }
+        constexpr bool from_pre = LW;   // this tile's g_out / xhat rows, rstd and input row were requested a tile ago
+        float rstd = 0.f;
+        // LW: take this tile's rows out of the prefetch registers and request the next tile's right away: they have the whole
+        // tile to arrive, and no other global load (hence no wait on the load counter) follows before the next tile's top
+        f32x4 gcur[LW ? OB : 1][4], xcur[LW ? OB : 1][4];
+        float xicur[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (LW) {
+            rstd = rpre;
+#pragma unroll
+            for (int o2 = 0; o2 < OB; ++o2)
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    gcur[o2][t2] = gpre[o2][t2];
+                    xcur[o2][t2] = xpre[o2][t2];
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xicur[k] = xipre[k];
+            lw_request_g(gt + (long)wg_count * NWV);
+            lw_request_x(gt + (long)wg_count * NWV);
+        } else {
+            rstd = has_ln ? p.rstd[srow_c] : 0.f;
+        }
         const float* grow = p.g_out != nullptr ? p.g_out + (long)b * p.out_bstride + (long)oidx * p.dout : nullptr;
         const float* garow = p.g_aggr != nullptr ? p.g_aggr + ((size_t)b * p.nseg_total + sg) * p.dout : nullptr;
         const float* xrow = has_ln ? p.xhat + srow_c * p.dout : nullptr;
         const float* zrow = p.z1 != nullptr ? p.z1 + srow_c * p.hid : nullptr;
         if constexpr (LW) {   // the tile's input rows (<= 4 columns), zero past the width and past the tile's rows
             if (hi == 0) {
-                const int kw = p.src[0].width;
-                const float* xr = p.src[0].ptr + (long)b * p.src[0].bstride + (long)prow_c * kw;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) xs[j * 4 + k] = (valid && k < kw) ? xr[k] : 0.f;
+                for (int k = 0; k < 4; ++k) xs[j * 4 + k] = valid ? xicur[k] : 0.f;
             }
             wave_lds_sync();
         }
@@ -1930,46 +2011,39 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
                 for (int tt = 0; tt < 4; ++tt) {
                     const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
                     f32x4 g = {0.f, 0.f, 0.f, 0.f};
-                    if (LW && gpre_ready) g = gpre[LW ? ob : 0][tt];
+                    if constexpr (from_pre) g = gcur[LW ? ob : 0][tt];
                     else if (RO) {
                         if (grow != nullptr) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) g[c] = c0 + c < p.dout ? grow[c0 + c] : 0.f;
                         }
                     } else if (grow != nullptr) g = *reinterpret_cast<const f32x4*>(grow + c0);
-                    if (garow != nullptr) g += *reinterpret_cast<const f32x4*>(garow + c0) * gscale;
+                    if constexpr (!LW) {
+                        if (garow != nullptr) g += *reinterpret_cast<const f32x4*>(garow + c0) * gscale;
+                    }
                     if (!valid) g = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (has_ln) xh[tt] = *reinterpret_cast<const f32x4*>(xrow + c0);
+                    if (has_ln) {
+                        if constexpr (from_pre) xh[tt] = xcur[LW ? ob : 0][tt];
+                        else xh[tt] = *reinterpret_cast<const f32x4*>(xrow + c0);
+                    }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) dz2[ob][4 * tt + c] = g[c];
                 }
-                if (LW && ob == OB - 1) {   // all of this tile's g rows are in dz2: issue the next tile's
-                    gpre_ready = false;
-                    const long gn = gt + (long)wg_count * NWV;
-                    if (lw_prefetch && gn < total_tiles) {
-                        const int bn = (int)(gn / p.ntiles);
-                        const long rown = min((long)(gn % p.ntiles) * 32 + j, (long)p.rows - 1);
-                        const float* gnrow = p.g_out + (long)bn * p.out_bstride + rown * p.dout;
-#pragma unroll
-                        for (int o2 = 0; o2 < OB; ++o2)
-#pragma unroll
-                            for (int t2 = 0; t2 < 4; ++t2) gpre[LW ? o2 : 0][t2] = *reinterpret_cast<const f32x4*>(gnrow + 8 * (o2 * 4 + t2) + 4 * hi);
-                        gpre_ready = true;
-                    }
-                }
+                if constexpr (LW) { NLAM_T_MARK(8) }
                 if (has_ln) {
                     // dbeta = colsum(dmsg), dgamma = colsum(dmsg * xhat), through the staged block
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt);
                     wave_lds_sync();
-                    colacc[(kDbt + ob) * 64] += block_colsum_half(stg, lane);
+                    cadd(kDbt + ob, block_colsum_half(stg, lane));
                     wave_lds_sync();
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt)
                         *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt) * xh[tt];
                     wave_lds_sync();
-                    colacc[(kDg + ob) * 64] += block_colsum_half(stg, lane);
+                    cadd(kDg + ob, block_colsum_half(stg, lane));
                     wave_lds_sync();
+                    if constexpr (LW) { NLAM_T_MARK(9) }
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
                         const f32x4 gm = *reinterpret_cast<const f32x4*>(&gml[8 * (ob * 4 + tt) + 4 * hi]);
@@ -1981,6 +2055,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
                             m2 += gy * xh[tt][c];
                         }
                     }
+                    if constexpr (LW) { NLAM_T_MARK(10) }
                 }
             }
             if (has_ln) {
@@ -1990,7 +2065,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
                 for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
-                        const f32x4 xh = LW ? *reinterpret_cast<const f32x4*>(xrow + 8 * (ob * 4 + tt) + 4 * hi) : xhs[LW ? 0 : ob][tt];
+                        const f32x4 xh = LW ? xcur[LW ? ob : 0][tt] : xhs[LW ? 0 : ob][tt];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const float v = rstd * (dz2[ob][4 * tt + c] - m1 - xh[c] * m2);
@@ -2000,13 +2075,13 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
             }
         }
         NLAM_T_MARK(2)
-        // ---- dz2 rows out (for wgrad) + db2 ----
+        // ---- dz2 rows out (for wgrad) + db2 ----  (LW: db2 falls out of the transposed dz2 fragments of dW2 below)
 #pragma unroll
-        for (int ob = 0; ob < OB; ++ob) {
+        for (int ob = 0; ob < (LW ? 0 : OB); ++ob) {
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt);
             wave_lds_sync();
-            colacc[(kDb2 + ob) * 64] += block_colsum_half(stg, lane);
+            cadd(kDb2 + ob, block_colsum_half(stg, lane));
             if (!LW && p.dz2 != nullptr) {
                 const size_t ldz2 = RO ? (size_t)OP : (size_t)p.dout;
                 float* dbase = p.dz2 + tile_row0 * ldz2 + 32 * ob;
@@ -2042,22 +2117,28 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         // LW: dz2^T fragments (A operand of dW2: feature lane & 31, rows 16 s + 8 hi .. + 7), made AFTER the dh GEMM so that
         // they are not live across it (the blocks are re-staged from the registers the GEMM has just read)
         BfFrag<NSW> a2[LW ? OB : 1][2];
+        if constexpr (LW) { NLAM_T_MARK(11) }
         if constexpr (LW) {
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(dz2[ob], tt);
                 wave_lds_sync();
+                float cs = 0.f;   // db2: this lane reads column j, rows 8 hi .. + 7 and 16 + 8 hi .. + 7 -- half of the column's sum
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     float a8[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) a8[q] = stg[(16 * s2 + 8 * hi + q) * kStgStride + j];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) cs += a8[q];
                     a2[ob][s2] = split8<NSW>(a8);
                     __builtin_amdgcn_sched_barrier(0);   // one fragment at a time (the scheduler otherwise interleaves the conversions: VGPRs)
                 }
+                cadd(kDb2 + ob, cs);
                 wave_lds_sync();
             }
+            NLAM_T_MARK(5)
         }
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb) {
@@ -2065,7 +2146,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 f32x4 z;
-                if (LW && recompute_z) {   // z1 = W1 x + b1 from the tile's input row (three FMAs per element) instead of a saved copy
+                if constexpr (recompute_z) {   // z1 = W1 x + b1 from the tile's input row (three FMAs per element) instead of a saved copy
                     const int f0 = 8 * (hb * 4 + tt) + 4 * hi;
                     const f32x4 xr = *reinterpret_cast<const f32x4*>(&xs[j * 4]);
                     z = *reinterpret_cast<const f32x4*>(&w1l[DPH * 4 + f0]);
@@ -2092,7 +2173,8 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
                 *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = v;
             }
             wave_lds_sync();
-            colacc[(kDb1 + hb) * 64] += block_colsum_half(stg, lane);
+            cadd(kDb1 + hb, block_colsum_half(stg, lane));
+            if constexpr (LW) { NLAM_T_MARK(7) }
             if constexpr (LW) {
                 __builtin_amdgcn_sched_barrier(0);
                 // dW1[:, k] += sum_rows dz1[row][:] * x[row][k]: the column sums of db1 with the input column as weight
@@ -2270,10 +2352,10 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         float* red = stg_all;   // NWV x 4 x 64 floats (fits: 8 x 32 x 36 staging)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const float v1 = k < HB ? colacc[(kDb1 + k) * 64] : 0.f;
-            const float v2 = k < OB ? colacc[(kDb2 + k) * 64] : 0.f;
-            const float v3 = k < OB ? colacc[(kDg + k) * 64] : 0.f;
-            const float v4 = k < OB ? colacc[(kDbt + k) * 64] : 0.f;
+            const float v1 = k < HB ? cget(kDb1 + k) : 0.f;
+            const float v2 = k < OB ? cget(kDb2 + k) : 0.f;
+            const float v3 = k < OB ? cget(kDg + k) : 0.f;
+            const float v4 = k < OB ? cget(kDbt + k) : 0.f;
             // lane (c, half): add the two row halves, keep in lanes < 32 -> column 32 * k + c
             const float s1 = v1 + __shfl_xor(v1, 32, 64), s2 = v2 + __shfl_xor(v2, 32, 64);
             const float s3 = v3 + __shfl_xor(v3, 32, 64), s4 = v4 + __shfl_xor(v4, 32, 64);
@@ -4493,7 +4575,7 @@ extern "C" int32_t nlam_mlp_bwd_group(const nlam_mlp_bwd_t* ps, int32_t n, void*
     for (int k = 0; k < n; ++k) {
         const nlam_mlp_bwd_t& p = ps[k];
         if (p.W1 == nullptr || p.W2 == nullptr || p.batch < 1 || p.rows < 1 || p.g_out == nullptr) return NLAM_EINVAL;
-        if (p.z1 == nullptr && ((p.flags & NLAM_F_LEAF_WGRAD) == 0 || p.b1 == nullptr)) return NLAM_EINVAL;
+        if ((p.flags & NLAM_F_LEAF_WGRAD) ? p.b1 == nullptr : p.z1 == nullptr) return NLAM_EINVAL;   // fused weight gradients: z1 is recomputed
         if (p.nsrc != 1 || bwd_is_wide(&p) || p.hid != ps[0].hid || p.dout != ps[0].dout || p.hid % 32 != 0 || p.dout % 32 != 0) return NLAM_EUNSUP;
         if ((p.flags & ~(NLAM_F_MM_MASK | NLAM_F_LEAF_WGRAD)) != 0 || (p.flags & (NLAM_F_MM_MASK | NLAM_F_LEAF_WGRAD)) != (ps[0].flags & (NLAM_F_MM_MASK | NLAM_F_LEAF_WGRAD)))
             return NLAM_EUNSUP;

@@ -286,6 +286,46 @@ def test_plain_mlp_matches_oracle(dev, kin, hid, dout, ln, wide_family):
         assert rel_err(p.grad.cpu(), q.grad) < TOL, k
 
 
+@pytest.mark.parametrize("fused_wgrad", [True, False])
+@pytest.mark.parametrize("d,shapes", [
+    (64, [(40003, 3), (131075, 3), (6561, 2), (33, 3)]),   # > 1 016 waves x 32 rows: a wave walks several tiles (next-tile prefetch)
+    (64, [(1, 3), (31, 1), (64, 3)]),                      # fewer tiles than waves, a single row, a one-column member
+    (32, [(5000, 3), (70001, 2)]),
+    (64, [(3000, 3), (2000, 5)]),                          # a 5-column member: not a leaf-weight-gradient shape -> the plain grouped backward
+])
+def test_grouped_static_embedders_match_oracle(dev, monkeypatch, d, shapes, fused_wgrad):
+    """gnn_layers.grouped_mlp_forward: the embedders of the static features (graph/base.py:286-295) as ONE launch each way.
+    With <= 3 input columns the backward accumulates the weight gradients in the kernel (NLAM_F_LEAF_WGRAD: z1 recomputed
+    from the input row, the next tile's g_out / xhat / rstd / input rows requested a tile ahead); outputs and every parameter
+    gradient against the oracle MLPs, with the fused weight gradients on and off, ragged last tiles included."""
+    from neural_lam_amd import ops
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    monkeypatch.setattr(ops, "FUSED_LEAF_WGRAD", fused_wgrad)
+    torch.manual_seed(d + len(shapes))
+    refs = [og.make_mlp([k, d, d]) for _, k in shapes]
+    nets = []
+    for r, (_, k) in zip(refs, shapes):
+        n = hl.make_mlp([k, d, d])
+        n.load_state_dict(r.state_dict())
+        nets.append(n.to(dev))
+    xs = [torch.randn(rows, k) for rows, k in shapes]
+    cots = [torch.randn(rows, d) for rows, _ in shapes]
+    outs = hl.grouped_mlp_forward([(n, x.to(dev)) for n, x in zip(nets, xs)])
+    for rep in range(2):   # twice: .grad accumulates (the kernel adds its partial sums to what is there)
+        if rep:
+            outs = hl.grouped_mlp_forward([(n, x.to(dev)) for n, x in zip(nets, xs)])
+        torch.autograd.backward(outs, [c.to(dev) for c in cots])
+    for r, x, c, o in zip(refs, xs, cots, outs):
+        y = r(x)
+        assert rel_err(o.cpu(), y) < TOL
+        (2.0 * (y * c).sum()).backward()
+    for i, (n, r) in enumerate(zip(nets, refs)):
+        for (k, pp), (_, q) in zip(n.named_parameters(), r.named_parameters()):
+            assert rel_err(pp.grad.cpu(), q.grad) < TOL, (i, k)
+
+
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16", "f32"])
 @pytest.mark.parametrize("widths,hid,B,shared_last", [
     ([17, 17, 18, 4], 64, 2, True),    # the grid input features of the MEPS configuration (graph/base.py:275-283): 56 columns
