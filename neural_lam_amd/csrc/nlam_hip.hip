@@ -55,6 +55,19 @@
 #define NLAM_RES_PRE 3   // narrow forward with a residual stash: input units prefetched a tile ahead (4 spilled in the tile loop;
                          // A/B at cfg2: 3 vs 4 vs 2 = same training step, +2.5 % forecast rate for 3)
 #endif
+#ifndef NLAM_BWD_G_BATCH
+#define NLAM_BWD_G_BATCH 2   // narrow backward, requests of the g_out / aggregated-gradient / xhat rows: 2 = the whole tile back to back,
+                             // 1 = one 32-column block at a time, 0 = one 16-byte chunk at a time (unconditional either way)
+#endif
+#ifndef NLAM_BWD_Z_EARLY
+#define NLAM_BWD_Z_EARLY 1   // z1 rows requested ahead of the dz2 stores (1) or one block at a time where they are used (0)
+#endif
+#ifndef NLAM_BWD_R_EARLY
+#define NLAM_BWD_R_EARLY 0   // residual (d src0 += g_out) rows requested ahead of the dh GEMM (1) or chunk by chunk behind the dx GEMM (0).
+                             // A/B at cfg2, five builds inside one gpurun call: G_BATCH 0 / 1 / 2 and Z_EARLY 0 / 1 are within noise of each
+                             // other and 2 % ahead of the branchy loads; R_EARLY = 1 makes the isolated kernel 10 % faster and the captured
+                             // step 6 % SLOWER (1.80 -> 1.91 ms): 32 more registers live across both GEMMs of every chain kernel
+#endif
 #define NLAM_IN_TU(k) (NLAM_TU == 0 || NLAM_TU == (k))
 
 namespace nlam_detail {   // launchers: external linkage, each defined in exactly one slice; arguments are already validated
@@ -228,9 +241,12 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MB], const float* Ap, in
 // note: (((mb*T + t)*2 + hi)*32 + i) == ((mb*T + t)*64 + lane) because lane = hi*32 + i.
 
 // chunk t of one row (row pointer already resolved); zero outside [0, w)
+// (c0 is made opaque: `c0 < w` is invariant across the tiles of a launch, and hoisted out of the tile loops these compares
+// become hundreds of scalar masks spilled to VGPR lanes -- a v_readlane pair plus hazard slots at every use instead of one v_cmp)
 __device__ __forceinline__ f32x4 load_chunk(const float* row, int w, int t, int hi, bool valid) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const int c0 = 8 * t + 4 * hi;
+    int c0 = 8 * t + 4 * hi;
+    asm volatile("" : "+v"(c0));
     if (valid && c0 < w) {
         if ((w & 3) == 0) {
             v = *reinterpret_cast<const f32x4*>(row + c0);
@@ -244,7 +260,8 @@ __device__ __forceinline__ f32x4 load_chunk(const float* row, int w, int t, int 
 }
 
 __device__ __forceinline__ void store_chunk(float* row, int w, int t, int hi, bool valid, f32x4 v) {
-    const int c0 = 8 * t + 4 * hi;
+    int c0 = 8 * t + 4 * hi;
+    asm volatile("" : "+v"(c0));
     if (valid && c0 < w) {
         if ((w & 3) == 0) {
             *reinterpret_cast<f32x4*>(row + c0) = v;
@@ -1062,7 +1079,11 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
             const int w = p.src[0].width, c0 = ucol[u] + 8 * hi;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cq = c0 + (q & 1) * 4 + (q >> 1) * 16;
+                int cq = c0 + (q & 1) * 4 + (q >> 1) * 16;
+                // opaque to the optimiser: the column-range compares below are tile-invariant, and hoisted out of the tile loop they
+                // become ~340 scalar masks spilled to VGPR lanes (v_readlane pairs at every use, six VGPRs, and with them two
+                // VGPR spills = a scratch segment, which slows every dispatch of the kernel); recomputed they are one v_cmp each
+                asm volatile("" : "+v"(cq));
                 xu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (ucol[u] + (q & 1) * 4 + (q >> 1) * 16 >= w) continue;   // wave-uniform: the whole quad lies past the row's end for both lane halves
 #pragma unroll
@@ -1087,7 +1108,8 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
         } else {               // ragged source: element-wise, zero past its width (clamped column: unconditional loads)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cq = c0 + (q & 1) * 4 + (q >> 1) * 16;
+                int cq = c0 + (q & 1) * 4 + (q >> 1) * 16;
+                asm volatile("" : "+v"(cq));   // see the concatenated-pieces path: keeps the column compares inside the tile loop
                 xu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (ucol[u] + (q & 1) * 4 + (q >> 1) * 16 >= w) continue;   // wave-uniform: a quad past the row's end for both lane halves costs no loads
                                                   // (the 2- / 3-column embedder inputs: 4 loads per lane instead of 16)
@@ -1742,6 +1764,10 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_kernel(const nlam_mlp_b
 // operands taken straight from the accumulator registers (slot-permuted K order, see the
 // split-bf16 notes above).
 // ---------------------------------------------------------------------------
+// 16 zero bytes: the source of a load whose tensor is absent (a null row pointer becomes this address with stride 0, so the
+// load stays unconditional) and of LDS-DMA lanes past the end of a row
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 // column sums of the wave's staged 32-column block: lane -> (column, half of the rows)
 __device__ __forceinline__ float block_colsum_half(const float* stg, int lane) {
     const int c = lane & 31, r0 = (lane >> 5) * 16;
@@ -1898,6 +1924,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         rown = min((long)(gn % p.ntiles) * 32 + j, (long)p.rows - 1);
     };
     auto lw_request_g = [&](long gn) {
+        if constexpr (!LW) return;   // (no captures, no closure object, in the other instantiations)
         int bn;
         long rown;
         lw_row(gn, bn, rown);
@@ -1908,6 +1935,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
             for (int t2 = 0; t2 < 4; ++t2) gpre[o2][t2] = *reinterpret_cast<const f32x4*>(gnrow + 8 * (o2 * 4 + t2) + 4 * hi);
     };
     auto lw_request_x = [&](long gn) {
+        if constexpr (!LW) return;
         int bn;
         long rown;
         lw_row(gn, bn, rown);
@@ -1996,20 +2024,70 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
             wave_lds_sync();
         }
 
+        // Every row the tile needs -- g_out, the aggregated gradient, xhat, z1 -- is requested here, unconditionally and back to
+        // back (an absent tensor reads one zero chunk: pointer select + stride 0).  As `if (ptr) g += load` per chunk, each chunk
+        // was a branch with its own full wait (the compiler merges the wait counters of both paths): 8 + 8 serial round trips per
+        // tile, the z1 ones behind the dz2 stores on top (a load behind a store waits for the store's acknowledgement).
+        f32x4 xhs[LW ? 1 : OB][4];
+        f32x4 gq[LW ? 1 : OB][4], aq[LW ? 1 : OB][4], zq[LW ? 1 : HB][4];
+        if constexpr (!LW) {
+            const float* gp = grow != nullptr ? grow : g_zero16;
+            const float* ap = garow != nullptr ? garow : g_zero16;
+            const float* xp = has_ln ? xrow : g_zero16;
+            const int gm = grow != nullptr ? 1 : 0, am = garow != nullptr ? 1 : 0, xm = has_ln ? 1 : 0;
+            if constexpr (NLAM_BWD_G_BATCH == 2) {
+#pragma unroll
+                for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
+                        if constexpr (!RO) gq[ob][tt] = *reinterpret_cast<const f32x4*>(gp + gm * c0);
+                        aq[ob][tt] = *reinterpret_cast<const f32x4*>(ap + am * c0);
+                        xhs[ob][tt] = *reinterpret_cast<const f32x4*>(xp + xm * c0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise pulls the first chunks' arithmetic (and their waits) in between the requests
+            }
+        }
+        auto request_block = [&](int ob) {   // NLAM_BWD_G_BATCH == 1
+            const float* gp = grow != nullptr ? grow : g_zero16;
+            const float* ap = garow != nullptr ? garow : g_zero16;
+            const float* xp = has_ln ? xrow : g_zero16;
+            const int gm = grow != nullptr ? 1 : 0, am = garow != nullptr ? 1 : 0, xm = has_ln ? 1 : 0;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
+                if constexpr (!RO) gq[LW ? 0 : ob][tt] = *reinterpret_cast<const f32x4*>(gp + gm * c0);
+                aq[LW ? 0 : ob][tt] = *reinterpret_cast<const f32x4*>(ap + am * c0);
+                xhs[LW ? 0 : ob][tt] = *reinterpret_cast<const f32x4*>(xp + xm * c0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto request_chunk = [&](int ob, int tt) {   // NLAM_BWD_G_BATCH == 0
+            const float* gp = grow != nullptr ? grow : g_zero16;
+            const float* ap = garow != nullptr ? garow : g_zero16;
+            const float* xp = has_ln ? xrow : g_zero16;
+            const int gm = grow != nullptr ? 1 : 0, am = garow != nullptr ? 1 : 0, xm = has_ln ? 1 : 0;
+            const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
+            if constexpr (!RO) gq[LW ? 0 : ob][tt] = *reinterpret_cast<const f32x4*>(gp + gm * c0);
+            aq[LW ? 0 : ob][tt] = *reinterpret_cast<const f32x4*>(ap + am * c0);
+            xhs[LW ? 0 : ob][tt] = *reinterpret_cast<const f32x4*>(xp + xm * c0);
+        };
+
         NLAM_T_MARK(1)
         // ---- dmsg (C-layout chunks), LayerNorm backward ----
         f32x16 dz2[OB];
         {
             float m1 = 0.f, m2 = 0.f;
             // xhat stays in registers between its two uses (the big edge sets are HBM-bound: one read); the fused-weight-gradient
-            // variant carries 64 accumulator registers through the tile loop and re-reads it (an L2 hit) instead
-            f32x4 xhs[LW ? 1 : OB][4];
+            // variant carries 64 accumulator registers through the tile loop and takes it from its prefetch registers
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob) {
                 f32x4(&xh)[4] = xhs[LW ? 0 : ob];
+                if constexpr (!LW && NLAM_BWD_G_BATCH == 1) request_block(ob);
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     const int c0 = 8 * (ob * 4 + tt) + 4 * hi;
+                    if constexpr (!LW && NLAM_BWD_G_BATCH == 0) request_chunk(ob, tt);
                     f32x4 g = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (from_pre) g = gcur[LW ? ob : 0][tt];
                     else if (RO) {
@@ -2017,14 +2095,13 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
 #pragma unroll
                             for (int c = 0; c < 4; ++c) g[c] = c0 + c < p.dout ? grow[c0 + c] : 0.f;
                         }
-                    } else if (grow != nullptr) g = *reinterpret_cast<const f32x4*>(grow + c0);
-                    if constexpr (!LW) {
-                        if (garow != nullptr) g += *reinterpret_cast<const f32x4*>(garow + c0) * gscale;
+                    } else {
+                        g = gq[LW ? 0 : ob][tt];
                     }
+                    if constexpr (!LW) g += aq[LW ? 0 : ob][tt] * gscale;
                     if (!valid) g = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (has_ln) {
-                        if constexpr (from_pre) xh[tt] = xcur[LW ? ob : 0][tt];
-                        else xh[tt] = *reinterpret_cast<const f32x4*>(xrow + c0);
+                    if constexpr (from_pre) {
+                        if (has_ln) xh[tt] = xcur[LW ? ob : 0][tt];
                     }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) dz2[ob][4 * tt + c] = g[c];
@@ -2075,6 +2152,13 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
             }
         }
         NLAM_T_MARK(2)
+        if constexpr (!LW && NLAM_BWD_Z_EARLY == 1) {   // z1 rows: requested ahead of the dz2 stores, needed behind the dh GEMM
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) zq[hb][tt] = *reinterpret_cast<const f32x4*>(zrow + 8 * (hb * 4 + tt) + 4 * hi);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- dz2 rows out (for wgrad) + db2 ----  (LW: db2 falls out of the transposed dz2 fragments of dW2 below)
 #pragma unroll
         for (int ob = 0; ob < (LW ? 0 : OB); ++ob) {
@@ -2091,6 +2175,17 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         }
 
         NLAM_T_MARK(3)
+        // out = msg + src0 (edge update / node residual): d src0 += g_out.  NLAM_BWD_R_EARLY = 1 requests its rows again here, ahead
+        // of the dz1 stores; the shipped 0 re-reads them chunk by chunk behind the dx GEMM of source 0 (see the macro)
+        f32x4 rq[LW ? 1 : OB][4];
+        if constexpr (!LW && NLAM_BWD_R_EARLY == 1) {
+            const float* rp = add_gout ? grow : g_zero16;
+            const int rm = add_gout ? 1 : 0;
+#pragma unroll
+            for (int mb = 0; mb < OB; ++mb)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) rq[mb][tt] = *reinterpret_cast<const f32x4*>(rp + rm * (8 * (mb * 4 + tt) + 4 * hi));
+        }
         // ---- dh = W2^T dz2 ; dz1 = dh * silu'(z1) ----
         f32x16 dz1[HB];
 #pragma unroll
@@ -2143,6 +2238,11 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb) {
             f32x4 hh[LW ? 4 : 1];   // LW: silu(z1) of this block, the B operand of dW2
+            if constexpr (!LW && NLAM_BWD_Z_EARLY == 0) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) zq[hb][tt] = *reinterpret_cast<const f32x4*>(zrow + 8 * (hb * 4 + tt) + 4 * hi);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 f32x4 z;
@@ -2156,7 +2256,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
                         z[c] += wr[0] * xr[0] + wr[1] * xr[1] + wr[2] * xr[2] + wr[3] * xr[3];
                     }
                 } else {
-                    z = *reinterpret_cast<const f32x4*>(zrow + 8 * (hb * 4 + tt) + 4 * hi);
+                    z = zq[LW ? 0 : hb][tt];
                 }
                 f32x4 v;
 #pragma unroll
@@ -2294,8 +2394,11 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     f32x4 v = acc_chunk(dx[mb], tt);
-                    if (s == 0 && add_gout)   // out = msg + src0: d src0 += g_out (L2-resident re-read; keeping it live costs 32 VGPRs)
-                        v += *reinterpret_cast<const f32x4*>(grow + 8 * (mb * 4 + tt) + 4 * hi);
+                    if constexpr (NLAM_BWD_R_EARLY == 1) {
+                        if (s == 0 && mb < OB) v += rq[LW ? 0 : (mb < OB ? mb : 0)][tt];   // zeros unless out = msg + src0
+                    } else {
+                        if (s == 0 && add_gout) v += *reinterpret_cast<const f32x4*>(grow + 8 * (mb * 4 + tt) + 4 * hi);
+                    }
                     if (s == 1 && add_gmsg) {   // msg = mlp + src1: d src1 += dmsg (re-read: rare PropagationNet path)
                         f32x4 g = {0.f, 0.f, 0.f, 0.f};
                         const int c0 = 8 * (mb * 4 + tt) + 4 * hi;
@@ -2429,7 +2532,6 @@ constexpr int kWgradThreads = 256;
 constexpr int kWgradRows = 32;
 constexpr int kWgTile = kWgradRows * 64;  // floats in one [32 rows][64 cols] LDS tile
 
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 // Fast path: m <= 64, every source width <= 64, all multiples of 4.
 // LDS holds, per buffer, one [32][64] tile for A and one per source, filled by
