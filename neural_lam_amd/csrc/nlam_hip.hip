@@ -1879,19 +1879,23 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
     // live in LDS (8 per lane: db1, db2, dgamma, dbeta x 2 blocks) because the kernel sits at the 256-VGPR limit
     float* colacc = colacc_all + (size_t)wave * 8 * 64 + lane;
     enum { kDb1 = 0, kDb2 = 2, kDg = 4, kDbt = 6 };
+    // In registers (kColRegs) they cost far more than eight: <2,2,3> goes from 196 to 249 VGPRs (measured, round 3), and the
+    // register count of a chain kernel decides which side-stream workgroups can share its CU (NLAM_BWD_R_EARLY); the
+    // fused-weight-gradient variant (452 registers) spills 12 VGPRs with them.  They stay in LDS.
+    constexpr bool kColRegs = false;
+    if constexpr (!kColRegs) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) colacc[k * 64] = 0.f;
-    float creg[LW ? 8 : 1];   // LW (512 registers per lane): the same accumulators in registers
+        for (int k = 0; k < 8; ++k) colacc[k * 64] = 0.f;
+    }
+    float creg[kColRegs ? 8 : 1];
 #pragma unroll
-    for (int k = 0; k < (LW ? 8 : 1); ++k) creg[k] = 0.f;
-    constexpr bool kColRegs = false;   // LW with the accumulators in registers: 12 VGPRs spilled (the scratch traffic then shares the
-                                       // load counter with the prefetch) -- they stay in LDS
+    for (int k = 0; k < (kColRegs ? 8 : 1); ++k) creg[k] = 0.f;
     auto cadd = [&](int k, float v) {   // k is a compile-time constant at every (unrolled) call site
-        if constexpr (LW && kColRegs) creg[k] += v;
+        if constexpr (kColRegs) creg[k] += v;
         else colacc[k * 64] += v;
     };
     auto cget = [&](int k) -> float {
-        if constexpr (LW && kColRegs) return creg[k];
+        if constexpr (kColRegs) return creg[k];
         else return colacc[k * 64];
     };
     float* xs = xs_all + (size_t)wave * 32 * 4;
