@@ -63,10 +63,14 @@
 #define NLAM_BWD_Z_EARLY 1   // z1 rows requested ahead of the dz2 stores (1) or one block at a time where they are used (0)
 #endif
 #ifndef NLAM_BWD_R_EARLY
-#define NLAM_BWD_R_EARLY 0   // residual (d src0 += g_out) rows requested ahead of the dh GEMM (1) or chunk by chunk behind the dx GEMM (0).
+#define NLAM_BWD_R_EARLY 0   // residual (d src0 += g_out) rows requested ahead of the dh GEMM (1), right ahead of the dx GEMM of source 0 (2),
+                             // ahead of the dh GEMM as that GEMM's initial accumulators (3), or chunk by chunk behind the dx GEMM (0).
                              // A/B at cfg2, five builds inside one gpurun call: G_BATCH 0 / 1 / 2 and Z_EARLY 0 / 1 are within noise of each
                              // other and 2 % ahead of the branchy loads; R_EARLY = 1 makes the isolated kernel 10 % faster and the captured
-                             // step 6 % SLOWER (1.80 -> 1.91 ms): 32 more registers live across both GEMMs of every chain kernel
+                             // step 6 % SLOWER (1.80 -> 1.91 ms): 225 instead of 196 VGPRs.  A chain workgroup is 2 waves per SIMD; at
+                             // 196 (allocated 200) it leaves 112 registers per SIMD, enough for a wave of wgrad_dma<1> / <2> (56 / 93),
+                             // reduce_jobs (78) or segment_sum (54) of a side stream to share the CU; at 225 it leaves 48: nothing fits.
+                             // 2: 225 VGPRs as well; 3: 213 VGPRs, 1.742-1.747 against 1.726-1.740 ms for 0 on one box.
 #endif
 #define NLAM_IN_TU(k) (NLAM_TU == 0 || NLAM_TU == (k))
 
@@ -2182,7 +2186,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         // out = msg + src0 (edge update / node residual): d src0 += g_out.  NLAM_BWD_R_EARLY = 1 requests its rows again here, ahead
         // of the dz1 stores; the shipped 0 re-reads them chunk by chunk behind the dx GEMM of source 0 (see the macro)
         f32x4 rq[LW ? 1 : OB][4];
-        if constexpr (!LW && NLAM_BWD_R_EARLY == 1) {
+        if constexpr (!LW && (NLAM_BWD_R_EARLY == 1 || NLAM_BWD_R_EARLY == 3)) {
             const float* rp = add_gout ? grow : g_zero16;
             const int rm = add_gout ? 1 : 0;
 #pragma unroll
@@ -2362,6 +2366,27 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dx[mb][r] = 0.f;
+            if constexpr (NLAM_BWD_R_EARLY == 3) {   // the residual rows ARE the initial accumulators of source 0 (chunk layout = accumulator layout)
+                if (s == 0) {
+#pragma unroll
+                    for (int mb = 0; mb < OB; ++mb)
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) dx[mb][4 * tt + c] = rq[LW ? 0 : mb][tt][c];
+                }
+            }
+            if constexpr (NLAM_BWD_R_EARLY == 2) {   // residual rows of source 0: requested right ahead of its dx GEMM
+                if (s == 0) {
+                    const float* rp = add_gout ? grow : g_zero16;
+                    const int rm = add_gout ? 1 : 0;
+#pragma unroll
+                    for (int mb = 0; mb < OB; ++mb)
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) rq[mb][tt] = *reinterpret_cast<const f32x4*>(rp + rm * (8 * (mb * 4 + tt) + 4 * hi));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             if constexpr (NS > 0) {
                 const u32x4* A1 = reinterpret_cast<const u32x4*>(W1t + w1_off[s]);
                 if (MBs == 2) {
@@ -2398,9 +2423,9 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     f32x4 v = acc_chunk(dx[mb], tt);
-                    if constexpr (NLAM_BWD_R_EARLY == 1) {
+                    if constexpr (NLAM_BWD_R_EARLY == 1 || NLAM_BWD_R_EARLY == 2) {
                         if (s == 0 && mb < OB) v += rq[LW ? 0 : (mb < OB ? mb : 0)][tt];   // zeros unless out = msg + src0
-                    } else {
+                    } else if constexpr (NLAM_BWD_R_EARLY == 0) {
                         if (s == 0 && add_gout) v += *reinterpret_cast<const f32x4*>(grow + 8 * (mb * 4 + tt) + 4 * hi);
                     }
                     if (s == 1 && add_gmsg) {   // msg = mlp + src1: d src1 += dmsg (re-read: rare PropagationNet path)
