@@ -59,6 +59,11 @@
 #define NLAM_BWD_G_BATCH 2   // narrow backward, requests of the g_out / aggregated-gradient / xhat rows: 2 = the whole tile back to back,
                              // 1 = one 32-column block at a time, 0 = one 16-byte chunk at a time (unconditional either way)
 #endif
+#ifndef NLAM_LW_PREFETCH_X
+#define NLAM_LW_PREFETCH_X 1   // grouped embedder backward: the next tile's xhat rows requested a tile ahead (1) or this tile's at the tile
+                               // top (0: 438 instead of 461 registers -- a wgrad_dma<1> wave then fits next to it, reduce_jobs still
+                               // does not -- and one request batch exposed per tile; cfg2 1.767-1.784 against 1.777-1.783 ms: noise)
+#endif
 #ifndef NLAM_BWD_Z_EARLY
 #define NLAM_BWD_Z_EARLY 1   // z1 rows requested ahead of the dz2 stores (1) or one block at a time where they are used (0)
 #endif
@@ -1950,10 +1955,12 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
         const size_t srn = (size_t)bn * p.rows + rown;
         {   // without a LayerNorm the same requests read g_out again (values unused): unconditional, see above
             const float* xn = has_ln ? p.xhat + srn * p.dout : p.g_out + (long)bn * p.out_bstride + rown * p.dout;
+            if constexpr (NLAM_LW_PREFETCH_X == 1) {
 #pragma unroll
-            for (int o2 = 0; o2 < (LW ? OB : 1); ++o2)
+                for (int o2 = 0; o2 < (LW ? OB : 1); ++o2)
 #pragma unroll
-                for (int t2 = 0; t2 < 4; ++t2) xpre[o2][t2] = *reinterpret_cast<const f32x4*>(xn + 8 * (o2 * 4 + t2) + 4 * hi);
+                    for (int t2 = 0; t2 < 4; ++t2) xpre[o2][t2] = *reinterpret_cast<const f32x4*>(xn + 8 * (o2 * 4 + t2) + 4 * hi);
+            }
             rpre = *(has_ln ? p.rstd + srn : xn);
         }
         const int kw = p.src[0].width;
@@ -2011,7 +2018,12 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
 #pragma unroll
                 for (int t2 = 0; t2 < 4; ++t2) {
                     gcur[o2][t2] = gpre[o2][t2];
-                    xcur[o2][t2] = xpre[o2][t2];
+                    if constexpr (NLAM_LW_PREFETCH_X == 1) {
+                        xcur[o2][t2] = xpre[o2][t2];
+                    } else {   // requested first: the wait for it does not cover the next tile's requests below
+                        const float* xc = has_ln ? p.xhat + srow_c * p.dout : p.g_out;
+                        xcur[o2][t2] = *reinterpret_cast<const f32x4*>(xc + (has_ln ? 8 * (o2 * 4 + t2) + 4 * hi : 0));
+                    }
                 }
 #pragma unroll
             for (int k = 0; k < 4; ++k) xicur[k] = xipre[k];
