@@ -287,13 +287,14 @@ def test_plain_mlp_matches_oracle(dev, kin, hid, dout, ln, wide_family):
 
 
 @pytest.mark.parametrize("fused_wgrad", [True, False])
-@pytest.mark.parametrize("d,shapes", [
-    (64, [(40003, 3), (131075, 3), (6561, 2), (33, 3)]),   # > 1 016 waves x 32 rows: a wave walks several tiles (next-tile prefetch)
-    (64, [(1, 3), (31, 1), (64, 3)]),                      # fewer tiles than waves, a single row, a one-column member
-    (32, [(5000, 3), (70001, 2)]),
-    (64, [(3000, 3), (2000, 5)]),                          # a 5-column member: not a leaf-weight-gradient shape -> the plain grouped backward
+@pytest.mark.parametrize("d,shapes,ln", [
+    (64, [(40003, 3), (131075, 3), (6561, 2), (33, 3)], True),   # > 1 016 waves x 32 rows: a wave walks several tiles (next-tile prefetch)
+    (64, [(1, 3), (31, 1), (64, 3)], True),                      # fewer tiles than waves, a single row, a one-column member
+    (32, [(5000, 3), (70001, 2)], True),
+    (64, [(3000, 3), (2000, 5)], True),                          # a 5-column member: not a leaf-weight-gradient shape -> the plain grouped backward
+    (64, [(50001, 3), (40000, 2)], False),                       # no LayerNorm: the prefetch has no xhat / rstd rows to ask for
 ])
-def test_grouped_static_embedders_match_oracle(dev, monkeypatch, d, shapes, fused_wgrad):
+def test_grouped_static_embedders_match_oracle(dev, monkeypatch, d, shapes, ln, fused_wgrad):
     """gnn_layers.grouped_mlp_forward: the embedders of the static features (graph/base.py:286-295) as ONE launch each way.
     With <= 3 input columns the backward accumulates the weight gradients in the kernel (NLAM_F_LEAF_WGRAD: z1 recomputed
     from the input row, the next tile's g_out / xhat / rstd / input rows requested a tile ahead); outputs and every parameter
@@ -304,10 +305,10 @@ def test_grouped_static_embedders_match_oracle(dev, monkeypatch, d, shapes, fuse
     hl = _hl()
     monkeypatch.setattr(ops, "FUSED_LEAF_WGRAD", fused_wgrad)
     torch.manual_seed(d + len(shapes))
-    refs = [og.make_mlp([k, d, d]) for _, k in shapes]
+    refs = [og.make_mlp([k, d, d], layer_norm=ln) for _, k in shapes]
     nets = []
     for r, (_, k) in zip(refs, shapes):
-        n = hl.make_mlp([k, d, d])
+        n = hl.make_mlp([k, d, d], layer_norm=ln)
         n.load_state_dict(r.state_dict())
         nets.append(n.to(dev))
     xs = [torch.randn(rows, k) for rows, k in shapes]
