@@ -245,6 +245,10 @@ int32_t nlam_max_width(void);
 /*   NLAM_TUNE_WGRAD_BIG_MIN_ROWS: rows (x batch) from which a split-bf16 weight gradient with more than 128 output rows uses
  *   256 x 256 windows; below it 128 x 128 windows (same launch width, a quarter of the row slices and partial sums). */
 #define NLAM_TUNE_WGRAD_BIG_MIN_ROWS 5
+/*   NLAM_TUNE_WBF_HALF: split-bf16 wide kernels on 4-wave workgroups of half the rows, TWO co-resident per CU, so that one
+ *   workgroup's load / store phases overlap the other's matrix phases (bit 0: forward, bit 1: backward; shapes without a
+ *   half-size instantiation keep the 8-wave kernels). */
+#define NLAM_TUNE_WBF_HALF 6
 int32_t nlam_set_tuning(int32_t key, int32_t value);
 /* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this
  * call; 0 when the call runs on the narrow (weights-in-LDS) kernels. */

@@ -90,6 +90,7 @@ int32_t fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream);      // slice 4
 int32_t bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream);      // slice 4
 int32_t wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream);      // slice 4
 extern int wbf_min_supertiles;                                     // nlam_set_tuning (defined in slice 1)
+extern int wbf_half;                                               // nlam_set_tuning (defined in slice 1)
 extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
 extern int wgrad_min_parts;                                        // nlam_set_tuning (defined in slice 1)
 extern int wgrad_big_min_rows;                                     // nlam_set_tuning (defined in slice 1)
@@ -4121,6 +4122,7 @@ __global__ void pack_bf_table_kernel(const nlam_pack_rec_t* recs) {
 // ---------------------------------------------------------------------------
 #if NLAM_IN_TU(1)
 int nlam_detail::wbf_min_supertiles = 192;
+int nlam_detail::wbf_half = 1;              // bit 0: forward, bit 1: backward on 4-wave workgroups, two per CU (NLAM_TUNE_WBF_HALF)
 int nlam_detail::lin_resident_wgs = 256;    // NLAM_LIN_WGS (experiments): one per CU
 int nlam_detail::wgrad_big_min_rows = 0;    // rows from which a wide weight gradient uses 256 x 256 windows (0 = always, the round-2 behaviour)
 int nlam_detail::wgrad_min_parts = 128;     // row slices a weight gradient of more than that many 32-row chunks is cut into at least
@@ -4150,6 +4152,11 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_WBF_MIN_SUPERTILES) {
         if (value < 0) return NLAM_EINVAL;
         nlam_detail::wbf_min_supertiles = value;
+        return 0;
+    }
+    if (key == NLAM_TUNE_WBF_HALF) {
+        if (value < 0 || value > 3) return NLAM_EINVAL;
+        nlam_detail::wbf_half = value;
         return 0;
     }
     if (key == NLAM_TUNE_LIN_WGS) {
@@ -4295,9 +4302,10 @@ int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p) {
     const long total = (long)p->ntiles * p->batch;
     if (!bwd_is_wide(p)) return grid_blocks(total);
     if (bwd_wbf_ns(p) > 0) {   // partial-sum rows: one per (workgroup, row group)
-        const WbfBwdPlan pl = wbf_bwd_plan(bwd_wide_maxw(p));
+        const WbfBwdPlan pl = wbf_bwd_choose(bwd_wide_maxw(p));
         const long nsuper = (long)((p->ntiles + pl.nrt - 1) / pl.nrt) * p->batch;
-        return (int32_t)((nsuper < kNumCUs ? (nsuper < 1 ? 1 : nsuper) : kNumCUs) * pl.rg);
+        const long cap = pl.nw == 4 ? 2 * kNumCUs : kNumCUs;   // one 8-wave workgroup per CU, or two of 4 waves
+        return (int32_t)((nsuper < cap ? (nsuper < 1 ? 1 : nsuper) : cap) * pl.rg);
     }
     const WideCfg cfg = wide_cfg(bwd_wide_maxw(p));
     if (cfg.nwv == 0) return 0;
@@ -4420,7 +4428,7 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
             }
             const size_t lds = fwd_wbf_lds(p, wns, pl);
             const long nsuper = (long)((p->ntiles + pl.nrt - 1) / pl.nrt) * p->batch;
-            const long wcap = kNumCUs;   // one 8-wave workgroup per CU
+            const long wcap = pl.nw == 4 ? 2 * kNumCUs : kNumCUs;   // one 8-wave workgroup per CU, or two of 4 waves
             const int wblocks = (int)(nsuper < wcap ? (nsuper < 1 ? 1 : nsuper) : wcap);
 #define NLAM_LAUNCH_FWD_WBF(NS_, NW_, FG_, FB_, RT_, RTP_)                                                                    \
     do {                                                                                                                      \
@@ -4432,11 +4440,14 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
                 if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(1, 8, 4, 1, 4, 2);
                 else if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF(1, 8, 8, 1, 4, 2);
                 else if (pl.cfg == 4) NLAM_LAUNCH_FWD_WBF(1, 8, 8, 1, 2, 2);
+                else if (pl.cfg == 5) NLAM_LAUNCH_FWD_WBF(1, 4, 4, 2, 2, 1);
+                else if (pl.cfg == 6) NLAM_LAUNCH_FWD_WBF(1, 4, 4, 4, 1, 1);
                 else NLAM_LAUNCH_FWD_WBF(1, 8, 8, 2, 2, 1);
             } else {
                 if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(3, 8, 4, 1, 4, 2);
                 else if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF(3, 8, 8, 1, 4, 2);
                 else if (pl.cfg == 4) NLAM_LAUNCH_FWD_WBF(3, 8, 8, 1, 2, 2);
+                else if (pl.cfg == 5) NLAM_LAUNCH_FWD_WBF(3, 4, 4, 2, 2, 1);
                 else NLAM_LAUNCH_FWD_WBF(3, 8, 8, 2, 2, 1);
             }
             return (int32_t)hipGetLastError();
@@ -4586,7 +4597,7 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
 int32_t nlam_detail::bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream) {
     const int wns = bwd_wbf_ns(p);
     {
-            const WbfBwdPlan pl = wbf_bwd_plan(bwd_wide_maxw(p));
+            const WbfBwdPlan pl = wbf_bwd_choose(bwd_wide_maxw(p));
             if ((p->flags & NLAM_F_WPACK_READY) == 0) {
                 packbf_jobs_t jobs;
                 const long most = build_bwd_wbf_jobs(p, wns, jobs);
@@ -4597,20 +4608,22 @@ int32_t nlam_detail::bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream) {
             }
             const size_t lds = bwd_wbf_lds(p, wns, pl);
             const int wblocks = nlam_mlp_bwd_blocks(p) / pl.rg;
-#define NLAM_LAUNCH_BWD_WBF(NS_, FG_, FB_, RT_)                                                                   \
-    do {                                                                                                          \
-        int rc = set_lds(mlp_bwd_wbf_kernel<NS_, FG_, FB_, RT_>, lds);                                            \
-        if (rc != 0) return rc;                                                                                   \
-        hipLaunchKernelGGL((mlp_bwd_wbf_kernel<NS_, FG_, FB_, RT_>), dim3(wblocks), dim3(512), lds, stream, *p);  \
+#define NLAM_LAUNCH_BWD_WBF(NS_, NW_, FG_, FB_, RT_)                                                                          \
+    do {                                                                                                                      \
+        int rc = set_lds(mlp_bwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_>, lds);                                                   \
+        if (rc != 0) return rc;                                                                                               \
+        hipLaunchKernelGGL((mlp_bwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p);    \
     } while (0)
             if (wns == 1) {
-                if (pl.cfg == 1) NLAM_LAUNCH_BWD_WBF(1, 4, 1, 2);
-                else if (pl.cfg == 2) NLAM_LAUNCH_BWD_WBF(1, 8, 1, 2);
-                else NLAM_LAUNCH_BWD_WBF(1, 8, 2, 1);
+                if (pl.cfg == 1) NLAM_LAUNCH_BWD_WBF(1, 8, 4, 1, 2);
+                else if (pl.cfg == 2) NLAM_LAUNCH_BWD_WBF(1, 8, 8, 1, 2);
+                else if (pl.cfg == 5) NLAM_LAUNCH_BWD_WBF(1, 4, 4, 2, 1);
+                else NLAM_LAUNCH_BWD_WBF(1, 8, 8, 2, 1);
             } else {
-                if (pl.cfg == 1) NLAM_LAUNCH_BWD_WBF(3, 4, 1, 2);
-                else if (pl.cfg == 2) NLAM_LAUNCH_BWD_WBF(3, 8, 1, 2);
-                else NLAM_LAUNCH_BWD_WBF(3, 8, 2, 1);
+                if (pl.cfg == 1) NLAM_LAUNCH_BWD_WBF(3, 8, 4, 1, 2);
+                else if (pl.cfg == 2) NLAM_LAUNCH_BWD_WBF(3, 8, 8, 1, 2);
+                else if (pl.cfg == 5) NLAM_LAUNCH_BWD_WBF(3, 4, 4, 2, 1);
+                else NLAM_LAUNCH_BWD_WBF(3, 8, 8, 2, 1);
             }
             return (int32_t)hipGetLastError();
     }

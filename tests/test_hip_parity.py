@@ -33,17 +33,21 @@ def _hl():
     return gnn_layers
 
 
-@pytest.fixture(params=["auto", "wbf"])
+@pytest.fixture(params=["auto", "wbf", "wbf4"])
 def wide_family(request):
     """Widths above 64 have two kernel families: the fp32 MFMA one (one 32-row tile per workgroup) and the
-    split-bf16 one (128-row super tiles), chosen by launch size.  "wbf" forces the second at test sizes."""
+    split-bf16 one (super tiles of 64-256 rows), chosen by launch size.  "wbf" forces the second at test sizes on its 8-wave
+    workgroups (one per CU), "wbf4" on the 4-wave instantiations, forward and backward (two workgroups per CU,
+    NLAM_TUNE_WBF_HALF; widths without one keep the 8-wave kernel).  The fixture value is "wbf" for both."""
     from neural_lam_amd import _lib as L
 
     lib = L.load()
-    if request.param == "wbf":
+    if request.param != "auto":
         assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 0) == 0
-    yield request.param
+        assert lib.nlam_set_tuning(L.TUNE_WBF_HALF, 3 if request.param == "wbf4" else 0) == 0
+    yield "auto" if request.param == "auto" else "wbf"
     assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
+    assert lib.nlam_set_tuning(L.TUNE_WBF_HALF, 1) == 0
 
 
 @pytest.fixture(params=["auto", "factorised"])
