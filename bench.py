@@ -104,10 +104,53 @@ def build(cfg, device, seed_offset=0, oracle=False):
     return ds, graph, raw, forecaster, step, batch
 
 
+def cpu_baseline_sample(cfg, threads=32):
+    """The wide configurations (cfg3 / cfg4 / cfg5: 10-200 s per oracle step on the host) on a BOUNDED sample: one training
+    step of the same model with ONE autoregressive step of the rollout (same graph, weights, widths; ar_steps 1 of the
+    T), one warm-up + one timed step, fixed thread count.  The metric counts B x T sample-steps per training step, so the
+    per-sample-step rate of the sample is directly comparable with `value`."""
+    from oracle import models as om
+
+    ncpu = os.cpu_count() or 1
+    threads = max(1, min(threads, ncpu))
+    ds, _, _, forecaster, _, batch = build(cfg, torch.device("cpu"), oracle=True)
+    batch = (batch[0], batch[1][:, :1].contiguous(), batch[2][:, :1].contiguous())
+    pvs, mask = om.per_var_std_uniform(ds), om.interior_mask_bool(ds)
+    opt = torch.optim.AdamW(forecaster.parameters(), lr=1e-3, betas=(0.9, 0.95))
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    times = []
+    try:
+        for it in range(2):
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            _, loss = om.training_loss(forecaster, om.standardize_batch(ds, *batch), pvs, mask)
+            loss.backward()
+            opt.step()
+            times.append(time.perf_counter() - t0)
+            if times[-1] > 45.0:   # the warm-up alone used the budget: it is the sample
+                break
+    finally:
+        torch.set_num_threads(old)
+    t = times[-1]
+    return {
+        "value": cfg["B"] * 1 / t,
+        "unit": "sample-steps/s",
+        "ms_per_step": t * 1e3,
+        "cores": threads,
+        "kind": "port",
+        "sample": f"ONE training step with ar_steps 1 of the {cfg['T']} (same model, graph, weights; B x 1 sample-steps), "
+                  f"{'second of two steps' if len(times) > 1 else 'single step (no warm-up: it alone took > 45 s)'}, oracle = PyG-free torch "
+                  f"fp32 restatement of the reference, torch.set_num_threads({threads}) on a {ncpu}-core host",
+    }
+
+
 def cpu_baseline(cfg, budget_s=30.0):
     """Oracle training step (fwd + wmse + bwd + AdamW) on the host cores: median of >= 10 steps."""
     from oracle import models as om
 
+    if cfg["d"] > 64:
+        return cpu_baseline_sample(cfg)
     ncpu = os.cpu_count() or 1
     ds, _, _, forecaster, _, batch = build(cfg, torch.device("cpu"), oracle=True)
     pvs, mask = om.per_var_std_uniform(ds), om.interior_mask_bool(ds)
@@ -153,7 +196,7 @@ def cpu_baseline(cfg, budget_s=30.0):
     }
 
 
-def gpu_reference_equivalent(cfg, device, steps=20):
+def gpu_reference_equivalent(cfg, device, steps=20, autocast=False):
     """BASELINE.md section 4 / north_star ">= 5x the reference PyG-CUDA-equivalent step time": the reference's
     formulation -- gather (index_select) -> cat -> Linear -> SiLU -> Linear -> LayerNorm -> index_add_, un-fused,
     autograd, torch.optim.AdamW -- through stock PyTorch-ROCm ops on THIS GPU, same weights and batch, eager (the
@@ -164,7 +207,8 @@ def gpu_reference_equivalent(cfg, device, steps=20):
     from oracle import models as om
 
     out = {"what": "oracle restatement of the reference on cuda:0 through stock PyTorch-ROCm ops (eager, autograd, "
-                   "torch.optim.AdamW), same weights / batch as the timed workload; loss_first_step = its loss on the initial weights",
+                   "torch.optim.AdamW), same weights / batch as the timed workload; loss_first_step = its loss on the initial weights"
+                   + ("; inside torch.autocast(bfloat16), as Lightning --precision bf16-mixed runs the reference" if autocast else ""),
            "steps": steps}
     for name, det in (("nondeterministic", False), ("deterministic", True)):
         ds, _, _, forecaster, _, batch = build(cfg, torch.device("cpu"), oracle=True)   # fresh seed-42 weights per mode
@@ -184,7 +228,8 @@ def gpu_reference_equivalent(cfg, device, steps=20):
         def one():
             opt.zero_grad(set_to_none=True)
             b = ((batch[0] - s_mean) / s_std, (batch[1] - s_mean) / s_std, (batch[2] - f_mean) / f_std)   # on_after_batch_transfer
-            _, loss = om.training_loss(forecaster, b, pvs, mask)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                _, loss = om.training_loss(forecaster, b, pvs, mask)
             loss.backward()
             opt.step()
             return loss.detach()
@@ -192,14 +237,19 @@ def gpu_reference_equivalent(cfg, device, steps=20):
         try:
             torch.use_deterministic_algorithms(det)
             first = float(one())
-            for _ in range(2):
-                one()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(steps):
+            one()
+            torch.cuda.synchronize()
+            nsteps = max(2, min(steps, int(4.0 / max(time.perf_counter() - t0, 1e-4))))   # ~4 s of timed steps per mode
+            one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
                 one()
             torch.cuda.synchronize()
-            out[f"ms_per_step_{name}"] = (time.perf_counter() - t0) / steps * 1e3
+            out[f"ms_per_step_{name}"] = (time.perf_counter() - t0) / nsteps * 1e3
+            out[f"steps_{name}"] = nsteps
             out[f"loss_first_step_{name}"] = first
         except Exception as exc:   # an op without a deterministic implementation on this build
             out[f"ms_per_step_{name}"] = None
@@ -210,13 +260,18 @@ def gpu_reference_equivalent(cfg, device, steps=20):
     return out
 
 
-def oracle_loss_step0(cfg):
-    """Loss of the CPU oracle on the benchmark's own weights and batch (forward only): printed beside the HIP loss."""
+def oracle_loss_step0(cfg, device=None):
+    """Loss of the oracle on the benchmark's own weights and batch (forward only, fp32): printed beside the HIP loss.  On the
+    host for cfg1 / cfg2; the wide configurations (minutes and tens of GB on the host) run the same restatement on ``device``."""
     from oracle import models as om
 
     ds, _, _, forecaster, _, batch = build(cfg, torch.device("cpu"), oracle=True)
+    pvs, mask = om.per_var_std_uniform(ds), om.interior_mask_bool(ds)
+    batch = om.standardize_batch(ds, *batch)
+    if device is not None and cfg["d"] > 64:
+        forecaster, batch, pvs, mask = forecaster.to(device), tuple(b.to(device) for b in batch), pvs.to(device), mask.to(device)
     with torch.no_grad():
-        _, loss = om.training_loss(forecaster, om.standardize_batch(ds, *batch), om.per_var_std_uniform(ds), om.interior_mask_bool(ds))
+        _, loss = om.training_loss(forecaster, batch, pvs, mask)
     return float(loss)
 
 
@@ -330,20 +385,53 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_regions(tr, b, steps):
+        """Regions of EXACTLY `steps` training steps, each bracketed by barrier + synchronize, a region's time = the max over
+        ranks.  One region is the contract; when it lasts under 0.5 s (20 steps of cfg2 are 35 ms: one scheduling hiccup is
+        3 %) four more follow and the MEDIAN region is reported, all of them listed.  Every rank takes the same decision:
+        it is made on the all-reduced time."""
+        regions, last = [], None
+        while True:
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                last = tr.step(*b)
+            sync()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t)
+            regions.append(el)
+            if (len(regions) == 1 and el >= 0.5) or len(regions) >= 5:
+                return regions, last
+
     for _ in range(args.warmup):
         trainer.step(*batch)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.step(*batch)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    regions, loss = timed_regions(trainer, batch, args.steps)
+    elapsed = sorted(regions)[len(regions) // 2]
     ms_per_step = elapsed / args.steps * 1e3
     value = world * cfg["B"] * cfg["T"] * args.steps / elapsed
+
+    # N > 1: BASELINE configs[2] (GraphLAM d = 256, 8 layers, ar_steps 4, one sample per GPU) is the configuration the
+    # 0.9-efficiency target is written for; it is timed as well (same contract, fewer steps) and reported under "also"
+    also = None
+    if world > 1 and args.config == "cfg2" and os.environ.get("NLAM_BENCH_ALSO", "1") == "1":
+        cfg3 = CONFIGS["cfg3"]
+        _, _, raw3, _, step3, batch3 = build(cfg3, device, seed_offset=rank)
+        tr3 = Trainer(step3, lr=1e-3, use_graph=not args.eager)
+        k3 = max(2, min(args.steps, 10))
+        for _ in range(2):
+            tr3.step(*batch3)
+        r3, loss3 = timed_regions(tr3, batch3, k3)
+        e3 = sorted(r3)[len(r3) // 2]
+        also = {"cfg3": {"value": world * cfg3["B"] * cfg3["T"] * k3 / e3, "unit": "sample-steps/s", "ms_per_step": e3 / k3 * 1e3,
+                         "steps": k3, "warmup": 2, "n_gpus": world, "scaling": "weak", "dtype": "f32", "regions_ms": [x * 1e3 for x in r3],
+                         "final_loss": float(loss3),
+                         "config": {"workload": f"cfg3: graph_lam, grid {cfg3['nx']}x{cfg3['ny']}, hidden_dim {cfg3['d']}, {cfg3['L']} processor layers, "
+                                                f"ar_steps {cfg3['T']}, batch {cfg3['B']}/GPU", "global_batch": world * cfg3["B"], "parallelism": f"dp{world}"}}}
+        del tr3, step3, batch3
+        torch.cuda.empty_cache()
 
     # forecast throughput (inference rollout, no grad), reported alongside; same launch mode as training
     fsteps = min(args.steps, 200)
@@ -433,13 +521,23 @@ def main():
         ops.PROFILE.reset(enabled=False)
         trainer.use_graph = not args.eager
         trainer.overlap_wgrad = overlap_was
-        traffic = None
-        for tfile in (ROOT / "profiles" / "round3" / "pmc_traffic.json", ROOT / "profiles" / "round2" / "pmc_traffic.json"):
-            if traffic is None and tfile.exists() and args.config == "cfg2" and args.precision == "fp32":
+        # PMC-measured HBM bytes per launch: rocprofv3 --pmc passes (tools/pmc_collect.py -> tools/make_pmc_traffic.py) cannot run
+        # inside this process, so they come from the newest profiles/roundN/pmc_traffic.json -- accepted only when it was
+        # collected on THIS build of the kernels (its library_stamp equals the hash of the sources): a stale file is refused
+        from neural_lam_amd import _lib as _L
+
+        traffic, traffic_src = None, "no profiles/round*/pmc_traffic.json"
+        if args.config == "cfg2" and args.precision == "fp32":
+            for tfile in sorted((ROOT / "profiles").glob("round*/pmc_traffic.json"), reverse=True):
                 try:
-                    traffic = json.loads(tfile.read_text()).get("bytes_per_launch")
+                    js = json.loads(tfile.read_text())
                 except Exception:
-                    traffic = None
+                    continue
+                if js.get("library_stamp") == _L.source_stamp():
+                    traffic, traffic_src = js.get("bytes_per_launch"), str(tfile.relative_to(ROOT))
+                    break
+                traffic_src = f"{tfile.relative_to(ROOT)} refused: collected on another build of the kernels (stamp {js.get('library_stamp')})"
+                break
         rows = kernel_rooflines(recs, meta, ms_per_step, traffic)
         for r in rows:
             r["launches"] = r["launches"] / psteps
@@ -459,6 +557,7 @@ def main():
                 "unit": "TFLOP/s" if top["bound"] == "mfma" else "GB/s",
                 "frac": top["frac"],
                 "traffic": top["traffic"],
+                "traffic_source": traffic_src,
                 "kernel": top["launch"] + ": " + top["what"],
                 "note": "frac = max(executed MFMA FLOPs / dense peak of the instruction issued, algorithmic HBM bytes / 8 TB/s); "
                         "times = HIP events on the launch stream, eager instrumented pass of %d steps with every launch on one stream (uncontended kernel durations)" % psteps,
@@ -482,6 +581,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "timed_regions_ms": [x * 1e3 for x in regions],   # each = exactly `steps` steps; value / ms_per_step = the median region
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -505,13 +605,17 @@ def main():
         }
         if data_path is not None:
             out["from_device_dataset"] = data_path
+        if also is not None:
+            out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
-            o0 = oracle_loss_step0(cfg)
+            o0 = oracle_loss_step0(cfg, device)
             out["oracle_loss_step0"] = o0
             out["loss_step0_rel_diff_vs_oracle"] = abs(loss_step0 - o0) / abs(o0)
             out["cpu_baseline"] = cpu_baseline(cfg)
         if world == 1 and not args.no_gpu_baseline:
-            g = gpu_reference_equivalent(cfg, device)
+            del trainer, step, forecaster
+            torch.cuda.empty_cache()
+            g = gpu_reference_equivalent(cfg, device, autocast=args.precision == "bf16")
             for k in ("nondeterministic", "deterministic"):
                 v = g.get(f"ms_per_step_{k}")
                 g[f"speedup_vs_{k}"] = (v / ms_per_step) if v else None

@@ -412,6 +412,18 @@ def check(rc: int, what: str):
 SLICES = (1, 2, 3, 4, 5)   # -DNLAM_TU=k translation-unit slices of csrc/nlam_hip.hip (see the comment at its top)
 
 
+def source_stamp() -> str:
+    """Hash of the library's sources (csrc/*.hip, csrc/*.inc, include/nlam_hip.h): measurements that belong to one build
+    of the kernels (profiles/roundN/pmc_traffic.json) carry it, and bench.py refuses them when it no longer matches."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = HERE / "csrc"
+    for f in sorted([*csrc.glob("*.hip"), *csrc.glob("*.inc"), HERE.parent / "include" / "nlam_hip.h"]):
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def build(verbose: bool = False, out: Path | None = None, defines=(), single_tu: bool | None = None) -> Path:
     """Compile csrc/nlam_hip.hip for gfx950 into the in-tree shared library.
 

@@ -52,6 +52,16 @@ FACTORISE_MIN_WIDTH_WIDE = int(os.environ.get("NLAM_FACTORISE_MIN_WIDTH_WIDE", "
 _DEVICE_LAYOUTS: dict = {}   # (id of the host EdgeCSR, device) -> device EdgeCSR (+ tiles): shared by every layer built on that edge set
 
 
+def clear_layout_caches():
+    """Drop the module-level edge-layout caches (host layouts by content hash in ``graph``, their device copies here).  Layers
+    that exist keep their own references; a process that builds many distinct graphs (sweeps, test suites) calls this between
+    them so that index tensors of graphs no layer uses any more are released."""
+    from . import graph as _graph
+
+    _DEVICE_LAYOUTS.clear()
+    getattr(_graph, "_LAYOUT_CACHE", {}).clear()
+
+
 class FusedMLP(nn.Sequential):
     """``[Linear -> SiLU] * hidden_layers -> Linear [-> LayerNorm]`` with the reference's child names
     (``0``, ``2``, ..: Linear; last: LayerNorm; utils/networks.py:8-40).

@@ -186,6 +186,11 @@ class WeightPacker:
         self.wide = {}
         self.wide_tables = {}      # kind -> (device table, [entries])
         self.wide_dirty = False
+        # Tables a captured HIP graph may have baked into its nlam_mlp_pack / nlam_pack_records launches stay alive for the
+        # packer's lifetime: entries registered AFTER a capture (a partial last batch taking the eager step registers wide
+        # entries of another row count) rebuild the tables, and a replay of the older graph still reads the older ones --
+        # freed, they would be read from recycled memory (raw source / destination pointers).  A table is <= a few KB.
+        self._retired = []
 
     class Entry:
         __slots__ = ("job", "fwd", "bwd", "packed_step")
@@ -253,6 +258,8 @@ class WeightPacker:
             live = [e for e in self.entries.values() if e.fwd is not None]
             arr = (L.PackJob * len(live))(*[e.job for e in live])
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            if self.table is not None:
+                self._retired.append(self.table)
             self.table = host.to(live[0].fwd.device)
             self.table_entries = live
             self.dirty = False
@@ -265,6 +272,7 @@ class WeightPacker:
             for e in self.wide.values():
                 if e.buf is not None:
                     by_kind.setdefault(e.kind, []).append(e)
+            self._retired.extend(t for t, _ in self.wide_tables.values())
             self.wide_tables = {}
             for kind, ents in by_kind.items():
                 host = torch.frombuffer(bytearray(b"".join(e.recs for e in ents)), dtype=torch.uint8)

@@ -90,6 +90,7 @@ class GradBuckets:
         self.index_of = {id(p): i for i, p in enumerate(fp.params)}
         self.pending = [0] * len(self.bounds)
         self.uses = {}        # parameter index -> fused-MLP forwards that used it and have not yet back-propagated
+        self.fired = set()    # parameters whose post-accumulate hook has fired while fused-MLP uses were still outstanding
         self.done = set()
         self.handles = []
         self.launched = []    # bucket indices in launch order (tests read it)
@@ -101,6 +102,10 @@ class GradBuckets:
         # (the hook fires for an undefined gradient too) and including any plain torch op sharing the parameter.  The
         # fused ops' own note_done reports are then ignored: a parameter fed by both mechanisms would otherwise be marked
         # complete by whichever finishes first, and the late contribution would land after the bucket's collective started.
+        # One case needs BOTH signals: a parameter back-propagated in the main graph and again in a nested backward
+        # (ops.early_backward_leaf) gets an AccumulateGrad firing per backward call, and the first one may precede the nested
+        # contribution -- so a hook that fires while fused-MLP forwards of the parameter are still un-back-propagated
+        # (``uses`` > 0) only marks it, and the last note_done completes it.
         self.hooks_armed = False
         if self.world > 1:
             for i, p in enumerate(fp.params):
@@ -149,9 +154,12 @@ class GradBuckets:
             self._reduce_slice(s, e)
 
     def _make_hook(self, i):
-        def hook(_param):   # autograd accumulated this parameter's (complete) gradient
+        def hook(_param):   # autograd accumulated this parameter's gradient (complete unless fused uses are outstanding)
             if self.enabled:
-                self._param_done(i)
+                if self.uses.get(i, 0) > 0:
+                    self.fired.add(i)
+                else:
+                    self._param_done(i)
 
         return hook
 
@@ -173,12 +181,12 @@ class GradBuckets:
                 continue
             left = self.uses.get(i, 1) - 1
             self.uses[i] = left
-            if left <= 0 and not self.hooks_armed:   # the last AR step's contribution is in: the gradient is complete
+            if left <= 0 and (not self.hooks_armed or i in self.fired):   # the last contribution is in: the gradient is complete
                 self._param_done(i)
 
     def begin_step(self):
         self.pending = [len(mem) for (_, _, mem) in self.bounds]
-        self.uses, self.done = {}, set()
+        self.uses, self.done, self.fired = {}, set(), set()
         self.handles, self.launched = [], []
 
     def finish_step(self):
@@ -337,15 +345,29 @@ class Trainer:
         # too -- one launch latency less per step than enqueueing it behind the replay.  With data parallelism the gradient
         # all-reduce separates the two and stays outside the capture.
         self._opt_in_graph = self.world == 1 and bool(getattr(self.opt, "capturable", False))
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-            self.fp.grad.zero_()
-            self._static_loss = self._fwd_bwd()
-            if self._opt_in_graph:
-                self.opt.step(1.0)
-        if self._opt_in_graph:
-            self.opt.t -= 1   # the capture recorded the launches without running them
+        t_before = getattr(self.opt, "t", None)
+        try:
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+                self.fp.grad.zero_()
+                self._static_loss = self._fwd_bwd()
+                if self._opt_in_graph:
+                    self.opt.step(1.0)
+        finally:
+            if t_before is not None:
+                self.opt.t = t_before   # the capture recorded the launches without running them (also when it failed half way)
+        self._opt_sig = self._opt_signature()
+
+    def _opt_signature(self):
+        """The optimizer's hyper-parameters are launch arguments of the captured AdamW kernel: a change (a learning-rate
+        schedule) must re-capture, or the replays would keep applying the old values."""
+        o = self.opt
+        return tuple(getattr(o, k, None) for k in ("lr", "betas", "eps", "wd")) if self._opt_in_graph else None
+
+    _opt_sig = None
 
     def _graph_step(self, *batch):
+        if self._graph is not None and self._opt_in_graph and self._opt_signature() != self._opt_sig:
+            self._graph = None   # lr / betas / weight decay changed since the capture: record the step again
         if self._graph is None:
             try:
                 self._capture(*batch)

@@ -9,6 +9,10 @@ at 64 bytes (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is taken as reported 
 of bench.py's roofline rows (kind:rows:k:n)."""
 import json
 import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from neural_lam_amd._lib import source_stamp  # noqa: E402
 
 d = 64
 NAMES = {   # kernel name prefix -> (kind, k, n) of the launch key at hidden_dim 64
@@ -20,6 +24,7 @@ NAMES = {   # kernel name prefix -> (kind, k, n) of the launch key at hidden_dim
 }
 out = {"note": "HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE KiB (gfx950 FETCH_SIZE correction); separate --pmc passes, "
                "kernel trace only; one InteractionNet edge stage (forward in training mode, backward, both weight gradients)",
+       "library_stamp": source_stamp(),   # bench.py refuses this file once the kernels' sources change
        "bytes_per_launch": {}, "counters": {}, "commands": []}
 for arg in sys.argv[1:]:
     path, rows = arg.split(":")
