@@ -30,6 +30,9 @@
  *   nlam_segment_sum, nlam_segment_sum_acc
  *       autograd of index_select (= index_add by sender), as a CSC segment sum; _acc adds onto
  *       an existing gradient buffer (what autograd's accumulation would do with one more launch).
+ *   nlam_split_combine
+ *       the deterministic form of PyG's scatter for receivers that exceed one tile
+ *       (gnn_layers.py:175-189 under Trainer(deterministic=True), train_model.py:566).
  *   nlam_affine_mix
  *       the elementwise tail of an AR step: prev_state + delta * diff_std + diff_mean
  *       (step_predictors/graph/base.py:331-343) and the boundary overwrite
@@ -83,6 +86,11 @@ extern "C" {
  * launch -- written by nlam_pack_records from the records nlam_mlp_*_pack_records gave for it, since the weights last
  * changed -- so the pack launch in front of the kernel is skipped. */
 #define NLAM_F_WPACK_READY 64u
+/* NLAM_F_NO_ACT: no activation between the two Linears (z1 goes into the second GEMM as it is, silu' = 1 in backward).  With
+ * W2 = identity, b2 = 0 the launch is `Linear [-> LayerNorm]` with the full gather / concat / residual / aggregation geometry:
+ * how utils.make_mlp's hidden_layers = 0 case (utils/networks.py:8-40: blueprint [in, out]) runs on the fused kernels.  fp32
+ * matrix path only (NLAM_F_MM_* bits must be 0: NLAM_EUNSUP otherwise); not for grouped / factorised / concatenated launches. */
+#define NLAM_F_NO_ACT 128u
 /* matrix path of the GEMMs (bits 8-9): 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains);
  * n = 1..3: operands split into n bf16 terms on the bf16 matrix cores, fp32 accumulate
  * (1 = plain bf16 operands, 2 = ~2^-16 product error, 3 = fp32-class ~2^-24).  Shapes the
@@ -323,6 +331,15 @@ int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr
 int32_t nlam_segment_sum_acc(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order,
                          const float* scale, float* out, int32_t nseg, int32_t width, int32_t batch,
                          void* hip_stream);
+
+/* buf[b, dst[s], :] = sum_{q in [ptr[s], ptr[s+1])} buf[b, src[q], :], q ascending, for s < n; rows of `width` floats, batch
+ * stride `bstride` floats.  Second pass of the DETERMINISTIC reduction of receivers with more in-edges than a 32-row tile
+ * (reference: PyG's scatter under Trainer(deterministic=True), gnn_layers.py:175-189, train_model.py:566): the tile schedule
+ * gives every piece of such a receiver a virtual segment behind the real ones (rowptr / inv_deg are extended accordingly, the
+ * kernels see ordinary one-receiver tiles and use plain stores), and this sums the pieces into the receiver's row.  The
+ * one-pass alternative -- NLAM_TILE_SPLIT tiles, atomic adds into a zeroed buffer -- stays available to ABI users. */
+int32_t nlam_split_combine(float* buf, int64_t bstride, const int32_t* ptr, const int32_t* src, const int32_t* dst, int32_t n,
+                           int32_t width, int32_t batch, void* hip_stream);
 
 /* out[i] (+)= sum_p partials[p * stride + i], i < n ; accumulate != 0 adds into out */
 int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stride, int32_t n, float* out,

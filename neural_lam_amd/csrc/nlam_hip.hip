@@ -804,7 +804,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_kernel(const nlam_mlp_fwd
                             store_chunk(z1row, p.hid, t, hi, valid, z);
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc1[hb][4 * tt + c] = silu_f(z[c]);
+                    for (int c = 0; c < 4; ++c) acc1[hb][4 * tt + c] = (p.flags & NLAM_F_NO_ACT) ? z[c] : silu_f(z[c]);
                 }
                 const int wb = FAST ? 32 : min(32, p.hid - 32 * hb);
                 if (p.z1 != nullptr && hid_vec && wb > 0) {
@@ -1667,7 +1667,7 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_kernel(const nlam_mlp_b
                     f32x4 v;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        v[c] = valid ? dz1[hb][4 * tt + c] * silu_grad_f(z[c]) : 0.f;
+                        v[c] = valid ? dz1[hb][4 * tt + c] * ((p.flags & NLAM_F_NO_ACT) ? 1.f : silu_grad_f(z[c])) : 0.f;
                         dz1[hb][4 * tt + c] = v[c];
                     }
                     if (drow != nullptr) store_chunk(drow, p.hid, t, hi, valid, v);
@@ -2891,6 +2891,20 @@ __global__ __launch_bounds__(256) void wgrad_smalln_kernel(const nlam_wgrad_t p)
 // ---------------------------------------------------------------------------
 // small HBM-bound kernels
 // ---------------------------------------------------------------------------
+// buf[b, dst[s], :] = sum over the pieces src[ptr[s] .. ptr[s+1]) of buf[b, piece, :], pieces in list order.  The second pass of
+// the deterministic reduction of receivers that are cut over several tiles (graph.build_tile_schedule, "virtual" split): their
+// pieces reduce into virtual rows behind the real ones with plain stores, this sums them up -- a handful of rows per layer.
+__global__ void split_combine_kernel(float* buf, long bstride, const int32_t* ptr, const int32_t* src, const int32_t* dst, int width) {
+    const int s = blockIdx.x;
+    float* base = buf + (long)blockIdx.y * bstride;
+    const int q0 = ptr[s], q1 = ptr[s + 1];
+    for (int c = threadIdx.x; c < width; c += blockDim.x) {
+        float acc = 0.f;
+        for (int q = q0; q < q1; ++q) acc += base[(long)src[q] * width + c];
+        base[(long)dst[s] * width + c] = acc;
+    }
+}
+
 __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32_t* ptr, const int32_t* order,
                                    const float* scale, float* out, int nseg, int width, int batch, int accumulate) {
     const int w4 = (width + 3) >> 2;
@@ -4383,6 +4397,7 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
     if ((p->flags & NLAM_F_MEAN) && p->inv_deg == nullptr) return NLAM_EINVAL;
     if ((p->flags & NLAM_F_ADD_SRC0) && p->src[0].width != p->dout) return NLAM_EINVAL;
     if ((p->flags & NLAM_F_ADD_SRC1) && (p->nsrc < 2 || p->src[1].width != p->dout)) return NLAM_EINVAL;
+    if ((p->flags & NLAM_F_NO_ACT) && ((p->flags & (NLAM_F_MM_MASK | NLAM_F_PRE_ADD)) != 0 || p->ncat != 0)) return NLAM_EUNSUP;
     if (p->ncat != 0) {   // src[0] = concatenation of pieces: one un-gathered source of <= 64 columns, whole float4s per row
         if (p->ncat < 0 || p->ncat > NLAM_MAX_CAT || p->nsrc != 1 || p->src[0].idx != nullptr) return NLAM_EINVAL;
         int wsum = 0;
@@ -4575,6 +4590,7 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
         if (p->vec_partials_rows < nlam_mlp_bwd_blocks(p) || p->vec_stride < wmax || p->vec_stride < 64 || p->vec_stride % 64 != 0)
             return NLAM_EINVAL;
     }
+    if ((p->flags & NLAM_F_NO_ACT) && (p->flags & (NLAM_F_MM_MASK | NLAM_F_PRE_ADD | NLAM_F_LEAF_WGRAD)) != 0) return NLAM_EUNSUP;
     if (p->rows == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
     if (bwd_is_wide(p) && (p->flags & NLAM_F_PRE_ADD) && bwd_wbf_ns(p) == 0) return NLAM_EUNSUP;
@@ -4794,6 +4810,7 @@ int32_t nlam_detail::bwd_narrow(const nlam_mlp_bwd_t* p, hipStream_t stream) {
     for (int s = 0; s < p->nsrc; ++s)
         if (p->dmode[s] != 0) fast = fast && (p->src[s].width == 32 || p->src[s].width == 64);
     if ((p->flags & NLAM_F_ADD_SRC0) && p->dmode[0] != 0 && p->src[0].width != p->dout) fast = false;
+    if (p->flags & NLAM_F_NO_ACT) fast = false;   // the generic kernel carries the activation switch
     if (p->flags & NLAM_F_PRE_ADD) {   // factorised edge MLP: FAST shapes and split-bf16 modes only
         bool ok = fast && ((p->flags & NLAM_F_MM_MASK) != 0) && (p->flags & NLAM_F_ADD_SRC1) == 0 && p->nsrc >= 2;
         ok = ok && (p->src[0].width == 32 || p->src[0].width == 64);
@@ -5119,6 +5136,18 @@ int32_t nlam_segment_sum_acc(const float* in, int64_t in_bstride, const int32_t*
                              float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream) {
     NLAM_RANGE("nlam_segment_sum_acc");
     return segment_sum_launch(in, in_bstride, ptr, order, scale, out, nseg, width, batch, 1, hip_stream);
+}
+
+int32_t nlam_split_combine(float* buf, int64_t bstride, const int32_t* ptr, const int32_t* src, const int32_t* dst, int32_t n,
+                           int32_t width, int32_t batch, void* hip_stream) {
+    NLAM_RANGE("nlam_split_combine");
+    if (buf == nullptr || ptr == nullptr || src == nullptr || dst == nullptr || n < 0 || width < 1 || batch < 1) return NLAM_EINVAL;
+    if (n == 0) return 0;
+    if (batch > 65535) return NLAM_EUNSUP;
+    const int threads = width >= 256 ? 256 : (width >= 128 ? 128 : 64);
+    hipLaunchKernelGGL(split_combine_kernel, dim3(n, batch), dim3(threads), 0, (hipStream_t)hip_stream, buf, (long)bstride, ptr, src,
+                       dst, width);
+    return (int32_t)hipGetLastError();
 }
 
 int32_t nlam_reduce_partials(const float* partials, int32_t nparts, int64_t stride, int32_t n, float* out,

@@ -62,15 +62,32 @@ def clear_layout_caches():
     getattr(_graph, "_LAYOUT_CACHE", {}).clear()
 
 
+_CONSTS: dict = {}   # (kind, n, device) -> identity matrix / zero vector shared by every MLP that needs one (never trained)
+
+
+def _const(kind: str, n: int, device):
+    key = (kind, n, str(device))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.eye(n, device=device) if kind == "eye" else torch.zeros(n, device=device)
+    return t
+
+
 class FusedMLP(nn.Sequential):
     """``[Linear -> SiLU] * hidden_layers -> Linear [-> LayerNorm]`` with the reference's child names
     (``0``, ``2``, ..: Linear; last: LayerNorm; utils/networks.py:8-40).
 
-    ``hidden_layers == 1`` (every BASELINE config, the reference's default) is ONE fused HIP kernel and can take
-    the gather / concat / residual / aggregation geometry of the GNN layers.  Other depths are composed: the
-    trailing ``Linear -> SiLU -> Linear [-> LayerNorm]`` pairs run on the fused kernel, a leftover leading
-    ``Linear -> SiLU`` (odd number of Linears) and the ``hidden_layers == 0`` case go through the ROCm library GEMM
-    (``F.linear``); the GNN layers then use their explicit-gather path.  GPU only either way."""
+    ``hidden_layers == 1`` (every BASELINE config, the reference's default, train_model.py:193-197) is ONE launch of the
+    fused kernel ``Linear -> SiLU -> Linear [-> LayerNorm]`` and takes the gather / concat / residual / aggregation geometry of
+    the GNN layers.  Every other depth is a chain of launches of the SAME kernels (no library GEMM, no eager op):
+
+    * a leading ``Linear -> SiLU`` is the fused kernel with ``W2 = I, b2 = 0`` and no LayerNorm (an exact product in the
+      fp32-class matrix modes: ``1.0`` is one bf16 term) -- the first one with the caller's gather / concat geometry;
+    * the trailing ``Linear -> SiLU -> Linear [-> LayerNorm]`` is the fused kernel as it is; when the caller wants residual
+      terms it reads the residual sources as extra inputs whose columns of the first weight matrix are zero;
+    * ``hidden_layers == 0`` (``Linear [-> LayerNorm]``) is ONE launch with ``NLAM_F_NO_ACT`` and ``W2 = I``, full geometry.
+
+    The identity / zero operands are constants shared per width and device; they get no gradient.  GPU only."""
 
     def __init__(self, blueprint, layer_norm: bool = True):
         hidden_layers = len(blueprint) - 2
@@ -86,6 +103,7 @@ class FusedMLP(nn.Sequential):
         self.has_layer_norm = layer_norm
         self.hidden_layers = hidden_layers
         self._geom = MlpGeometry(nsrc=1)
+        self._geom_noact = MlpGeometry(nsrc=1, flags=L.F_NO_ACT)
 
     @property
     def fully_fused(self) -> bool:
@@ -94,47 +112,89 @@ class FusedMLP(nn.Sequential):
     def _linears(self):
         return [m for m in self if isinstance(m, nn.Linear)]
 
+    def _ln(self):
+        ln = self[len(self) - 1] if self.has_layer_norm else None
+        return (ln.weight, ln.bias) if ln is not None else (None, None)
+
     def params(self):
         """(W1, b1, W2, b2, ln_w, ln_b) of the last ``Linear -> SiLU -> Linear [-> LN]`` block."""
         lin = self._linears()
-        ln = self[len(self) - 1] if self.has_layer_norm else None
-        return (
-            lin[-2].weight, lin[-2].bias, lin[-1].weight, lin[-1].bias,
-            ln.weight if ln is not None else None, ln.bias if ln is not None else None,
-        )
+        return (lin[-2].weight, lin[-2].bias, lin[-1].weight, lin[-1].bias, *self._ln())
 
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("neural_lam_amd layers run on MI355X only (no CPU / eager fallback; see oracle/ for a CPU reference)")
-        lin = self._linears()
-        n = len(lin)
-        if n == 1:   # hidden_layers == 0: Linear [-> LayerNorm]
-            y = torch.nn.functional.linear(x, lin[0].weight, lin[0].bias)
-            if self.has_layer_norm:
-                ln = self[len(self) - 1]
-                y = torch.nn.functional.layer_norm(y, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
-            return y
-        k = 0
         leaf_input = not x.requires_grad
-        if n % 2 == 1:   # leftover leading Linear -> SiLU
-            x = torch.nn.functional.silu(torch.nn.functional.linear(x, lin[0].weight, lin[0].bias))
-            k = 1
-        while k < n:
-            last = k + 2 == n
-            ln = self[len(self) - 1] if (last and self.has_layer_norm) else None
-            out, _ = FusedMLPFunction.apply(
-                self._geom, lin[k].weight, lin[k].bias, lin[k + 1].weight, lin[k + 1].bias,
-                ln.weight if ln is not None else None, ln.bias if ln is not None else None, x,
-            )
-            x = out if last else torch.nn.functional.silu(out)
-            k += 2
+        out, _ = self.forward_fused(self._geom, x)
         # an MLP of input data / static features: nothing upstream needs its data gradient (ops.early_backward_leaf)
-        return ops.early_backward_leaf(x) if leaf_input else x
+        return ops.early_backward_leaf(out) if leaf_input else out
 
     def forward_fused(self, geom: MlpGeometry, *srcs):
-        """Run with a caller-supplied geometry (concatenated sources, residuals, ...); hidden_layers == 1 only."""
-        assert self.fully_fused
-        return FusedMLPFunction.apply(geom, *self.params(), *srcs)
+        """Run with a caller-supplied geometry (gathered / concatenated sources, residuals, aggregation) -> (out, aggr)."""
+        lin = self._linears()
+        n = len(lin)
+        dev = srcs[0].device
+        if n == 2:
+            return FusedMLPFunction.apply(geom, *self.params(), *srcs)
+        if n == 1:   # Linear [-> LayerNorm]: no activation, identity second Linear
+            dout = lin[0].out_features
+            g = self._geom_noact if geom is self._geom else _with_flags(geom, geom.flags | L.F_NO_ACT)
+            return FusedMLPFunction.apply(g, lin[0].weight, lin[0].bias, _const("eye", dout, dev), _const("zero", dout, dev),
+                                          *self._ln(), *srcs)
+        # ---- hidden_layers >= 2: [Linear -> SiLU] prefixes, then the fused pair ----
+        first = _prefix_geometry(geom)
+        h = lin[0].out_features
+        a, _ = FusedMLPFunction.apply(first, lin[0].weight, lin[0].bias, _const("eye", h, dev), _const("zero", h, dev), None, None, *srcs)
+        for k in range(1, n - 2):
+            h = lin[k].out_features
+            a, _ = FusedMLPFunction.apply(self._geom, lin[k].weight, lin[k].bias, _const("eye", h, dev), _const("zero", h, dev),
+                                          None, None, a)
+        last, res_srcs = _suffix_geometry(geom, srcs)
+        W1 = lin[n - 2].weight
+        if res_srcs:   # the residual sources ride along as inputs with zero weight columns
+            W1 = torch.cat([W1.new_zeros(W1.shape[0], sum(t.shape[-1] for t in res_srcs)), W1], dim=1)
+        return FusedMLPFunction.apply(last, W1, lin[n - 2].bias, lin[n - 1].weight, lin[n - 1].bias, *self._ln(), *res_srcs, a)
+
+
+def _with_flags(geom: MlpGeometry, flags: int) -> MlpGeometry:
+    import dataclasses
+
+    key = ("flags", flags)
+    cache = geom.__dict__.setdefault("_derived", {})
+    if key not in cache:
+        cache[key] = dataclasses.replace(geom, flags=flags)
+        cache[key].__dict__.pop("_derived", None)
+    return cache[key]
+
+
+def _prefix_geometry(geom: MlpGeometry) -> MlpGeometry:
+    """Geometry of the FIRST launch of a deeper MLP: the caller's sources (gather indices, tiles, gradient modes), output rows
+    in tile-row order, no residual, no aggregation."""
+    import dataclasses
+
+    cache = geom.__dict__.setdefault("_derived", {})
+    if "prefix" not in cache:
+        g = dataclasses.replace(geom, flags=0, out_idx=None, out_rows=None, want_out=True, aggregate=False)
+        g.__dict__.pop("_derived", None)
+        cache["prefix"] = g
+    return cache["prefix"]
+
+
+def _suffix_geometry(geom: MlpGeometry, srcs):
+    """Geometry of the LAST launch of a deeper MLP, whose input is the previous launch's output (tile-row order, identity
+    index): the caller's output index / aggregation / residual flags.  NLAM_F_ADD_SRC0 / _SRC1 name sources 0 / 1 of a launch, so
+    those sources stay in place (gathered as the caller gathers them, zero weight columns) and the real input comes last."""
+    import dataclasses
+
+    keep = 2 if geom.flags & L.F_ADD_SRC1 else (1 if geom.flags & L.F_ADD_SRC0 else 0)
+    cache = geom.__dict__.setdefault("_derived", {})
+    if "suffix" not in cache:
+        idx = [geom.src_idx[k] if k < len(geom.src_idx) else None for k in range(keep)] + [None]
+        dm = [geom.dmode[k] for k in range(keep)] + [1]
+        g = dataclasses.replace(geom, nsrc=keep + 1, src_idx=idx + [None] * (3 - len(idx)), dmode=dm + [1] * (3 - len(dm)))
+        g.__dict__.pop("_derived", None)
+        cache["suffix"] = g
+    return cache["suffix"], tuple(srcs[:keep])
 
 
 def grouped_mlp_forward(pairs):
@@ -322,10 +382,14 @@ class InteractionNet(nn.Module):
                 out_rows=csr.num_edges,
                 want_out=want_out,
                 aggregate=True,
-                rowptr=csr.rowptr,
-                inv_deg=csr.inv_deg,
+                # receivers cut over several tiles reduce piecewise into virtual segments (extended row pointers / scales),
+                # summed up afterwards by nlam_split_combine: deterministic, the kernels see ordinary tiles
+                rowptr=csr.rowptr_ext if csr.comb_ptr is not None else csr.rowptr,
+                inv_deg=csr.inv_deg_ext if csr.comb_ptr is not None else csr.inv_deg,
                 seg_of_row=csr.rec,
                 nseg_total=csr.num_rec,
+                nseg_ext=csr.nseg_ext,
+                comb=(csr.comb_ptr, csr.comb_src, csr.comb_dst) if csr.comb_ptr is not None else None,
                 has_split=csr.has_split,
                 dmode=[1, 2, 3],
                 colptr=csr.colptr,
@@ -353,14 +417,16 @@ class InteractionNet(nn.Module):
         csr = self._csr(send_rep.device, send_rep.shape[-2])
         if isinstance(self.edge_mlp, SplitMLPs) and self.edge_mlp.fully_fused:
             return self._messages_chunked(csr, send_rep, rec_rep, edge_rep, want_out, add_edge)
-        if isinstance(self.edge_mlp, SplitMLPs) or not self.edge_mlp.fully_fused:
+        if isinstance(self.edge_mlp, SplitMLPs):   # chunked AND another depth than the default: per-chunk MLP chains on an explicit gather
             return self._messages_generic(csr, send_rep, rec_rep, edge_rep, want_out, add_edge)
         key = (str(send_rep.device), send_rep.shape[-2])
         if csr.has_split and torch.are_deterministic_algorithms_enabled():
-            # receivers with more than 32 in-edges are cut over several tiles whose partial sums meet through atomic adds: the
-            # one place of the fused path whose summation order is not fixed (train_model.py:566 trains with deterministic=True)
-            msg = (f"this edge set has receivers with in-degree > 32 (max {csr.max_in_degree}): their aggregation and receiver "
-                   "gradients use atomic adds and are not bit-reproducible")
+            # only with graph.VIRTUAL_SPLIT switched off (the one-pass NLAM_TILE_SPLIT tiles of the C-ABI): partial sums of a
+            # receiver's pieces then meet through atomic adds, the one summation order of the fused path that is not fixed
+            # (train_model.py:566 trains with deterministic=True).  The default schedule reduces such receivers in two
+            # fixed-order passes and never gets here.
+            msg = (f"this edge set has receivers with in-degree > 32 (max {csr.max_in_degree}) on NLAM_TILE_SPLIT tiles: their aggregation "
+                   "and receiver gradients use atomic adds and are not bit-reproducible")
             if torch.is_deterministic_algorithms_warn_only_enabled():
                 import warnings
 
@@ -385,6 +451,8 @@ class InteractionNet(nn.Module):
     def _factorise(self, csr, send_rep, rec_rep, edge_rep) -> bool:
         """Factorised edge MLP (see FACTORISE_MIN_EDGES): InteractionNet messages (no ``x_j +`` term), split-bf16 matrix
         modes, widths that the narrow kernels take as whole 32-column units."""
+        if not self.edge_mlp.fully_fused:
+            return False
         d, hid = edge_rep.shape[-1], self.edge_mlp[0].out_features
         dout = self.edge_mlp[2].out_features
         wide = max(d, hid, dout) > 64
@@ -446,8 +514,9 @@ class InteractionNet(nn.Module):
         return aggr, edge_out
 
     def _messages_generic(self, csr, send_rep, rec_rep, edge_rep, want_out, add_edge):
-        # chunked edge MLPs (HiLAMParallel): per-chunk fused MLP kernels over an explicit
-        # gathered concat; aggregation by the CSR segment-sum kernel.
+        # chunked edge MLPs (HiLAMParallel) of another depth than hidden_layers = 1: every chunk's MLP is a chain of fused
+        # launches (FusedMLP) over an explicitly gathered concat; aggregation by the CSR segment-sum kernel.  The gather /
+        # concat / split here are data movement through torch; every GEMM, activation and LayerNorm runs in the library.
         # device copy of the local edge index, made once per device (a host-to-device copy per call would also be
         # illegal inside a HIP-graph capture; the trainer's warm-up steps populate this cache before capturing)
         dkey = ("ei", str(send_rep.device))
@@ -480,7 +549,7 @@ class InteractionNet(nn.Module):
                 rec_b = rec_rep.expand(*lead, -1, -1) if rec_rep.shape[:-2] != lead else rec_rep
                 out, _ = ChunkedMLPFunction.apply(geom, len(self.aggr_mlp.mlps), *self.aggr_mlp.flat_params(), rec_b, aggr)
                 return out
-        if isinstance(self.aggr_mlp, SplitMLPs) or not self.aggr_mlp.fully_fused:
+        if isinstance(self.aggr_mlp, SplitMLPs):
             rec_diff = self.aggr_mlp(torch.cat((rec_rep, aggr), dim=-1))
             return self.node_residual_target(rec_rep, aggr) + rec_diff
         out, _ = self.aggr_mlp.forward_fused(self._node_geom(), rec_rep, aggr)

@@ -488,6 +488,15 @@ class EdgeCSR:
     cperm: torch.Tensor  # (E,) CSR positions sorted by sender (stable)
     inv_deg: torch.Tensor  # (N_r,) 1 / max(in_degree, 1)  float32
     max_in_degree: int
+    # Receivers with more in-edges than a tile holds (build_tile_schedule, "virtual" split): the pieces of such a receiver are
+    # tiles of their own that reduce into VIRTUAL segments behind the real ones, and ``nlam_split_combine`` adds the pieces
+    # up in a fixed order -- no atomics anywhere.  None / 0 when the edge set has no such receiver.
+    rowptr_ext: torch.Tensor | None = None    # (nseg_ext + 1,): rowptr, then the row ranges of the virtual segments
+    inv_deg_ext: torch.Tensor | None = None   # (nseg_ext,): inv_deg, then the scale of each virtual segment's real receiver
+    nseg_ext: int = 0                         # rows of an aggregation buffer: num_rec + 1 + virtual segments
+    comb_ptr: torch.Tensor | None = None      # (n_split + 1,): pieces of split receiver s = comb_src[comb_ptr[s]:comb_ptr[s+1]]
+    comb_src: torch.Tensor | None = None      # virtual segment ids, in CSR order
+    comb_dst: torch.Tensor | None = None      # (n_split,): the real receiver
 
     def to(self, device):
         kw = {}
@@ -559,19 +568,35 @@ TILE_ROWS = 32  # columns of v_mfma_f32_32x32x2_f32 = rows (edges) one wave owns
 TILE_SPLIT = 1 << 30
 
 
-def build_tile_schedule(rowptr: torch.Tensor, tile_rows: int = TILE_ROWS):
+# Receivers with more than TILE_ROWS in-edges: "virtual" = deterministic two-pass reduction (default: the reference trains with
+# deterministic=True, train_model.py:566, on whatever graph create_graph.py emits); False = the one-pass NLAM_TILE_SPLIT tiles of
+# the C-ABI, whose partial sums meet through atomic adds (kept for ABI users and covered by a test).
+VIRTUAL_SPLIT = True
+
+
+def build_tile_schedule(rowptr: torch.Tensor, tile_rows: int = TILE_ROWS, virtual_split: bool | None = None):
     """Partition the receivers into tiles of whole receivers with <= ``tile_rows``
     edges (and <= ``tile_rows`` receivers).  A receiver with more in-edges than a
-    tile holds is split over several tiles flagged ``TILE_SPLIT`` (the kernel
-    adds those partial sums atomically; everything else uses plain stores).
+    tile holds is cut into pieces of <= ``tile_rows`` edges:
 
-    Returns (int32 tensor (ntiles, 4) = [row0, nrows, seg0, nseg|flag], has_split).
+    * ``virtual_split`` (default): every piece is an ordinary one-receiver tile whose segment id is a VIRTUAL receiver
+      behind the real ones -- ids ``num_rec + 1 ..``; ``split["rowptr_ext"]`` continues ``rowptr`` with the pieces' row
+      ranges (one terminating entry per split receiver, a gap segment no tile owns) -- so the kernels reduce it with plain
+      stores like any tile, and ``nlam_split_combine`` then sums a receiver's pieces in CSR order into its real row.
+      Deterministic; no kernel knows about it.
+    * otherwise the pieces are flagged ``TILE_SPLIT`` and the kernels add their partial sums atomically into a zeroed output.
+
+    Returns (int32 tensor (ntiles, 4) = [row0, nrows, seg0, nseg|flag], has_split, split) -- ``has_split`` is True only for
+    flagged tiles; ``split`` is None or a dict(rowptr_ext, seg_real, nseg_ext, comb_ptr, comb_src, comb_dst) of int32 tensors.
     """
+    if virtual_split is None:
+        virtual_split = VIRTUAL_SPLIT
     rp = rowptr.detach().cpu().numpy().astype(np.int64)
     nrec = rp.shape[0] - 1
     tiles = []
     has_split = False
     cur_r0, cur_e0, cur_ne, cur_nr = 0, 0, 0, 0
+    ext_ptr, ext_real, comb_ptr, comb_src, comb_dst = [], [], [0], [], []
 
     def flush():
         nonlocal cur_ne, cur_nr
@@ -583,9 +608,21 @@ def build_tile_schedule(rowptr: torch.Tensor, tile_rows: int = TILE_ROWS):
         deg = int(rp[r + 1] - rp[r])
         if deg > tile_rows:
             flush()
-            has_split = True
-            for e in range(int(rp[r]), int(rp[r + 1]), tile_rows):
-                tiles.append((e, min(tile_rows, int(rp[r + 1]) - e), r, 1 | TILE_SPLIT))
+            if virtual_split:
+                for e in range(int(rp[r]), int(rp[r + 1]), tile_rows):
+                    v = nrec + 1 + len(ext_ptr)          # rowptr_ext[v] = e, rowptr_ext[v + 1] = start of the next piece / the end
+                    tiles.append((e, min(tile_rows, int(rp[r + 1]) - e), v, 1))
+                    ext_ptr.append(e)
+                    ext_real.append(r)
+                    comb_src.append(v)
+                ext_ptr.append(int(rp[r + 1]))           # terminates the last piece; as a segment it is a gap nothing writes or reads
+                ext_real.append(r)
+                comb_ptr.append(len(comb_src))
+                comb_dst.append(r)
+            else:
+                has_split = True
+                for e in range(int(rp[r]), int(rp[r + 1]), tile_rows):
+                    tiles.append((e, min(tile_rows, int(rp[r + 1]) - e), r, 1 | TILE_SPLIT))
             cur_r0, cur_e0 = r + 1, int(rp[r + 1])
             continue
         if cur_nr == 0:
@@ -597,7 +634,27 @@ def build_tile_schedule(rowptr: torch.Tensor, tile_rows: int = TILE_ROWS):
         cur_nr += 1
     flush()
     t = torch.tensor(tiles, dtype=torch.int64).reshape(-1, 4).to(torch.int32)
-    return t.contiguous(), has_split
+    split = None
+    if comb_dst:
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32)
+        nseg_ext = nrec + 1 + len(ext_ptr)
+        # nseg_ext + 1 entries: the real row pointers (nrec + 1), the virtual ones, one terminator for the last gap segment
+        rowptr_ext = torch.cat([rowptr.detach().cpu().to(torch.int32), i32(ext_ptr), i32([int(rp[nrec])])])
+        split = dict(rowptr_ext=rowptr_ext.contiguous(), seg_real=i32(ext_real), nseg_ext=nseg_ext,
+                     comb_ptr=i32(comb_ptr), comb_src=i32(comb_src), comb_dst=i32(comb_dst))
+    return t.contiguous(), has_split, split
+
+
+def attach_split(csr: EdgeCSR, split) -> EdgeCSR:
+    """Store a virtual-split plan (build_tile_schedule) on the layout: extended row pointers / scales and the combine lists."""
+    if split is None:
+        return csr
+    csr.rowptr_ext = split["rowptr_ext"]
+    real = split["seg_real"].long()
+    csr.inv_deg_ext = torch.cat([csr.inv_deg, torch.ones(1, dtype=torch.float32), csr.inv_deg[real]]).contiguous()
+    csr.nseg_ext = int(split["nseg_ext"])
+    csr.comb_ptr, csr.comb_src, csr.comb_dst = split["comb_ptr"], split["comb_src"], split["comb_dst"]
+    return csr
 
 
 # --------------------------------------------------------------------------
@@ -612,6 +669,7 @@ def build_tile_schedule(rowptr: torch.Tensor, tile_rows: int = TILE_ROWS):
 EDGE_LAYOUT_FILENAME = "edge_layouts.pt"
 _LAYOUT_CACHE: dict = {}
 _LAYOUT_FIELDS = ("perm", "send", "rec", "rowptr", "colptr", "cperm", "inv_deg")
+_SPLIT_FIELDS = ("rowptr_ext", "inv_deg_ext", "comb_ptr", "comb_src", "comb_dst")   # present when a receiver exceeds a tile
 
 
 def edge_layout_key(edge_index: torch.Tensor, num_send: int, num_rec: int) -> str:
@@ -619,7 +677,7 @@ def edge_layout_key(edge_index: torch.Tensor, num_send: int, num_rec: int) -> st
 
     ei = edge_index.detach().cpu().to(torch.int64).contiguous()
     h = hashlib.sha1(ei.numpy().tobytes())
-    h.update(f"{tuple(ei.shape)}|{int(num_send)}|{int(num_rec)}|{TILE_ROWS}".encode())
+    h.update(f"{tuple(ei.shape)}|{int(num_send)}|{int(num_rec)}|{TILE_ROWS}|split={'virtual' if VIRTUAL_SPLIT else 'atomic'}".encode())
     return h.hexdigest()
 
 
@@ -635,7 +693,8 @@ def edge_layout(edge_index: torch.Tensor, num_send: int | None = None, num_rec: 
     hit = _LAYOUT_CACHE.get(key)
     if hit is None:
         csr = build_edge_csr(ei, num_send=num_send, num_rec=num_rec)
-        tiles, has_split = build_tile_schedule(csr.rowptr)
+        tiles, has_split, split = build_tile_schedule(csr.rowptr)
+        attach_split(csr, split)
         hit = _LAYOUT_CACHE[key] = (csr, tiles, has_split)
     return hit
 
@@ -644,12 +703,18 @@ def _layout_to_record(csr: EdgeCSR, tiles: torch.Tensor, has_split: bool) -> dic
     rec = {f: getattr(csr, f) for f in _LAYOUT_FIELDS}
     rec.update(tiles=tiles, has_split=bool(has_split), num_send=csr.num_send, num_rec=csr.num_rec, num_edges=csr.num_edges,
                max_in_degree=csr.max_in_degree)
+    if csr.rowptr_ext is not None:
+        rec.update({f: getattr(csr, f) for f in _SPLIT_FIELDS}, nseg_ext=int(csr.nseg_ext))
     return rec
 
 
 def _record_to_layout(rec: dict):
     csr = EdgeCSR(num_send=int(rec["num_send"]), num_rec=int(rec["num_rec"]), num_edges=int(rec["num_edges"]),
                   max_in_degree=int(rec["max_in_degree"]), **{f: rec[f] for f in _LAYOUT_FIELDS})
+    if "rowptr_ext" in rec:
+        for f in _SPLIT_FIELDS:
+            setattr(csr, f, rec[f])
+        csr.nseg_ext = int(rec["nseg_ext"])
     return csr, rec["tiles"], bool(rec["has_split"])
 
 

@@ -408,6 +408,20 @@ class MlpGeometry:
     colptr: torch.Tensor | None = None
     cperm: torch.Tensor | None = None
     num_send: int = 0
+    # receivers cut over several tiles (graph.build_tile_schedule, virtual split): rows of the aggregation / receiver-gradient
+    # buffers including the virtual segments, and the (ptr, src, dst) lists of nlam_split_combine.  rowptr / inv_deg above are
+    # then the extended arrays; nseg_total stays the number of REAL receivers.
+    nseg_ext: int = 0
+    comb: tuple | None = None
+
+
+def split_combine(buf, geom):
+    """Second pass of the deterministic split-receiver reduction: sum the pieces (virtual rows of ``buf`` (B, nseg_ext, w)) into
+    their receivers' rows, in place, fixed order."""
+    ptr, src, dst = geom.comb
+    B, _, w = buf.shape
+    L.check(L.load().nlam_split_combine(_ptr(buf), buf.shape[1] * w, _ptr(ptr), _ptr(src), _ptr(dst), int(dst.numel()), w, B, _stream()),
+            "nlam_split_combine")
 
 
 def _fill_src(dst, tensor, bstride, width, idx):
@@ -442,6 +456,8 @@ class FusedMLPFunction(torch.autograd.Function):
         lib = L.load()
         assert len(srcs) == geom.nsrc
         mm_flags = _mm_flags()   # read before anything can change the autocast state; backward re-uses it
+        if geom.flags & L.F_NO_ACT:
+            mm_flags = 0   # Linear [-> LayerNorm] launches (hidden_layers = 0): the fp32 MFMA kernels carry the activation switch
         # storage is fp32 throughout: low-precision activations handed in by an autocast region are widened here
         srcs = tuple(s if s.dtype == torch.float32 or not s.is_floating_point() else s.float() for s in srcs)
         _require_gpu(W1, b1, W2, b2, ln_w, ln_b, *srcs)
@@ -482,10 +498,11 @@ class FusedMLPFunction(torch.autograd.Function):
             out_rows = geom.out_rows if geom.out_rows is not None else rows
             out = torch.empty((B, out_rows, dout), device=dev, dtype=torch.float32)
             p.out, p.out_idx, p.out_bstride = _ptr(out), _ptr(geom.out_idx), out_rows * dout
+        nseg_rows = geom.nseg_ext if geom.comb is not None else geom.nseg_total   # incl. the virtual segments of split receivers
         if geom.aggregate:
             alloc = torch.zeros if geom.has_split else torch.empty
-            aggr = alloc((B, geom.nseg_total, dout), device=dev, dtype=torch.float32)
-            p.aggr, p.rowptr, p.inv_deg, p.nseg_total = _ptr(aggr), _ptr(geom.rowptr), _ptr(geom.inv_deg), geom.nseg_total
+            aggr = alloc((B, nseg_rows, dout), device=dev, dtype=torch.float32)
+            p.aggr, p.rowptr, p.inv_deg, p.nseg_total = _ptr(aggr), _ptr(geom.rowptr), _ptr(geom.inv_deg), nseg_rows
         z1 = xhat = rstd = None
         if need_grad:
             z1 = torch.empty((B, rows, hid), device=dev, dtype=torch.float32)
@@ -506,7 +523,7 @@ class FusedMLPFunction(torch.autograd.Function):
             else:
                 wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
                 p.wpack, p.wpack_floats = _ptr(wpack), nwp
-        elif PACKER is not None:   # narrow kernels under a trainer: the image packed once for this step
+        elif PACKER is not None and mm_flags != 0:   # narrow split-bf16 kernels under a trainer: the image packed once for this step
             pack = PACKER.get(W1c, W2c, widths, hid, dout, pre, kin if pre else 0, mm_flags)
             if pack is not None:
                 p.wpack, p.wpack_floats = pack.fwd.data_ptr(), pack.fwd.numel()
@@ -531,6 +548,9 @@ class FusedMLPFunction(torch.autograd.Function):
                             + (" + segment aggregate" if geom.aggregate else "") + (" (saves z1/xhat/rstd)" if need_grad else "")}
 
         L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_fwd(C.byref(p), _stream()), fwd_meta), "nlam_mlp_fwd")
+        if aggr is not None and geom.comb is not None:
+            split_combine(aggr, geom)
+            aggr = aggr[:, : geom.nseg_total]
 
         if need_grad:
             ctx.geom, ctx.B, ctx.rows, ctx.ntiles = geom, B, rows, ntiles
@@ -588,7 +608,8 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     p.nsrc, p.batch, p.rows, p.ntiles = nsrc, B, rows, ntiles
     p.tiles = _ptr(geom.tiles)
     p.W1, p.W2, p.ln_w = _ptr(W1), _ptr(W2), _ptr(ln_w) if ctx.has_ln else None
-    p.hid, p.dout, p.flags, p.nseg_total = hid, dout, geom.flags | ctx.mm_flags, geom.nseg_total
+    p.hid, p.dout, p.flags, p.nseg_total = hid, dout, geom.flags | ctx.mm_flags, geom.nseg_total   # = rows of g_aggr per batch item
+    nseg_rows = geom.nseg_ext if geom.comb is not None else geom.nseg_total   # rows of a receiver-gradient buffer (mode 3)
     pre = bool(geom.flags & L.F_PRE_ADD)
     p.ldw1 = kin if pre else 0
     if g_out is not None:
@@ -621,8 +642,8 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
             p.dsrc[k], p.dsrc_bstride[k] = _ptr(tmp2[k]), rows * w
         elif mode == 3:
             alloc = torch.zeros if geom.has_split else torch.empty
-            dsrc[k] = alloc((B, geom.nseg_total, w), device=dev, dtype=torch.float32)
-            p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), geom.nseg_total * w
+            dsrc[k] = alloc((B, nseg_rows, w), device=dev, dtype=torch.float32)
+            p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), nseg_rows * w
     dz2, dpad = _alloc_dz2(lib, p, B * rows, dout, dev)   # (rows, dout); 32-padded columns for a ragged output width (output_map)
     nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
     wpack = None
@@ -680,6 +701,11 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
                 "what": "LayerNorm/SiLU backward + dh = dz2 W2 + dx = dz1 W1 (data gradients; writes dz1, dz2 for the weight gradients)"}
 
     L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_bwd(C.byref(p), _stream()), bwd_meta), "nlam_mlp_bwd")
+    if geom.comb is not None:   # receiver gradients of split receivers: sum their pieces, drop the virtual rows
+        for k in range(nsrc):
+            if dsrc[k] is not None and p.dmode[k] == 3:
+                split_combine(dsrc[k], geom)
+                dsrc[k] = dsrc[k][:, : geom.nseg_total]
 
     if pre:
         for k in range(1, nsrc):
@@ -688,7 +714,7 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     for k in range(nsrc):
         if tmp2[k] is not None:  # finish scatter-by-sender as a CSC segment sum
             tw = ctx.twin_of.get(k)
-            if tw is not None and dsrc[tw] is not None and dsrc[tw].shape == (B, geom.num_send, widths[k]):
+            if tw is not None and dsrc[tw] is not None and dsrc[tw].shape == (B, geom.num_send, widths[k]) and dsrc[tw].is_contiguous():
                 # senders and receivers are the same tensor (mesh <-> mesh layers): add onto the receiver-side
                 # gradient and report nothing for this slot -- one autograd add launch less per layer
                 segment_sum(tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B,

@@ -127,14 +127,20 @@ def test_other_depths_keep_reference_structure():
 
 
 
-def test_tile_schedule_covers_every_edge_and_receiver_once():
+def _skewed_edges():
     g = torch.Generator().manual_seed(3)
-    ns, nr, E = 40, 25, 900  # some receivers exceed 32 in-edges -> split tiles
+    ns, nr, E = 40, 25, 900  # some receivers exceed 32 in-edges -> cut over several tiles
     ei = torch.stack([torch.randint(0, ns, (E,), generator=g), (torch.rand(E, generator=g) ** 3 * nr).long()])
     ei[1, -1] = nr - 1
+    return ei, ns, nr, E
+
+
+def test_tile_schedule_covers_every_edge_and_receiver_once():
+    """The C-ABI's one-pass schedule: pieces of a receiver with more than 32 in-edges are NLAM_TILE_SPLIT tiles (atomic adds)."""
+    ei, ns, nr, E = _skewed_edges()
     csr = G.build_edge_csr(ei, num_send=ns)
-    tiles, has_split = G.build_tile_schedule(csr.rowptr)
-    assert has_split == (csr.max_in_degree > 32)
+    tiles, has_split, split = G.build_tile_schedule(csr.rowptr, virtual_split=False)
+    assert has_split == (csr.max_in_degree > 32) and split is None
     cov_e = torch.zeros(E, dtype=torch.int32)
     cov_r = torch.zeros(csr.num_rec, dtype=torch.int32)
     for row0, nrows, seg0, nseg in tiles.tolist():
@@ -149,6 +155,41 @@ def test_tile_schedule_covers_every_edge_and_receiver_once():
             assert int(csr.rowptr[seg0]) == row0 and int(csr.rowptr[seg0 + nseg]) == row0 + nrows
             cov_r[seg0 : seg0 + nseg] += 1
     assert torch.all(cov_e == 1) and torch.all(cov_r == 1)
+
+
+def test_virtual_split_schedule_is_a_plain_schedule_on_extended_row_pointers():
+    """The default (deterministic) schedule: no flagged tile; a piece of a long receiver is an ordinary one-receiver tile on
+    a VIRTUAL segment whose row range the extended row pointers give, and the combine lists map the pieces back to the
+    receiver in CSR order.  Emulating kernel + nlam_split_combine on the host reproduces index_add."""
+    ei, ns, nr, E = _skewed_edges()
+    csr = G.build_edge_csr(ei, num_send=ns)
+    tiles, has_split, split = G.build_tile_schedule(csr.rowptr)
+    assert not has_split and split is not None and csr.max_in_degree > 32
+    G.attach_split(csr, split)
+    rp = csr.rowptr_ext.tolist()
+    assert len(rp) == csr.nseg_ext + 1 and rp[: nr + 1] == csr.rowptr.tolist() and csr.inv_deg_ext.shape[0] == csr.nseg_ext
+    cov_e = torch.zeros(E, dtype=torch.int32)
+    written = set()
+    vals = torch.randn(E, 3, dtype=torch.float64)             # per CSR position
+    buf = torch.full((csr.nseg_ext, 3), float("nan"), dtype=torch.float64)
+    for row0, nrows, seg0, nseg in tiles.tolist():
+        assert not (nseg & G.TILE_SPLIT) and 0 <= nrows <= 32 and 1 <= nseg <= 32
+        assert rp[seg0] == row0 and rp[seg0 + nseg] == row0 + nrows   # what the kernels read: rowptr[seg0 .. seg0 + nseg]
+        cov_e[row0 : row0 + nrows] += 1
+        for sg in range(seg0, seg0 + nseg):
+            assert sg not in written
+            written.add(sg)
+            buf[sg] = vals[rp[sg] : rp[sg + 1]].sum(0) * float(csr.inv_deg_ext[sg])
+    assert torch.all(cov_e == 1)
+    cp, cs, cd = csr.comb_ptr.tolist(), csr.comb_src.tolist(), csr.comb_dst.tolist()
+    long_recs = [r for r in range(nr) if int(csr.rowptr[r + 1] - csr.rowptr[r]) > 32]
+    assert cd == long_recs and all(r not in written for r in cd)
+    for s, r in enumerate(cd):
+        pieces = cs[cp[s] : cp[s + 1]]
+        assert all(v > nr and v in written for v in pieces) and len(pieces) == -(-int(csr.rowptr[r + 1] - csr.rowptr[r]) // 32)
+        buf[r] = buf[pieces].sum(0)
+    ref = torch.zeros(nr, 3, dtype=torch.float64).index_add_(0, csr.rec.long(), vals) * csr.inv_deg.double()[:, None]
+    assert torch.allclose(buf[:nr], ref, atol=1e-12)
 
 
 # ---------------------------------------------------------------------------

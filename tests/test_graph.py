@@ -190,7 +190,7 @@ def test_edge_layouts_travel_with_the_graph_directory(tmp_path):
         csr, tiles, has_split = layer._host_csr
         assert G._LAYOUT_CACHE == before                      # nothing was rebuilt
         ref = G.build_edge_csr(ei, num_send=ns, num_rec=nr)
-        ref_tiles, ref_split = G.build_tile_schedule(ref.rowptr)
+        ref_tiles, ref_split, _ = G.build_tile_schedule(ref.rowptr)
         assert all(torch.equal(getattr(csr, f), getattr(ref, f)) for f in G._LAYOUT_FIELDS)
         assert torch.equal(tiles, ref_tiles) and has_split == ref_split and csr.max_in_degree == ref.max_in_degree
     # layers on the same edge set share the host layout object (and with it one device copy)

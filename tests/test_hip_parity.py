@@ -1012,25 +1012,95 @@ def test_node_linear_pair_matches_torch(dev, d, rows):
     assert float(W.grad[:, :d].abs().max()) == 0.0
 
 
+class _NoLibraryGemm:
+    """Fails the test if a torch library GEMM / activation / LayerNorm runs: every depth of utils.make_mlp goes through the fused
+    kernels (missing 2)."""
+
+    NAMES = ("linear", "silu", "layer_norm")
+
+    def __enter__(self):
+        import torch.nn.functional as F
+
+        self.F, self.saved = F, {n: getattr(F, n) for n in self.NAMES}
+
+        def boom(*a, **k):
+            raise AssertionError("a torch library op ran inside the product's MLP path")
+
+        for n in self.NAMES:
+            setattr(F, n, boom)
+        self.mm = torch.Tensor.__matmul__
+        torch.Tensor.__matmul__ = boom
+
+    def __exit__(self, *exc):
+        for n, f in self.saved.items():
+            setattr(self.F, n, f)
+        torch.Tensor.__matmul__ = self.mm
+
+
 @pytest.mark.parametrize("hidden_layers", [0, 2, 3])
-def test_other_mlp_depths_match_oracle(dev, hidden_layers):
-    """utils.make_mlp with hidden_layers != 1 (utils/networks.py:8-40): composed from the fused kernel + library GEMMs."""
+@pytest.mark.parametrize("width,dout,ln", [(64, 64, True), (24, 17, False), (160, 160, True)])
+def test_other_mlp_depths_match_oracle(dev, hidden_layers, width, dout, ln):
+    """utils.make_mlp with hidden_layers != 1 (utils/networks.py:8-40, CLI flag train_model.py:193-197): a chain of launches of the
+    fused kernels -- [Linear -> SiLU] prefixes with an identity second Linear, Linear [-> LayerNorm] with NLAM_F_NO_ACT --
+    narrow, ragged (the output_map shape: 17 columns, no LayerNorm) and wide widths."""
     from oracle import gnn_layers as og
 
     hl = _hl()
     torch.manual_seed(hidden_layers)
-    bp = [24] + [64] * (hidden_layers + 1)
-    ref, net = og.make_mlp(bp), hl.make_mlp(bp)
+    bp = [24] + [width] * hidden_layers + [dout]
+    ref, net = og.make_mlp(bp, layer_norm=ln), hl.make_mlp(bp, layer_norm=ln)
     assert list(ref.state_dict().keys()) == list(net.state_dict().keys())
     net.load_state_dict(ref.state_dict())
     net.to(dev)
     x = torch.randn(2, 700, 24)
     x1, x2 = x.clone().requires_grad_(), x.to(dev).requires_grad_()
-    y1, y2 = ref(x1), net(x2)
-    assert rel_err(y2.cpu(), y1) < TOL
+    y1 = ref(x1)
     y1.sin().sum().backward()
-    y2.sin().sum().backward()
+    with _NoLibraryGemm():
+        y2 = net(x2)
+        y2.sin().sum().backward()
+    assert rel_err(y2.cpu(), y1) < TOL
     assert rel_err(x2.grad.cpu(), x1.grad) < TOL
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < TOL, k
+
+
+@pytest.mark.parametrize("cls_name", ["InteractionNet", "PropagationNet"])
+@pytest.mark.parametrize("hidden_layers,d", [(0, 32), (2, 32), (3, 64), (0, 128), (2, 128)])
+def test_gnn_layers_of_other_depths_keep_the_fused_gather(dev, cls_name, hidden_layers, d):
+    """InteractionNet / PropagationNet with ``hidden_layers`` 0 / 2 / 3 (gnn_layers.py:23-108 builds edge_mlp / aggr_mlp with
+    utils.make_mlp of that depth): gather, concat, residuals and aggregation stay inside the fused launches -- no index_select /
+    cat / library GEMM -- incl. a receiver that is cut over several tiles, with a batch, forward and backward."""
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    ei = _rand_ei(23, 19, 211, seed=5)
+    ei[1, :70] = 4                       # in-degree > 32: the deterministic two-pass reduction
+    torch.manual_seed(5)
+    ref = getattr(og, cls_name)(ei, d, hidden_layers=hidden_layers)
+    net = getattr(hl, cls_name)(ei, d, hidden_layers=hidden_layers)
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    send, rec, edge = torch.randn(2, 23, d), torch.randn(2, 19, d), torch.randn(2, 211, d)
+    s1, r1, e1 = (t.clone().requires_grad_() for t in (send, rec, edge))
+    s2, r2, e2 = (t.to(dev).requires_grad_() for t in (send, rec, edge))
+    o1 = ref(s1, r1, e1)
+    sum(o.square().sum() for o in o1).backward()
+    real_select, real_cat = torch.Tensor.index_select, torch.cat
+    try:
+        def no_gather(*a, **k):
+            raise AssertionError("explicit gather in a GNN layer")
+
+        torch.Tensor.index_select = no_gather
+        with _NoLibraryGemm():
+            o2 = net(s2, r2, e2)
+            sum(o.square().sum() for o in o2).backward()
+    finally:
+        torch.Tensor.index_select = real_select
+    for a, b in zip(o2, o1):
+        assert rel_err(a.cpu(), b) < TOL
+    for a, b in ((s2, s1), (r2, r1), (e2, e1)):
+        assert rel_err(a.grad.cpu(), b.grad) < TOL
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         assert rel_err(p.grad.cpu(), q.grad) < TOL, k
 
@@ -1097,25 +1167,81 @@ def test_segment_sum_long_and_short_segments_match_index_add(width, nseg, avg, b
     assert float(got[:, ::7].cpu().sub(base[:, ::7] if accumulate else 0.0).abs().max()) == 0.0   # empty segments: zero contribution
 
 
-def test_split_receivers_refuse_deterministic_mode(dev):
-    """Receivers with in-degree > 32 are the one place of the fused path that uses atomic adds (NLAM_TILE_SPLIT): under
-    ``torch.use_deterministic_algorithms(True)`` -- what the reference's trainer sets, train_model.py:566 -- such a layer raises
-    (warns in warn-only mode) instead of differing silently from run to run; graphs without split receivers are unaffected."""
+def test_split_receivers_are_reduced_deterministically(dev):
+    """Receivers with in-degree > 32 (none on the MEPS graphs; a finer grid / coarser mesh g2m has them) are cut over several
+    tiles.  The reference trains such graphs with ``Trainer(deterministic=True)`` (train_model.py:566; PyG's scatter,
+    gnn_layers.py:175-189, has a deterministic path): here the pieces reduce into virtual segments with plain stores and
+    ``nlam_split_combine`` adds them up in CSR order, so the layer runs under ``torch.use_deterministic_algorithms(True)``,
+    is bit-reproducible forward and backward, and matches the oracle -- for sum and mean aggregation, with a batch.
+    The C-ABI's one-pass NLAM_TILE_SPLIT tiles (atomic adds; ``graph.VIRTUAL_SPLIT = False``) still refuse that mode."""
+    from neural_lam_amd import graph as G
+    from oracle import gnn_layers as og
+
     hl = _hl()
-    ei_split = torch.stack([torch.arange(200) % 50, torch.zeros(200, dtype=torch.int64)])   # receiver 0: in-degree 200
-    ei_split[1, -1] = 3
-    ei_ok = _rand_ei(50, 40, 300, 1)
-    bad, good = hl.InteractionNet(ei_split, 8).to(dev), hl.InteractionNet(ei_ok, 8).to(dev)
-    args_bad = (torch.randn(50, 8, device=dev), torch.randn(4, 8, device=dev), torch.randn(200, 8, device=dev))
-    args_ok = (torch.randn(50, 8, device=dev), torch.randn(40, 8, device=dev), torch.randn(300, 8, device=dev))
-    bad(*args_bad)   # fine without the switch
+    E = 300
+    ei = torch.stack([torch.arange(E) % 50, torch.zeros(E, dtype=torch.int64)])   # receiver 0: in-degree 200
+    ei[1, 200:260] = 2                                                              # receiver 2: in-degree 60; 1 isolated
+    ei[1, 260:] = torch.arange(40) % 5 + 3
+    from neural_lam_amd import _lib as L
+
+    for cls_name, d, wbf in (("InteractionNet", 64, False), ("PropagationNet", 16, False), ("InteractionNet", 128, False),
+                             ("InteractionNet", 128, True)):
+        # d = 128: the fp32 one-tile-per-workgroup wide kernels, then the split-bf16 super-tile kernels forced at this size
+        assert L.load().nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 0 if wbf else 192) == 0
+        torch.manual_seed(1)
+        ref = getattr(og, cls_name)(ei, d)
+        net = getattr(hl, cls_name)(ei, d)
+        net.load_state_dict(ref.state_dict())
+        net.to(dev)
+        assert net._host_csr[0].comb_ptr is not None and not net._host_csr[2]
+        send, rec, edge = torch.randn(2, 50, d), torch.randn(2, 8, d), torch.randn(2, E, d)
+        r_out = ref(*(t.clone().requires_grad_() for t in (send, rec, edge)))
+        runs = []
+        try:
+            torch.use_deterministic_algorithms(True)
+            for _ in range(2):
+                args = [t.to(dev).requires_grad_() for t in (send, rec, edge)]
+                out = net(*args)
+                (out[0].sum() + 2.0 * out[1].sum()).backward()
+                runs.append([o.detach().clone() for o in out] + [a.grad.clone() for a in args]
+                            + [p.grad.clone() for p in net.parameters()])
+                net.zero_grad()
+        finally:
+            torch.use_deterministic_algorithms(False)
+        for a, b in zip(*runs):
+            assert torch.equal(a, b), cls_name
+        for o, r in zip(runs[0][:2], r_out):
+            assert rel_err(o.cpu(), r.detach()) < TOL, cls_name
+        sg, rg, eg = (t.clone().requires_grad_() for t in (send, rec, edge))
+        o2 = ref(sg, rg, eg)
+        (o2[0].sum() + 2.0 * o2[1].sum()).backward()
+        for h, r in zip(runs[0][2:5], (sg.grad, rg.grad, eg.grad)):
+            assert rel_err(h.cpu(), r) < TOL, cls_name
+        for h, (k, p) in zip(runs[0][5:], ref.named_parameters()):
+            assert rel_err(h.cpu(), p.grad) < TOL, (cls_name, k)
+    assert L.load().nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
+
+    # the one-pass schedule of the C-ABI (atomic partial sums): same results within tolerance, refused in deterministic mode
     try:
-        torch.use_deterministic_algorithms(True)
-        good(*args_ok)
-        with pytest.raises(RuntimeError, match="in-degree > 32"):
-            bad(*args_bad)
-        torch.use_deterministic_algorithms(True, warn_only=True)
-        with pytest.warns(UserWarning, match="in-degree > 32"):
-            bad(*args_bad)
+        G.VIRTUAL_SPLIT = False
+        torch.manual_seed(1)
+        ref = og.InteractionNet(ei, 64)
+        bad = hl.InteractionNet(ei, 64)
+        bad.load_state_dict(ref.state_dict())
+        bad.to(dev)
+        assert bad._host_csr[2] and bad._host_csr[0].comb_ptr is None
+        send, rec, edge = torch.randn(50, 64), torch.randn(8, 64), torch.randn(E, 64)
+        o = bad(send.to(dev), rec.to(dev), edge.to(dev))
+        r = ref(send, rec, edge)
+        assert rel_err(o[0].cpu(), r[0].detach()) < TOL and rel_err(o[1].cpu(), r[1].detach()) < TOL
+        try:
+            torch.use_deterministic_algorithms(True)
+            with pytest.raises(RuntimeError, match="in-degree > 32"):
+                bad(send.to(dev), rec.to(dev), edge.to(dev))
+            torch.use_deterministic_algorithms(True, warn_only=True)
+            with pytest.warns(UserWarning, match="in-degree > 32"):
+                bad(send.to(dev), rec.to(dev), edge.to(dev))
+        finally:
+            torch.use_deterministic_algorithms(False)
     finally:
-        torch.use_deterministic_algorithms(False)
+        G.VIRTUAL_SPLIT = True
