@@ -327,8 +327,9 @@ def test_cfg5_full_rollout_under_bf16_autocast_against_the_oracle_on_the_gpu(dev
     bench.py's gpu_reference_equivalent), its loss and gradients are moved to the host, and the product's captured trainer
     step under torch.autocast(bfloat16) is compared with them.  The oracle's own rounding error is bounded first: one
     d = 512 mesh layer in fp64 against the same layer in fp32.
-    Tolerances (bf16 operands / bf16 saved activations against an fp32 reference, eight chained AR steps): prediction and
-    loss 5e-2, parameter gradients relative L2 <= 1.5e-1 and cosine >= 0.985; the measured values are printed."""
+    Tolerances (bf16 operands against an fp32 reference, eight chained AR steps): prediction 3e-2, loss 1e-2, parameter
+    gradients relative L2 <= 6e-2 and cosine >= 0.998; the measured values are printed (round 4, fp32 storage: prediction
+    7.0e-3, loss 6.3e-4, worst gradient rel-L2 1.3e-2, worst cosine 0.99993, oracle fp32-vs-fp64 8.9e-7)."""
     import gc
 
     import bench
@@ -394,8 +395,8 @@ def test_cfg5_full_rollout_under_bf16_autocast_against_the_oracle_on_the_gpu(dev
     print(f"cfg5 (T=8) bf16 autocast vs fp32 oracle on the GPU: prediction {e_pred:.3e}, loss {e_loss:.3e} "
           f"(no-grad forward {abs(float(h_loss0) - o_loss) / abs(o_loss):.3e}), worst gradient rel-L2 {worst_l2:.3e}, "
           f"worst cosine {worst_cos:.6f}; oracle fp32-vs-fp64 layer error {oracle_err:.2e}")
-    assert e_pred < 5e-2 and e_loss < 5e-2
-    assert worst_l2 < 1.5e-1 and worst_cos > 0.985, (worst_l2, worst_cos)
+    assert e_pred < 3e-2 and e_loss < 1e-2
+    assert worst_l2 < 6e-2 and worst_cos > 0.998, (worst_l2, worst_cos)
 
 
 def test_cfg2_hip_graph_trainer_step_matches_oracle_adamw(dev):
