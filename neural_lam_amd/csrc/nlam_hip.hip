@@ -4023,7 +4023,7 @@ long build_bwd_wbf_jobs(const nlam_mlp_bwd_t* p, int wns, packbf_jobs_t& jobs) {
     int kin = 0;
     for (int s = 0; s < (pre ? 1 : p->nsrc); ++s) kin += p->src[s].width;
     if (pre && p->ldw1 > 0) kin = p->ldw1;
-    const int TKA = 2 * OBT, TKB = 2 * HBT;
+    const int TKA = wbf_bwd_tk(OBT, wns), TKB = wbf_bwd_tk(HBT, wns);   // padded to whole A-ring revolutions: zero groups
     u32x4* base = reinterpret_cast<u32x4*>(p->wpack);
     jobs.njobs = 0;
     long most = (long)HBT * TKA * 64;
