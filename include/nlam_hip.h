@@ -91,6 +91,15 @@ extern "C" {
  * how utils.make_mlp's hidden_layers = 0 case (utils/networks.py:8-40: blueprint [in, out]) runs on the fused kernels.  fp32
  * matrix path only (NLAM_F_MM_* bits must be 0: NLAM_EUNSUP otherwise); not for grouped / factorised / concatenated launches. */
 #define NLAM_F_NO_ACT 128u
+/* NLAM_F_STORE_BF16 (nlam_mlp_fwd / nlam_mlp_bwd): z1, xhat (forward: written, backward: read) and dz1, dz2 (backward: written)
+ * are rows of bfloat16 instead of float -- the pointers of the structs are then reinterpreted, (batch, rows, width) contiguous.
+ * What Lightning's --precision bf16-mixed (train_model.py:163-168) makes of the reference's nn.Linear outputs and their
+ * gradients; halves the bytes a layer saves for and hands to its own backward.  Only where nlam_store_bf16_supported() says so
+ * (one-term split-bf16 wide kernels, hid and dout whole 32-column blocks); NLAM_EUNSUP otherwise.
+ * nlam_wgrad: NLAM_F_A_BF16 = `A` (dz1 / dz2) is bf16, NLAM_F_S_BF16 = src[0] (z1; nsrc must be 1, no gather index) is bf16. */
+#define NLAM_F_STORE_BF16 (1u << 10)
+#define NLAM_F_A_BF16     (1u << 10)
+#define NLAM_F_S_BF16     (1u << 11)
 /* matrix path of the GEMMs (bits 8-9): 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains);
  * n = 1..3: operands split into n bf16 terms on the bf16 matrix cores, fp32 accumulate
  * (1 = plain bf16 operands, 2 = ~2^-16 product error, 3 = fp32-class ~2^-24).  Shapes the
@@ -264,6 +273,9 @@ int64_t nlam_mlp_fwd_wpack_floats(const nlam_mlp_fwd_t* p);
 int64_t nlam_mlp_bwd_wpack_floats(const nlam_mlp_bwd_t* p);
 /* workgroups nlam_mlp_bwd launches for this call (rows of vec_partials it writes) */
 int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p);
+/* 1 if this forward launch (every field but z1 / xhat / wpack set) and the backward / weight-gradient launches that belong to it
+ * can run with NLAM_F_STORE_BF16 (z1, xhat, dz1, dz2 as bfloat16 rows) */
+int32_t nlam_store_bf16_supported(const nlam_mlp_fwd_t* p);
 /* row stride the call's dz2 buffer must have (set p->dz2_ld to it); 0 = dout (every shape but a ragged output width) */
 int32_t nlam_mlp_bwd_dz2_ld(const nlam_mlp_bwd_t* p);
 /* number of row slices (p->nparts) that fills the chip for this weight-gradient shape */
@@ -331,6 +343,11 @@ int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr
 int32_t nlam_segment_sum_acc(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order,
                          const float* scale, float* out, int32_t nseg, int32_t width, int32_t batch,
                          void* hip_stream);
+
+/* nlam_segment_sum over input rows stored as bfloat16 (width % 8 == 0; out is float): the dz1 rows of a backward launch that ran with
+ * NLAM_F_STORE_BF16 */
+int32_t nlam_segment_sum_bf16(const uint16_t* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order,
+                              const float* scale, float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream);
 
 /* buf[b, dst[s], :] = sum_{q in [ptr[s], ptr[s+1])} buf[b, src[q], :], q ascending, for s < n; rows of `width` floats, batch
  * stride `bstride` floats.  Second pass of the DETERMINISTIC reduction of receivers with more in-edges than a 32-row tile

@@ -19,6 +19,7 @@ NLAM_MAX_CAT = 6
 NLAM_MAX_REDUCE_JOBS = 40
 NLAM_MAX_GROUP = 8
 F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD, F_LEAF_WGRAD, F_WPACK_READY, F_NO_ACT = 1, 2, 4, 8, 16, 32, 64, 128
+F_STORE_BF16, F_A_BF16, F_S_BF16 = 1 << 10, 1 << 10, 1 << 11
 TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning keys (include/nlam_hip.h)
 TUNE_WGRAD_CHUNKS = 2
 TUNE_LIN_WGS = 3
@@ -50,6 +51,8 @@ EXPORTS = [
     "nlam_segment_sum",
     "nlam_segment_sum_acc",
     "nlam_split_combine",
+    "nlam_segment_sum_bf16",
+    "nlam_store_bf16_supported",
     "nlam_reduce_partials",
     "nlam_reduce_jobs",
     "nlam_wmse_fwd",
@@ -352,6 +355,10 @@ def load():
     lib.nlam_segment_sum.restype = i32
     lib.nlam_segment_sum_acc.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.nlam_segment_sum_acc.restype = i32
+    lib.nlam_segment_sum_bf16.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.nlam_segment_sum_bf16.restype = i32
+    lib.nlam_store_bf16_supported.argtypes = [C.POINTER(MlpFwd)]
+    lib.nlam_store_bf16_supported.restype = i32
     lib.nlam_split_combine.argtypes = [vp, i64, vp, vp, vp, i32, i32, i32, vp]
     lib.nlam_split_combine.restype = i32
     lib.nlam_reduce_partials.argtypes = [vp, i32, i64, i32, vp, i32, vp]

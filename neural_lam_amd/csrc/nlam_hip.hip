@@ -4304,6 +4304,11 @@ int64_t nlam_mlp_bwd_wpack_floats(const nlam_mlp_bwd_t* p) {
     return f;
 }
 
+int32_t nlam_store_bf16_supported(const nlam_mlp_fwd_t* p) {
+    if (p == nullptr) return 0;
+    return store_bf16_ok(p) ? 1 : 0;
+}
+
 int32_t nlam_mlp_bwd_dz2_ld(const nlam_mlp_bwd_t* p) {
     if (p == nullptr) return 0;
     if (bwd_is_wide(p))   // split-bf16 wide kernel with a ragged output width: padded so that the W2 gradient has m % 4 == 0
@@ -4398,6 +4403,7 @@ int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
     if ((p->flags & NLAM_F_ADD_SRC0) && p->src[0].width != p->dout) return NLAM_EINVAL;
     if ((p->flags & NLAM_F_ADD_SRC1) && (p->nsrc < 2 || p->src[1].width != p->dout)) return NLAM_EINVAL;
     if ((p->flags & NLAM_F_NO_ACT) && ((p->flags & (NLAM_F_MM_MASK | NLAM_F_PRE_ADD)) != 0 || p->ncat != 0)) return NLAM_EUNSUP;
+    if ((p->flags & NLAM_F_STORE_BF16) && !store_bf16_ok(p)) return NLAM_EUNSUP;
     if (p->ncat != 0) {   // src[0] = concatenation of pieces: one un-gathered source of <= 64 columns, whole float4s per row
         if (p->ncat < 0 || p->ncat > NLAM_MAX_CAT || p->nsrc != 1 || p->src[0].idx != nullptr) return NLAM_EINVAL;
         int wsum = 0;
@@ -4451,6 +4457,21 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
         if (rc != 0) return rc;                                                                                               \
         hipLaunchKernelGGL((mlp_fwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_, RTP_>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p); \
     } while (0)
+#define NLAM_LAUNCH_FWD_WBF_S(NW_, FG_, FB_, RT_, RTP_)                                                                          \
+    do {                                                                                                                      \
+        int rc = set_lds(mlp_fwd_wbf_kernel<1, NW_, FG_, FB_, RT_, RTP_, true>, lds);                                          \
+        if (rc != 0) return rc;                                                                                               \
+        hipLaunchKernelGGL((mlp_fwd_wbf_kernel<1, NW_, FG_, FB_, RT_, RTP_, true>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p); \
+    } while (0)
+            if (p->flags & NLAM_F_STORE_BF16) {   // z1 / xhat as bf16 rows: one term, whole blocks, the shapes of store_bf16_ok()
+                if (!store_bf16_ok(p)) return NLAM_EUNSUP;
+                if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF_S(8, 8, 1, 4, 2);
+                else if (pl.cfg == 5) NLAM_LAUNCH_FWD_WBF_S(4, 4, 2, 2, 1);
+                else if (pl.cfg == 6) NLAM_LAUNCH_FWD_WBF_S(4, 4, 4, 1, 1);
+                else if (pl.cfg == 3) NLAM_LAUNCH_FWD_WBF_S(8, 8, 2, 2, 1);
+                else return NLAM_EUNSUP;
+                return (int32_t)hipGetLastError();
+            }
             if (wns == 1) {
                 if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(1, 8, 4, 1, 4, 2);
                 else if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF(1, 8, 8, 1, 4, 2);
@@ -4591,6 +4612,7 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
             return NLAM_EINVAL;
     }
     if ((p->flags & NLAM_F_NO_ACT) && (p->flags & (NLAM_F_MM_MASK | NLAM_F_PRE_ADD | NLAM_F_LEAF_WGRAD)) != 0) return NLAM_EUNSUP;
+    if ((p->flags & NLAM_F_STORE_BF16) && !(bwd_is_wide(p) && bwd_wbf_ns(p) == 1)) return NLAM_EUNSUP;
     if (p->rows == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
     if (bwd_is_wide(p) && (p->flags & NLAM_F_PRE_ADD) && bwd_wbf_ns(p) == 0) return NLAM_EUNSUP;
@@ -4630,6 +4652,19 @@ int32_t nlam_detail::bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream) {
         if (rc != 0) return rc;                                                                                               \
         hipLaunchKernelGGL((mlp_bwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p);    \
     } while (0)
+#define NLAM_LAUNCH_BWD_WBF_S(NW_, FG_, FB_, RT_)                                                                                \
+    do {                                                                                                                      \
+        int rc = set_lds(mlp_bwd_wbf_kernel<1, NW_, FG_, FB_, RT_, true>, lds);                                                \
+        if (rc != 0) return rc;                                                                                               \
+        hipLaunchKernelGGL((mlp_bwd_wbf_kernel<1, NW_, FG_, FB_, RT_, true>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p);  \
+    } while (0)
+            if (p->flags & NLAM_F_STORE_BF16) {
+                if (wns != 1 || p->hid % 32 != 0 || p->dout % 32 != 0 || p->dz2_ld != 0 || pl.cfg == 1) return NLAM_EUNSUP;
+                if (pl.cfg == 2) NLAM_LAUNCH_BWD_WBF_S(8, 8, 1, 2);
+                else if (pl.cfg == 5) NLAM_LAUNCH_BWD_WBF_S(4, 4, 2, 1);
+                else NLAM_LAUNCH_BWD_WBF_S(8, 8, 2, 1);
+                return (int32_t)hipGetLastError();
+            }
             if (wns == 1) {
                 if (pl.cfg == 1) NLAM_LAUNCH_BWD_WBF(1, 8, 4, 1, 2);
                 else if (pl.cfg == 2) NLAM_LAUNCH_BWD_WBF(1, 8, 8, 1, 2);
@@ -4878,6 +4913,7 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     hipStream_t stream = (hipStream_t)hip_stream;
     if (!(p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) && wgrad_is_wide(p)) {
         if (wgrad_wbf_ns(p) > 0) return nlam_detail::wgrad_wbf(p, stream);   // split-bf16 matrix path (nlam_wbf.inc)
+        if (p->flags & (NLAM_F_A_BF16 | NLAM_F_S_BF16)) return NLAM_EUNSUP;
         return nlam_detail::wgrad_wide(p, stream);
     }
     return nlam_detail::wgrad_narrow(p, stream);
@@ -4906,6 +4942,26 @@ int32_t nlam_detail::wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream) {
         else NLAM_LAUNCH_WG_WBF(NS_, S_, 2, 2, 2);     \
     } while (0)
         const bool silu = (p->flags & NLAM_F_SILU_B) != 0;
+        if (p->flags & (NLAM_F_A_BF16 | NLAM_F_S_BF16)) {   // operands stored as bf16 (layers running with NLAM_F_STORE_BF16)
+            // dW1 = dz1^T [fp32 sources]: A bf16; dW2 = dz2^T silu(z1): A and the single un-gathered source bf16
+            const bool sb = (p->flags & NLAM_F_S_BF16) != 0;
+            if (wns != 1 || (p->flags & NLAM_F_A_BF16) == 0 || (sb && (p->nsrc != 1 || p->src[0].idx != nullptr || !silu)) || (!sb && silu))
+                return NLAM_EUNSUP;
+#define NLAM_LAUNCH_WG_WBF_B(S_, WM_, WN_, NBW_, SB_)                                                                             \
+    do {                                                                                                                          \
+        int rc = set_lds(wgrad_wbf_kernel<1, S_, 1, WM_, WN_, NBW_, true, SB_>, lds);                                              \
+        if (rc != 0) return rc;                                                                                                   \
+        hipLaunchKernelGGL((wgrad_wbf_kernel<1, S_, 1, WM_, WN_, NBW_, true, SB_>), grid, dim3(WM_ * WN_ * 64), lds, stream, *p);  \
+    } while (0)
+            if (sb) {
+                if (big) NLAM_LAUNCH_WG_WBF_B(true, 4, 2, 4, true);
+                else NLAM_LAUNCH_WG_WBF_B(true, 2, 2, 2, true);
+            } else {
+                if (big) NLAM_LAUNCH_WG_WBF_B(false, 4, 2, 4, false);
+                else NLAM_LAUNCH_WG_WBF_B(false, 2, 2, 2, false);
+            }
+            return (int32_t)hipGetLastError();
+        }
         if (wns == 1 && silu) NLAM_LAUNCH_WG_WBF2(1, true);
         else if (wns == 1) NLAM_LAUNCH_WG_WBF2(1, false);
         else if (silu) NLAM_LAUNCH_WG_WBF2(3, true);
@@ -5098,6 +5154,50 @@ int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream) {
 #if NLAM_IN_TU(1)
 extern "C" {
 
+// the same segment sum over rows stored as bf16 (the dz1 rows of a layer running with NLAM_F_STORE_BF16: gradient of a
+// sender-gathered addend of the factorised edge MLP); width % 8 == 0: thread -> (batch, segment, 8 columns), 16-byte loads, 8 rows in
+// flight, fp32 accumulation in a fixed order
+__global__ void segment_sum_bf16_kernel(const unsigned short* in, long in_bstride, const int32_t* ptr, const int32_t* order,
+                                        const float* scale, float* out, int nseg, int width, int batch) {
+    const int w8 = width >> 3;
+    const long total = (long)batch * nseg * w8;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(gid % w8);
+        const long rest = gid / w8;
+        const int sgm = (int)(rest % nseg);
+        const int b = (int)(rest / nseg);
+        const int lo = ptr[sgm], hi_ = ptr[sgm + 1];
+        const unsigned short* base = in + (long)b * in_bstride + 8 * c8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        auto add = [&](const u32x4 v) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[2 * k] += __builtin_bit_cast(float, v[k] << 16);
+                acc[2 * k + 1] += __builtin_bit_cast(float, v[k] & 0xffff0000u);
+            }
+        };
+        int q = lo;
+        for (; q + 8 <= hi_; q += 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long row = order != nullptr ? order[q + u] : q + u;
+                v[u] = *reinterpret_cast<const u32x4*>(base + row * width);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) add(v[u]);
+        }
+        for (; q < hi_; ++q) {
+            const long row = order != nullptr ? order[q] : q;
+            add(*reinterpret_cast<const u32x4*>(base + row * width));
+        }
+        const float sc = scale != nullptr ? scale[sgm] : 1.f;
+        float* o = out + ((size_t)b * nseg + sgm) * width + 8 * c8;
+        *reinterpret_cast<f32x4*>(o) = f32x4{acc[0] * sc, acc[1] * sc, acc[2] * sc, acc[3] * sc};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[4] * sc, acc[5] * sc, acc[6] * sc, acc[7] * sc};
+    }
+}
+
 static int32_t segment_sum_launch(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
                                   float* out, int32_t nseg, int32_t width, int32_t batch, int accumulate, void* hip_stream) {
     if (in == nullptr || ptr == nullptr || out == nullptr || nseg < 0 || width < 1 || batch < 1) return NLAM_EINVAL;
@@ -5130,6 +5230,20 @@ int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr
                          float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream) {
     NLAM_RANGE("nlam_segment_sum");
     return segment_sum_launch(in, in_bstride, ptr, order, scale, out, nseg, width, batch, 0, hip_stream);
+}
+
+int32_t nlam_segment_sum_bf16(const uint16_t* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
+                              float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream) {
+    NLAM_RANGE("nlam_segment_sum_bf16");
+    if (in == nullptr || ptr == nullptr || out == nullptr || nseg < 0 || width < 8 || batch < 1) return NLAM_EINVAL;
+    if (width % 8 != 0) return NLAM_EUNSUP;
+    if (nseg == 0) return 0;
+    const long total = (long)batch * nseg * (width / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(segment_sum_bf16_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, in, (long)in_bstride, ptr,
+                       order, scale, out, nseg, width, batch);
+    return (int32_t)hipGetLastError();
 }
 
 int32_t nlam_segment_sum_acc(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,

@@ -46,6 +46,12 @@ def _mm_flags() -> int:
     return _MM_FLAGS[MATMUL_MODE]
 
 
+# bf16 STORAGE of what a fused MLP saves for / hands to its own backward (z1, xhat, dz1, dz2) inside a torch.autocast(bfloat16)
+# region -- what Lightning's --precision bf16-mixed makes of the reference's nn.Linear outputs and their gradients
+# (train_model.py:163-168) -- wherever the library has the kernels for it (nlam_store_bf16_supported: the one-term wide kernels).
+STORE_BF16 = os.environ.get("NLAM_STORE_BF16", "1") == "1"
+
+
 # When a trainer owns every parameter's .grad as a zero-initialised view of one flat buffer
 # (trainer.FlatParams), the backward of a fused MLP adds its weight / bias / LayerNorm gradients straight
 # into those views inside the partial-sum reduction and returns None for them: ~6 AccumulateGrad add
@@ -504,19 +510,27 @@ class FusedMLPFunction(torch.autograd.Function):
             aggr = alloc((B, nseg_rows, dout), device=dev, dtype=torch.float32)
             p.aggr, p.rowptr, p.inv_deg, p.nseg_total = _ptr(aggr), _ptr(geom.rowptr), _ptr(geom.inv_deg), nseg_rows
         z1 = xhat = rstd = None
+        sbf = False
         if need_grad:
-            z1 = torch.empty((B, rows, hid), device=dev, dtype=torch.float32)
+            # saved tensors as bf16 rows: bf16 autocast only, where forward, backward and both weight gradients have the kernels
+            sbf = (STORE_BF16 and mm_flags == _MM_FLAGS["bf16"] and torch.is_autocast_enabled("cuda")
+                   and bool(lib.nlam_store_bf16_supported(C.byref(p))))
+            sdt = torch.bfloat16 if sbf else torch.float32
+            if sbf:
+                p.flags = int(p.flags) | L.F_STORE_BF16
+            z1 = torch.empty((B, rows, hid), device=dev, dtype=sdt)
             p.z1 = _ptr(z1)
             if ln_w is not None:
-                xhat = torch.empty((B, rows, dout), device=dev, dtype=torch.float32)
+                xhat = torch.empty((B, rows, dout), device=dev, dtype=sdt)
                 rstd = torch.empty((B, rows), device=dev, dtype=torch.float32)
                 p.xhat, p.rstd = _ptr(xhat), _ptr(rstd)
+        ctx.store_bf16 = sbf
         nwp = lib.nlam_mlp_fwd_wpack_floats(C.byref(p))
         pack = None
         if nwp > 0:  # wide kernels: the weights in MFMA A-operand order -- packed once per step under a trainer, else scratch the launch fills
             wbuf = None
             if PACKER is not None:
-                wbuf = PACKER.get_wide("f", p, nwp, ("f", W1c.data_ptr(), W2c.data_ptr(), tuple(widths), hid, dout, int(p.flags), int(p.ldw1),
+                wbuf = PACKER.get_wide("f", p, nwp, ("f", W1c.data_ptr(), W2c.data_ptr(), tuple(widths), hid, dout, int(p.flags) & ~L.F_STORE_BF16, int(p.ldw1),
                                                       rows, ntiles, B))
             if wbuf is not None:
                 p.wpack, p.wpack_floats, p.flags = wbuf.data_ptr(), nwp, int(p.flags) | L.F_WPACK_READY
@@ -540,7 +554,7 @@ class FusedMLPFunction(torch.autograd.Function):
                 nbytes += aggr.numel() * 4
             for t_ in (z1, xhat, rstd):
                 if t_ is not None:
-                    nbytes += t_.numel() * 4
+                    nbytes += t_.numel() * t_.element_size()
             name, mf = _mm_executed(mm_flags, hid, dout, widths, ragged_out_ok=ln_w is None and not geom.aggregate)
             k1 = widths[0] if pre else kin
             return {"flops": 2.0 * rows * B * (k1 * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
@@ -618,7 +632,10 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
         p.g_aggr, p.seg_of_row = _ptr(g_aggr), _ptr(geom.seg_of_row)
     p.rowptr, p.inv_deg = _ptr(geom.rowptr), _ptr(geom.inv_deg)
     p.z1, p.xhat, p.rstd = _ptr(z1), _ptr(xhat), _ptr(rstd)
-    dz1 = torch.empty((B * rows, hid), device=dev, dtype=torch.float32)
+    sbf = bool(getattr(ctx, "store_bf16", False))   # the forward saved z1 / xhat as bf16 rows: dz1 / dz2 leave as bf16 too
+    if sbf:
+        p.flags = int(p.flags) | L.F_STORE_BF16
+    dz1 = torch.empty((B * rows, hid), device=dev, dtype=torch.bfloat16 if sbf else torch.float32)
     p.dz1 = _ptr(dz1)
     dsrc = [None] * nsrc
     tmp2 = [None] * nsrc
@@ -644,13 +661,17 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
             alloc = torch.zeros if geom.has_split else torch.empty
             dsrc[k] = alloc((B, nseg_rows, w), device=dev, dtype=torch.float32)
             p.dsrc[k], p.dsrc_bstride[k] = _ptr(dsrc[k]), nseg_rows * w
-    dz2, dpad = _alloc_dz2(lib, p, B * rows, dout, dev)   # (rows, dout); 32-padded columns for a ragged output width (output_map)
+    if sbf:
+        dz2, dpad = torch.empty((B * rows, dout), device=dev, dtype=torch.bfloat16), dout
+        p.dz2, p.dz2_ld = _ptr(dz2), 0
+    else:
+        dz2, dpad = _alloc_dz2(lib, p, B * rows, dout, dev)   # (rows, dout); 32-padded columns for a ragged output width (output_map)
     nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
     wpack = None
     if nwp > 0:
         wbuf = None
         if PACKER is not None:
-            wbuf = PACKER.get_wide("b", p, nwp, ("b", W1.data_ptr(), W2.data_ptr(), tuple(widths), hid, dout, int(p.flags), int(p.ldw1),
+            wbuf = PACKER.get_wide("b", p, nwp, ("b", W1.data_ptr(), W2.data_ptr(), tuple(widths), hid, dout, int(p.flags) & ~L.F_STORE_BF16, int(p.ldw1),
                                                   rows, ntiles, B, tuple(int(p.dmode[k]) for k in range(nsrc)), int(p.dz2_ld)))
         if wbuf is not None:
             p.wpack, p.wpack_floats, p.flags = wbuf.data_ptr(), nwp, int(p.flags) | L.F_WPACK_READY
@@ -692,7 +713,7 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     key = ("mlp_bwd", rows * B, kin, hid, dout, nsrc, g_aggr is not None)
 
     def bwd_meta():
-        nbytes = sum(t_.numel() * 4 for t_ in (g_out, g_aggr, z1, xhat, rstd, dz1, dz2) if t_ is not None)
+        nbytes = sum(t_.numel() * t_.element_size() for t_ in (g_out, g_aggr, z1, xhat, rstd, dz1, dz2) if t_ is not None)
         nbytes += sum(t_.numel() * 4 for t_ in (*dsrc, *tmp2) if t_ is not None)
         kin_live = sum(w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0 and not (pre and k_ > 0))
         name, mf = _mm_executed(ctx.mm_flags, hid, dout, [w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0] or [hid],
@@ -710,7 +731,12 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     if pre:
         for k in range(1, nsrc):
             if needs[n_fixed + k] and geom.dmode[k] == 2:   # no (rows, w) round trip: dz1 is the data
-                dsrc[k] = segment_sum(dz1, rows * hid, geom.colptr, geom.cperm, None, geom.num_send, hid, B)
+                if sbf:
+                    dsrc[k] = torch.empty((B, geom.num_send, hid), device=dev, dtype=torch.float32)
+                    L.check(lib.nlam_segment_sum_bf16(_ptr(dz1), rows * hid, _ptr(geom.colptr), _ptr(geom.cperm), None, _ptr(dsrc[k]),
+                                                      geom.num_send, hid, B, _stream()), "nlam_segment_sum_bf16")
+                else:
+                    dsrc[k] = segment_sum(dz1, rows * hid, geom.colptr, geom.cperm, None, geom.num_send, hid, B)
     for k in range(nsrc):
         if tmp2[k] is not None:  # finish scatter-by-sender as a CSC segment sum
             tw = ctx.twin_of.get(k)
@@ -744,8 +770,8 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
         key = ("wgrad", rows * B, m, n)
 
         def wg_meta():
-            nbytes = A.numel() * 4 + partials.numel() * 4
-            nbytes += sum(t.shape[-2] * w * 4 * (B if bstride != 0 or B == 1 else 1) for (t, bstride, w, idx) in src_list)
+            nbytes = A.numel() * A.element_size() + partials.numel() * 4
+            nbytes += sum(t.shape[-2] * w * t.element_size() * (B if bstride != 0 or B == 1 else 1) for (t, bstride, w, idx) in src_list)
             narrow = m <= 64 and all(w <= 64 for (_, _, w, _) in src_list)
             name, mf = ("f32", 0) if narrow else _mm_executed(ctx.mm_flags, m, m, [w for (_, _, w, _) in src_list])
             return {"flops": 2.0 * rows * B * m * n, "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
@@ -761,8 +787,8 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     kin1 = widths[0] if pre else kin
     results = [None] * 6   # dW1, db1, dW2, db2, dgamma, dbeta
     with side_ctx:
-        part1 = wgrad(dz1, hid, src_list, kin1, 0) if needs[1] else None
-        part2 = wgrad(dz2, dpad, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B) if needs[3] else None
+        part1 = wgrad(dz1, hid, src_list, kin1, L.F_A_BF16 if sbf else 0) if needs[1] else None
+        part2 = wgrad(dz2, dpad, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B | ((L.F_A_BF16 | L.F_S_BF16) if sbf else 0)) if needs[3] else None
 
         # ---- one launch reduces every partial sum; with DIRECT_PARAM_GRADS it accumulates into .grad ----
         jobs = L.ReduceJobs()

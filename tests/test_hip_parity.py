@@ -655,6 +655,89 @@ def test_matmul_modes_match_oracle(dev, mode, tol):
         assert rel_err(p.grad.cpu(), q.grad) < tol, k
 
 
+@pytest.mark.parametrize("cls_name,d,factorised,half", [("InteractionNet", 256, True, 1), ("InteractionNet", 256, False, 0), ("PropagationNet", 256, False, 3),
+                                                        ("InteractionNet", 512, True, 1), ("InteractionNet", 512, False, 0), ("InteractionNet", 384, True, 0)])
+def test_bf16_storage_of_saved_tensors_under_autocast(dev, cls_name, d, factorised, half):
+    """NLAM_F_STORE_BF16: inside torch.autocast(bfloat16) the one-term wide kernels keep z1, xhat, dz1 and dz2 as bf16 rows
+    (what --precision bf16-mixed makes of the reference's nn.Linear outputs and their gradients, train_model.py:163-168).
+    Against the same launches with fp32 storage: the forward is bit-identical (only what is SAVED changes), every gradient
+    agrees to bf16 rounding of the saved tensors (max-norm 2e-2, cosine > 0.9995); against the fp32 oracle the autocast
+    tolerance 3e-2 holds.  Plain and factorised edge MLP (the sender gradient is a segment sum over bf16 dz1 rows), 8-wave and
+    4-wave instantiations, a batch, an edge set of several super tiles per workgroup."""
+    from neural_lam_amd import _lib as L
+    from neural_lam_amd import ops
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    lib = L.load()
+    ns, nr, e, B = 301, 257, 9001, 2
+    ei = _rand_ei(ns, nr, e, seed=13)
+    torch.manual_seed(13)
+    ref = getattr(og, cls_name)(ei, d)
+    send, rec, edge = torch.randn(B, ns, d), torch.randn(B, nr, d), torch.randn(B, e, d)
+    old = (hl.FACTORISE_MIN_EDGES_WIDE, hl.FACTORISE_MIN_WORK_WIDE, hl.FACTORISE_MIN_WIDTH_WIDE, ops.STORE_BF16)
+    res = {}
+    try:
+        assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 0) == 0 and lib.nlam_set_tuning(L.TUNE_WBF_HALF, half) == 0
+        hl.FACTORISE_MIN_WORK_WIDE, hl.FACTORISE_MIN_WIDTH_WIDE = 0, 0
+        hl.FACTORISE_MIN_EDGES_WIDE = 0 if factorised else 1 << 30
+        for store in (False, True):
+            ops.STORE_BF16 = store
+            net = getattr(hl, cls_name)(ei, d)
+            net.load_state_dict(ref.state_dict())
+            net.to(dev)
+            args = [t.to(dev).requires_grad_() for t in (send, rec, edge)]
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = net(*args)
+                loss = sum(o.float().square().sum() for o in out)
+            loss.backward()
+            res[store] = ([o.detach() for o in out], [a.grad for a in args], {k: p.grad for k, p in net.named_parameters()})
+    finally:
+        hl.FACTORISE_MIN_EDGES_WIDE, hl.FACTORISE_MIN_WORK_WIDE, hl.FACTORISE_MIN_WIDTH_WIDE, ops.STORE_BF16 = old
+        assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0 and lib.nlam_set_tuning(L.TUNE_WBF_HALF, 1) == 0
+
+    def cos(a, b):
+        a, b = a.double().reshape(-1), b.double().reshape(-1)
+        return float((a @ b) / (a.norm() * b.norm()).clamp(min=1e-30))
+
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    for tag, a, b in [("d_in", x, y) for x, y in zip(res[True][1], res[False][1])] + [(k, res[True][2][k], res[False][2][k]) for k in res[True][2]]:
+        assert rel_err(a.cpu(), b.cpu()) < 2e-2 and cos(a, b) > 0.9995, (tag, rel_err(a.cpu(), b.cpu()), cos(a, b))
+    s1, r1, e1 = (t.clone().requires_grad_() for t in (send, rec, edge))
+    o1 = ref(s1, r1, e1)
+    sum(o.square().sum() for o in o1).backward()
+    for a, b in zip(res[True][0], o1):
+        assert rel_err(a.cpu(), b.detach()) < 3e-2
+    for a, b in zip(res[True][1], (s1.grad, r1.grad, e1.grad)):
+        assert rel_err(a.cpu(), b) < 3e-2
+
+
+def test_segment_sum_over_bf16_rows(dev):
+    """nlam_segment_sum_bf16 (sender gradient of a factorised edge MLP running with bf16 storage) against index_add in fp64."""
+    import ctypes as C
+
+    from neural_lam_amd import _lib as L
+
+    g = torch.Generator().manual_seed(4)
+    B, rows, nseg, width = 2, 5000, 300, 256
+    lens = torch.randint(0, 34, (nseg,), generator=g)
+    lens[7] = 0
+    lens = (lens.double() * (rows / float(lens.sum()))).floor().long()
+    lens[-1] += rows - int(lens.sum())
+    ptr = torch.zeros(nseg + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(lens, 0)
+    order = torch.randperm(rows, generator=g).to(torch.int32)
+    x = torch.randn(B, rows, width, generator=g).bfloat16()
+    seg_of_pos = torch.repeat_interleave(torch.arange(nseg), lens)
+    ref = torch.zeros(B, nseg, width, dtype=torch.float64).index_add_(1, seg_of_pos, x[:, order.long()].double())
+    xd, pd, od, out = x.to(dev), ptr.to(dev), order.to(dev), torch.empty(B, nseg, width, device=dev)   # (named: temporaries would be freed before the launch)
+    rc = L.load().nlam_segment_sum_bf16(xd.data_ptr(), rows * width, pd.data_ptr(), od.data_ptr(), None, out.data_ptr(),
+                                        nseg, width, B, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    assert rel_err(out.cpu().double(), ref) < 1e-5
+
+
 @pytest.mark.parametrize("d", [64, 128])
 def test_autocast_region_uses_bf16_operands(dev, d, wide_family):
     """Lightning ``--precision bf16-mixed`` wraps the step in torch.autocast: the fused MLPs then take plain bf16
