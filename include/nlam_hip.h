@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define NLAM_ABI_VERSION 4
+#define NLAM_ABI_VERSION 5
 #define NLAM_MAX_SRC 3
 #define NLAM_MAX_CAT 6
 

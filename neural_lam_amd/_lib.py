@@ -290,7 +290,7 @@ class PackRec(C.Structure):
     _fields_ = [("bytes", C.c_ubyte * 64)]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

@@ -1,8 +1,16 @@
-./tools/probes/bf16_block_probe
-timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -k "bf16_storage or over_bf16_rows" > gpurun_out/t8.log 2>&1; grep -n "passed\|failed\|Error\|assert " gpurun_out/t8.log | head -30
-timeout 900 python -m pytest tests/test_full_size_parity.py -m gpu -x -q -s -k "cfg5" > gpurun_out/t7.log 2>&1; grep "cfg5 (T\|passed\|failed\|Error" gpurun_out/t7.log
-for sb in 0 1; do NLAM_STORE_BF16=$sb NLAM_KB_AUTOCAST=1 python tools/kernel_bench.py m2m 12 512 edge 2>&1 | grep -v amdgpu | sed "s/^/[store_bf16=$sb] /"; done
-for rep in 1 2; do for sb in 0 1; do NLAM_STORE_BF16=$sb python bench.py --config cfg5 --precision bf16 --steps 4 --warmup 2 --no-cpu-baseline --no-gpu-baseline --no-roofline --no-data-path 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('store_bf16=$sb cfg5', round(d['ms_per_step'],3), 'ms/step', round(d['forecast_steps_per_s'],1), 'forecast steps/s', 'loss', d['final_loss'])"; done; done
-for sb in 0 1; do NLAM_STORE_BF16=$sb python bench.py --config cfg3 --precision bf16 --steps 12 --warmup 2 --no-cpu-baseline --no-gpu-baseline --no-roofline --no-data-path 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('store_bf16=$sb cfg3-bf16', round(d['ms_per_step'],3), 'ms/step', round(d['forecast_steps_per_s'],1), 'forecast steps/s', 'loss', d['final_loss'])"; done
+mkdir -p gpurun_out/r4
+python bench.py --config cfg5 --precision bf16 --steps 4 --warmup 2 --no-data-path > gpurun_out/r4/bench_cfg5_bf16.json 2> gpurun_out/r4/bench_cfg5.err
+python bench.py --config cfg3 --steps 12 --warmup 2 --no-data-path > gpurun_out/r4/bench_cfg3.json 2> gpurun_out/r4/bench_cfg3.err
+python bench.py --config cfg4 --steps 30 --warmup 3 --no-data-path > gpurun_out/r4/bench_cfg4.json 2> gpurun_out/r4/bench_cfg4.err
+tail -2 gpurun_out/r4/*.err
+python - <<'PY'
+import json
+for f in ["bench_cfg5_bf16","bench_cfg3","bench_cfg4"]:
+    try:
+        d=json.load(open("gpurun_out/r4/"+f+".json"))
+    except Exception as e:
+        print(f, "unreadable", e); continue
+    print(f, round(d["ms_per_step"],2), "ms", "cpu", d.get("cpu_baseline",{}).get("ms_per_step"), "gpu_ref", {k:v for k,v in d.get("gpu_reference_equivalent",{}).items() if "ms_per" in k or "speedup" in k})
+    for k in d["roofline"]["kernels"]:
+        print("   %-40s n=%3d avg %.3f ms tot %.2f share %.3f mfma %.3f hbm %.3f"%(k["launch"],k["launches"],k["avg_launch_ms"],k["total_ms"],k["share_of_step"],k["mfma_frac"],k["hbm_frac"]))
+PY
