@@ -4449,7 +4449,9 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
             }
             const size_t lds = fwd_wbf_lds(p, wns, pl);
             const long nsuper = (long)((p->ntiles + pl.nrt - 1) / pl.nrt) * p->batch;
-            const long wcap = pl.nw == 4 ? 2 * kNumCUs : kNumCUs;   // one 8-wave workgroup per CU, or two of 4 waves
+            // one 8-wave workgroup per CU, or two of 4 waves (ONE 4-wave workgroup per CU, leaving half of every CU to the
+            // weight-gradient kernels of the side streams, measured 20 % slower in the captured cfg3 step: 59.8 vs 49.4 ms)
+            const long wcap = pl.nw == 4 ? 2 * kNumCUs : kNumCUs;
             const int wblocks = (int)(nsuper < wcap ? (nsuper < 1 ? 1 : nsuper) : wcap);
 #define NLAM_LAUNCH_FWD_WBF(NS_, NW_, FG_, FB_, RT_, RTP_)                                                                    \
     do {                                                                                                                      \
