@@ -49,6 +49,9 @@ FACTORISE_MIN_WORK_WIDE = int(os.environ.get("NLAM_FACTORISE_MIN_WORK_WIDE", "14
 FACTORISE_MIN_WIDTH_WIDE = int(os.environ.get("NLAM_FACTORISE_MIN_WIDTH_WIDE", "256"))
 
 
+PAD_EMBEDDER_MIN_WIDTH = int(os.environ.get("NLAM_PAD_EMBEDDER_MIN_WIDTH", "256"))
+
+
 _DEVICE_LAYOUTS: dict = {}   # (id of the host EdgeCSR, device) -> device EdgeCSR (+ tiles): shared by every layer built on that edge set
 
 
@@ -104,6 +107,7 @@ class FusedMLP(nn.Sequential):
         self.hidden_layers = hidden_layers
         self._geom = MlpGeometry(nsrc=1)
         self._geom_noact = MlpGeometry(nsrc=1, flags=L.F_NO_ACT)
+        self._geom_padded = MlpGeometry(nsrc=1, no_pack=True)
 
     @property
     def fully_fused(self) -> bool:
@@ -125,9 +129,39 @@ class FusedMLP(nn.Sequential):
         if not x.is_cuda:
             raise RuntimeError("neural_lam_amd layers run on MI355X only (no CPU / eager fallback; see oracle/ for a CPU reference)")
         leaf_input = not x.requires_grad
+        lin0 = self[0]
+        if (self.hidden_layers == 1 and leaf_input and x.shape[-1] % 4 != 0 and x.dtype == torch.float32
+                and max(lin0.out_features, self[2].out_features) > PAD_EMBEDDER_MIN_WIDTH):
+            # A WIDE embedder of a few static feature columns (edge features [len, dx, dy], mesh coordinates: 2 - 3 columns,
+            # graph/base.py:286-295): the split-bf16 super-tile kernels read their inputs as 16-byte pieces, so a width that is
+            # not a multiple of 4 fell to the fp32 one-tile kernels (at d = 512 the <8,2> instantiation: 2.0 ms per launch at
+            # 255 136 rows, 8.1 ms = 5 % of the cfg5 step for the four embedders).  The input gets zero columns up to the next
+            # multiple of 4 (cached: the features are static) and the first weight matrix matching zero columns.  From d > 256
+            # only: the padded first weight is not a trainer-owned gradient view, so this MLP's weight-gradient launches stay on the
+            # backward stream -- at d = 128 / 256, where the fp32 kernels are not pathological, that cost more than the kernels
+            # gained (cfg4 11.57 -> 11.93 ms, cfg3 48.5 -> 49.0; cfg5 152.8 -> 146.4 ms, forecast 170 -> 201 steps/s).
+            out, _ = FusedMLPFunction.apply(self._geom_padded, _PadWeight.apply(lin0.weight, self._padded_weight(lin0.weight)), lin0.bias,
+                                            self[2].weight, self[2].bias, *self._ln(), self._padded_input(x))
+            return ops.early_backward_leaf(out)
         out, _ = self.forward_fused(self._geom, x)
         # an MLP of input data / static features: nothing upstream needs its data gradient (ops.early_backward_leaf)
         return ops.early_backward_leaf(out) if leaf_input else out
+
+    _xpad = None
+    _wpad = None
+
+    def _padded_input(self, x):
+        key = (x.data_ptr(), tuple(x.shape), x._version)
+        if self._xpad is None or self._xpad[0] != key:
+            self._xpad = (key, torch.nn.functional.pad(x.detach(), (0, -x.shape[-1] % 4)).contiguous())
+        return self._xpad[1]
+
+    def _padded_weight(self, W):
+        """Persistent (hid, padded width) buffer: its address is what the weight packer keys on."""
+        kp = W.shape[1] + (-W.shape[1] % 4)
+        if self._wpad is None or self._wpad.device != W.device or tuple(self._wpad.shape) != (W.shape[0], kp):
+            self._wpad = torch.zeros((W.shape[0], kp), device=W.device, dtype=W.dtype)
+        return self._wpad
 
     def forward_fused(self, geom: MlpGeometry, *srcs):
         """Run with a caller-supplied geometry (gathered / concatenated sources, residuals, aggregation) -> (out, aggr)."""
@@ -154,6 +188,21 @@ class FusedMLP(nn.Sequential):
         if res_srcs:   # the residual sources ride along as inputs with zero weight columns
             W1 = torch.cat([W1.new_zeros(W1.shape[0], sum(t.shape[-1] for t in res_srcs)), W1], dim=1)
         return FusedMLPFunction.apply(last, W1, lin[n - 2].bias, lin[n - 1].weight, lin[n - 1].bias, *self._ln(), *res_srcs, a)
+
+
+class _PadWeight(torch.autograd.Function):
+    """``W`` (hid, k) copied into the leading columns of a persistent zero-padded buffer (hid, k') -> that buffer; the gradient
+    is the leading (hid, k) block of the buffer's gradient.  The copy is a (hid x k) elementwise launch per step."""
+
+    @staticmethod
+    def forward(ctx, W, buf):
+        buf[:, : W.shape[1]].copy_(W.detach())
+        ctx.k = W.shape[1]
+        return buf.view_as(buf)   # a fresh view: the buffer itself stays a plain tensor without history
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g[:, : ctx.k].contiguous() if g is not None else None), None
 
 
 def _with_flags(geom: MlpGeometry, flags: int) -> MlpGeometry:
@@ -201,8 +250,9 @@ def grouped_mlp_forward(pairs):
     """``[mlp(x) for mlp, x in pairs]`` for independent MLPs of data inputs (static feature embedders), as grouped launches of
     up to 8 members (ops.GroupedMLPFunction) where the members are one-kernel MLPs of the same shape on GPU tensors."""
     def ok(m, x):
+        # (wide members have no grouped kernel: they run one by one, through FusedMLP.forward and its input padding)
         return (isinstance(m, FusedMLP) and m.fully_fused and x.is_cuda and x.dim() == 2 and not x.requires_grad
-                and x.dtype == torch.float32)
+                and x.dtype == torch.float32 and max(m[0].out_features, m[2].out_features) <= PAD_EMBEDDER_MIN_WIDTH)
 
     outs = [None] * len(pairs)
     classes = {}

@@ -419,6 +419,9 @@ class MlpGeometry:
     # then the extended arrays; nseg_total stays the number of REAL receivers.
     nseg_ext: int = 0
     comb: tuple | None = None
+    # weights that are rewritten DURING the step (a padded copy made in forward): the trainer's once-per-step weight images would
+    # be a step stale -- such a launch packs its weights itself
+    no_pack: bool = False
 
 
 def split_combine(buf, geom):
@@ -529,7 +532,7 @@ class FusedMLPFunction(torch.autograd.Function):
         pack = None
         if nwp > 0:  # wide kernels: the weights in MFMA A-operand order -- packed once per step under a trainer, else scratch the launch fills
             wbuf = None
-            if PACKER is not None:
+            if PACKER is not None and not geom.no_pack:
                 wbuf = PACKER.get_wide("f", p, nwp, ("f", W1c.data_ptr(), W2c.data_ptr(), tuple(widths), hid, dout, int(p.flags) & ~L.F_STORE_BF16, int(p.ldw1),
                                                       rows, ntiles, B))
             if wbuf is not None:
@@ -537,7 +540,7 @@ class FusedMLPFunction(torch.autograd.Function):
             else:
                 wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
                 p.wpack, p.wpack_floats = _ptr(wpack), nwp
-        elif PACKER is not None and mm_flags != 0:   # narrow split-bf16 kernels under a trainer: the image packed once for this step
+        elif PACKER is not None and mm_flags != 0 and not geom.no_pack:   # narrow split-bf16 kernels under a trainer: the image packed once for this step
             pack = PACKER.get(W1c, W2c, widths, hid, dout, pre, kin if pre else 0, mm_flags)
             if pack is not None:
                 p.wpack, p.wpack_floats = pack.fwd.data_ptr(), pack.fwd.numel()
@@ -670,7 +673,7 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     wpack = None
     if nwp > 0:
         wbuf = None
-        if PACKER is not None:
+        if PACKER is not None and not geom.no_pack:
             wbuf = PACKER.get_wide("b", p, nwp, ("b", W1.data_ptr(), W2.data_ptr(), tuple(widths), hid, dout, int(p.flags) & ~L.F_STORE_BF16, int(p.ldw1),
                                                   rows, ntiles, B, tuple(int(p.dmode[k]) for k in range(nsrc)), int(p.dz2_ld)))
         if wbuf is not None:

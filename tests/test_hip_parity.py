@@ -713,6 +713,45 @@ def test_bf16_storage_of_saved_tensors_under_autocast(dev, cls_name, d, factoris
         assert rel_err(a.cpu(), b) < 3e-2
 
 
+@pytest.mark.parametrize("kin,d,autocast", [(3, 256, False), (2, 512, True), (3, 128, False), (5, 512, False)])
+def test_wide_embedder_of_a_few_static_columns(dev, kin, d, autocast):
+    """The embedders of the static edge / mesh features at hidden widths above 64 (graph/base.py:286-295: [len, dx, dy] -> d):
+    the input is zero-padded to a multiple of 4 columns so that the launch takes the split-bf16 super-tile kernels instead of
+    the fp32 one-tile kernels; outputs and every parameter gradient (the first weight's through the padded copy) match the
+    oracle, with and without a trainer-style direct gradient buffer."""
+    import contextlib
+
+    from neural_lam_amd import _lib as L
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    old_min, hl.PAD_EMBEDDER_MIN_WIDTH = hl.PAD_EMBEDDER_MIN_WIDTH, 64   # (the product pads from d > 256)
+    torch.manual_seed(kin + d)
+    ref, net = og.make_mlp([kin, d, d]), hl.make_mlp([kin, d, d])
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    x = torch.randn(30011, kin)
+    y1 = ref(x)
+    c = torch.randn_like(y1)
+    (y1 * c).sum().backward()
+    tol = 3e-2 if autocast else TOL
+    try:
+        assert L.load().nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 0) == 0
+        amp = torch.autocast("cuda", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()
+        for _ in range(2):   # the second pass re-uses the cached padded input and the persistent padded weight
+            net.zero_grad()
+            with amp:
+                y2 = net(x.to(dev))
+            (y2.float() * c.to(dev)).sum().backward()
+            assert rel_err(y2.float().cpu(), y1.detach()) < tol
+            for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+                assert p.grad is not None and rel_err(p.grad.cpu(), q.grad) < tol, k
+    finally:
+        assert L.load().nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
+        hl.PAD_EMBEDDER_MIN_WIDTH = old_min
+    assert net._xpad is not None and net._xpad[1].shape[-1] % 4 == 0
+
+
 def test_segment_sum_over_bf16_rows(dev):
     """nlam_segment_sum_bf16 (sender gradient of a factorised edge MLP running with bf16 storage) against index_add in fp64."""
     import ctypes as C
