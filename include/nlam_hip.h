@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define NLAM_ABI_VERSION 5
+#define NLAM_ABI_VERSION 6
 #define NLAM_MAX_SRC 3
 #define NLAM_MAX_CAT 6
 
@@ -331,6 +331,16 @@ int32_t nlam_mlp_pack(const nlam_pack_job_t* jobs_device, int32_t njobs, void* h
 int32_t nlam_mlp_group_blocks(const int64_t* tiles, int32_t n, int32_t* blocks);
 int32_t nlam_mlp_fwd_group(const nlam_mlp_fwd_t* ps, int32_t n, void* hip_stream);
 int32_t nlam_mlp_bwd_group(const nlam_mlp_bwd_t* ps, int32_t n, void* hip_stream);
+/* Round 4: the grouped entry points also take members of the fp32 WIDE family (a width in 65 .. 128 columns below the
+ * split-bf16 super-tile threshold, or matrix mode 0): the chunks of a `SplitMLPs` layer (gnn_layers.py:274-324 called from
+ * hi_lam_parallel.py:127-143 -- 3 .. 206 tiles each at the bench size), any source / residual / aggregation set the single
+ * launch takes, one shape (hid, dout, source widths, flags, dmode, LayerNorm) for all members.  nlam_mlp_*_family says which
+ * kernel family a launch runs on (0 narrow, 1 fp32 wide, 2 split-bf16 wide: members of family 2 are launched one by one);
+ * nlam_mlp_bwd_group_blocks gives the workgroups (= vec_partials rows written) per member of a grouped backward of either
+ * family, checking the members as the launch would. */
+int32_t nlam_mlp_fwd_family(const nlam_mlp_fwd_t* p);
+int32_t nlam_mlp_bwd_family(const nlam_mlp_bwd_t* p);
+int32_t nlam_mlp_bwd_group_blocks(const nlam_mlp_bwd_t* ps, int32_t n, int32_t* blocks);
 int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream);
 
 /* out[b, s, :] = scale(s) * sum_{q in [ptr[s], ptr[s+1])} in[b, order[q], :]   (order NULL = q) */

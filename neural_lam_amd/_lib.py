@@ -63,6 +63,9 @@ EXPORTS = [
     "nlam_mlp_group_blocks",
     "nlam_mlp_fwd_group",
     "nlam_mlp_bwd_group",
+    "nlam_mlp_fwd_family",
+    "nlam_mlp_bwd_family",
+    "nlam_mlp_bwd_group_blocks",
     "nlam_linear",
     "nlam_pre_add_supported",
     "nlam_step_tail_fwd",
@@ -290,7 +293,7 @@ class PackRec(C.Structure):
     _fields_ = [("bytes", C.c_ubyte * 64)]
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 
@@ -389,6 +392,12 @@ def load():
     lib.nlam_mlp_fwd_group.restype = i32
     lib.nlam_mlp_bwd_group.argtypes = [C.POINTER(MlpBwd), i32, vp]
     lib.nlam_mlp_bwd_group.restype = i32
+    lib.nlam_mlp_fwd_family.argtypes = [C.POINTER(MlpFwd)]
+    lib.nlam_mlp_fwd_family.restype = i32
+    lib.nlam_mlp_bwd_family.argtypes = [C.POINTER(MlpBwd)]
+    lib.nlam_mlp_bwd_family.restype = i32
+    lib.nlam_mlp_bwd_group_blocks.argtypes = [C.POINTER(MlpBwd), i32, C.POINTER(i32)]
+    lib.nlam_mlp_bwd_group_blocks.restype = i32
     lib.nlam_pre_add_supported.argtypes = [C.POINTER(MlpFwd)]
     lib.nlam_pre_add_supported.restype = i32
     lib.nlam_linear.argtypes = [C.POINTER(Linear), vp]

@@ -85,6 +85,10 @@ int32_t bwd_narrow(const nlam_mlp_bwd_t* p, hipStream_t stream);   // slice 2
 int32_t wgrad_narrow(const nlam_wgrad_t* p, hipStream_t stream);   // slice 2
 int32_t fwd_wide(const nlam_mlp_fwd_t* p, hipStream_t stream);     // slice 3
 int32_t bwd_wide(const nlam_mlp_bwd_t* p, hipStream_t stream);     // slice 3
+int32_t fwd_wide_group(const nlam_mlp_fwd_t* ps, int n, hipStream_t stream);   // slice 3
+int32_t bwd_wide_group(const nlam_mlp_bwd_t* ps, int n, hipStream_t stream);   // slice 3
+int32_t fwd_check(const nlam_mlp_fwd_t* p);                        // argument checks of nlam_mlp_fwd (slice 1)
+int32_t bwd_check(const nlam_mlp_bwd_t* p);                        // argument checks of nlam_mlp_bwd (slice 1)
 int32_t wgrad_wide(const nlam_wgrad_t* p, hipStream_t stream);     // slice 3
 int32_t fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream);      // slice 4
 int32_t bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream);      // slice 4
@@ -3986,6 +3990,35 @@ void group_blocks(const long* tiles, int n, int* blocks) {
     }
 }
 
+// members of one grouped wide launch run one kernel instantiation with one LDS layout
+bool same_fwd_shape(const nlam_mlp_fwd_t& a, const nlam_mlp_fwd_t& b) {
+    if (a.hid != b.hid || a.dout != b.dout || a.nsrc != b.nsrc || a.ncat != b.ncat) return false;
+    if ((a.flags & ~NLAM_F_WPACK_READY) != (b.flags & ~NLAM_F_WPACK_READY) || (a.ln_w == nullptr) != (b.ln_w == nullptr)) return false;
+    for (int s = 0; s < a.nsrc; ++s)
+        if (a.src[s].width != b.src[s].width) return false;
+    return true;
+}
+bool same_bwd_shape(const nlam_mlp_bwd_t& a, const nlam_mlp_bwd_t& b) {
+    if (a.hid != b.hid || a.dout != b.dout || a.nsrc != b.nsrc) return false;
+    if ((a.flags & ~NLAM_F_WPACK_READY) != (b.flags & ~NLAM_F_WPACK_READY) || (a.ln_w == nullptr) != (b.ln_w == nullptr)) return false;
+    for (int s = 0; s < a.nsrc; ++s)
+        if (a.src[s].width != b.src[s].width || a.dmode[s] != b.dmode[s]) return false;
+    return true;
+}
+
+// the same for the fp32 wide kernels: `cap` = the workgroups one launch keeps resident (wide_grid)
+void wide_group_blocks(const long* tiles, int n, long cap, int* blocks) {
+    long tot = 0;
+    for (int k = 0; k < n; ++k) tot += tiles[k] < 1 ? 1 : tiles[k];
+    for (int k = 0; k < n; ++k) {
+        const long t = tiles[k] < 1 ? 1 : tiles[k];
+        long b = tot <= cap ? t : (t * cap) / tot;
+        if (b < 1) b = 1;
+        if (b > t) b = t;
+        blocks[k] = (int)b;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // pack jobs of the wide launches (weights -> MFMA A-fragment order in `wpack`): built here so that the launchers (slices 3 / 4)
 // and the pre-pack API (nlam_mlp_*_pack_records, slice 1) describe one launch's scratch identically.
@@ -4331,6 +4364,44 @@ int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p) {
     return wide_grid(total, bwd_wide_lds(p, cfg.nwv), cfg.nwv);
 }
 
+// which kernel family a launch described by `p` runs on: 0 = narrow, 1 = fp32 wide, 2 = split-bf16 wide super-tiles.
+// Grouped launches take members of one family (0: nlam_mlp_*_group's narrow kernels, 1: the wide group kernels).
+int32_t nlam_mlp_fwd_family(const nlam_mlp_fwd_t* p) {
+    if (p == nullptr) return NLAM_EINVAL;
+    if (!fwd_is_wide(p)) return 0;
+    return fwd_wbf_ns(p) > 0 ? 2 : 1;
+}
+
+int32_t nlam_mlp_bwd_family(const nlam_mlp_bwd_t* p) {
+    if (p == nullptr) return NLAM_EINVAL;
+    if (!bwd_is_wide(p)) return 0;
+    return bwd_wbf_ns(p) > 0 ? 2 : 1;
+}
+
+// workgroups (= rows of `vec_partials` written) per member of a grouped backward launch
+int32_t nlam_mlp_bwd_group_blocks(const nlam_mlp_bwd_t* ps, int32_t n, int32_t* blocks) {
+    if (ps == nullptr || blocks == nullptr || n < 1 || n > NLAM_MAX_GROUP) return NLAM_EINVAL;
+    long tiles[NLAM_MAX_GROUP];
+    for (int k = 0; k < n; ++k) tiles[k] = (long)ps[k].ntiles * ps[k].batch;
+    if (!bwd_is_wide(&ps[0])) {
+        group_blocks(tiles, n, blocks);
+        return 0;
+    }
+    size_t lds = 0;
+    const WideCfg cfg = wide_cfg(bwd_wide_maxw(&ps[0]));
+    for (int k = 0; k < n; ++k) {
+        const nlam_mlp_bwd_t& p = ps[k];
+        const int32_t bad = nlam_detail::bwd_check(&p);
+        if (bad != 0) return bad;
+        if (p.rows < 1) return NLAM_EINVAL;
+        if (nlam_mlp_bwd_family(&p) != 1 || !same_bwd_shape(p, ps[0])) return NLAM_EUNSUP;
+        const size_t l = bwd_wide_lds(&p, cfg.nwv);
+        if (l > lds) lds = l;
+    }
+    wide_group_blocks(tiles, n, wide_grid(1L << 40, lds, cfg.nwv), blocks);
+    return 0;
+}
+
 int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     if (p == nullptr) return 0;
     const long total_chunks = (long)p->batch * ((p->rows + kWgradRows - 1) / kWgradRows);
@@ -4396,35 +4467,11 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
 
 int32_t nlam_mlp_fwd(const nlam_mlp_fwd_t* p, void* hip_stream) {
     NLAM_RANGE("nlam_mlp_fwd");
-    if (p == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
-    if (p->batch < 1 || p->rows < 0 || p->hid < 1 || p->dout < 1) return NLAM_EINVAL;
-    if (p->aggr != nullptr && (p->rowptr == nullptr || p->tiles == nullptr)) return NLAM_EINVAL;
-    if ((p->flags & NLAM_F_MEAN) && p->inv_deg == nullptr) return NLAM_EINVAL;
-    if ((p->flags & NLAM_F_ADD_SRC0) && p->src[0].width != p->dout) return NLAM_EINVAL;
-    if ((p->flags & NLAM_F_ADD_SRC1) && (p->nsrc < 2 || p->src[1].width != p->dout)) return NLAM_EINVAL;
-    if ((p->flags & NLAM_F_NO_ACT) && ((p->flags & (NLAM_F_MM_MASK | NLAM_F_PRE_ADD)) != 0 || p->ncat != 0)) return NLAM_EUNSUP;
-    if ((p->flags & NLAM_F_STORE_BF16) && !store_bf16_ok(p)) return NLAM_EUNSUP;
-    if (p->ncat != 0) {   // src[0] = concatenation of pieces: one un-gathered source of <= 64 columns, whole float4s per row
-        if (p->ncat < 0 || p->ncat > NLAM_MAX_CAT || p->nsrc != 1 || p->src[0].idx != nullptr) return NLAM_EINVAL;
-        int wsum = 0;
-        for (int k = 0; k < p->ncat; ++k) {
-            if (p->cat_ptr[k] == nullptr || p->cat_width[k] < 1) return NLAM_EINVAL;
-            wsum += p->cat_width[k];
-        }
-        if (wsum != p->src[0].width) return NLAM_EINVAL;
-        if (fwd_is_wide(p) || wsum % 4 != 0 || (p->flags & (NLAM_F_ADD_SRC0 | NLAM_F_ADD_SRC1 | NLAM_F_PRE_ADD)) != 0 || p->tiles != nullptr)
-            return NLAM_EUNSUP;
-        if (p->ncat > 4) return NLAM_EUNSUP;   // the kernel resolves a column among four pieces
-        if (p->rows > 0 && p->batch > 0 && ((long)p->rows >= (1L << 31) || p->batch >= (1 << 30))) return NLAM_EUNSUP;
-    }
+    const int32_t bad = nlam_detail::fwd_check(p);
+    if (bad != 0) return bad;
     if (p->rows == 0) return 0;
     hipStream_t stream = (hipStream_t)hip_stream;
     if (fwd_is_wide(p)) {
-        if ((p->flags & NLAM_F_PRE_ADD) && fwd_wbf_ns(p) == 0) return NLAM_EUNSUP;   // the fp32 wide kernels have no factorised variant
-        const WideCfg cfg = wide_cfg(p->hid > p->dout ? p->hid : p->dout);
-        if (cfg.nwv == 0) return NLAM_EUNSUP;
-        const int64_t need = nlam_mlp_fwd_wpack_floats(p);
-        if (p->wpack == nullptr || p->wpack_floats < need) return NLAM_EINVAL;
         if (fwd_wbf_ns(p) > 0) return nlam_detail::fwd_wbf(p, stream);   // split-bf16 matrix path (nlam_wbf.inc)
         return nlam_detail::fwd_wide(p, stream);
     }
@@ -4594,11 +4641,41 @@ int32_t nlam_detail::fwd_narrow(const nlam_mlp_fwd_t* p, hipStream_t stream) {
 #endif
 
 #if NLAM_IN_TU(1)
-extern "C" {
+// the argument checks of nlam_mlp_fwd / nlam_mlp_bwd, shared with the grouped entry points
+int32_t nlam_detail::fwd_check(const nlam_mlp_fwd_t* p) {
+    if (p == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
+    if (p->batch < 1 || p->rows < 0 || p->hid < 1 || p->dout < 1) return NLAM_EINVAL;
+    if (p->aggr != nullptr && (p->rowptr == nullptr || p->tiles == nullptr)) return NLAM_EINVAL;
+    if ((p->flags & NLAM_F_MEAN) && p->inv_deg == nullptr) return NLAM_EINVAL;
+    if ((p->flags & NLAM_F_ADD_SRC0) && p->src[0].width != p->dout) return NLAM_EINVAL;
+    if ((p->flags & NLAM_F_ADD_SRC1) && (p->nsrc < 2 || p->src[1].width != p->dout)) return NLAM_EINVAL;
+    if ((p->flags & NLAM_F_NO_ACT) && ((p->flags & (NLAM_F_MM_MASK | NLAM_F_PRE_ADD)) != 0 || p->ncat != 0)) return NLAM_EUNSUP;
+    if ((p->flags & NLAM_F_STORE_BF16) && !store_bf16_ok(p)) return NLAM_EUNSUP;
+    if (p->ncat != 0) {   // src[0] = concatenation of pieces: one un-gathered source of <= 64 columns, whole float4s per row
+        if (p->ncat < 0 || p->ncat > NLAM_MAX_CAT || p->nsrc != 1 || p->src[0].idx != nullptr) return NLAM_EINVAL;
+        int wsum = 0;
+        for (int k = 0; k < p->ncat; ++k) {
+            if (p->cat_ptr[k] == nullptr || p->cat_width[k] < 1) return NLAM_EINVAL;
+            wsum += p->cat_width[k];
+        }
+        if (wsum != p->src[0].width) return NLAM_EINVAL;
+        if (fwd_is_wide(p) || wsum % 4 != 0 || (p->flags & (NLAM_F_ADD_SRC0 | NLAM_F_ADD_SRC1 | NLAM_F_PRE_ADD)) != 0 || p->tiles != nullptr)
+            return NLAM_EUNSUP;
+        if (p->ncat > 4) return NLAM_EUNSUP;   // the kernel resolves a column among four pieces
+        if (p->rows > 0 && p->batch > 0 && ((long)p->rows >= (1L << 31) || p->batch >= (1 << 30))) return NLAM_EUNSUP;
+    }
+    if (p->rows == 0) return 0;
+    if (fwd_is_wide(p)) {
+        if ((p->flags & NLAM_F_PRE_ADD) && fwd_wbf_ns(p) == 0) return NLAM_EUNSUP;   // the fp32 wide kernels have no factorised variant
+        const WideCfg cfg = wide_cfg(p->hid > p->dout ? p->hid : p->dout);
+        if (cfg.nwv == 0) return NLAM_EUNSUP;
+        const int64_t need = nlam_mlp_fwd_wpack_floats(p);
+        if (p->wpack == nullptr || p->wpack_floats < need) return NLAM_EINVAL;
+    }
+    return 0;
+}
 
-
-int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
-    NLAM_RANGE("nlam_mlp_bwd");
+int32_t nlam_detail::bwd_check(const nlam_mlp_bwd_t* p) {
     if (p == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC || p->W1 == nullptr || p->W2 == nullptr) return NLAM_EINVAL;
     if (p->z1 == nullptr) return NLAM_EINVAL;
     if (p->ln_w != nullptr && (p->xhat == nullptr || p->rstd == nullptr)) return NLAM_EINVAL;
@@ -4616,7 +4693,6 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
     if ((p->flags & NLAM_F_NO_ACT) && (p->flags & (NLAM_F_MM_MASK | NLAM_F_PRE_ADD | NLAM_F_LEAF_WGRAD)) != 0) return NLAM_EUNSUP;
     if ((p->flags & NLAM_F_STORE_BF16) && !(bwd_is_wide(p) && bwd_wbf_ns(p) == 1)) return NLAM_EUNSUP;
     if (p->rows == 0) return 0;
-    hipStream_t stream = (hipStream_t)hip_stream;
     if (bwd_is_wide(p) && (p->flags & NLAM_F_PRE_ADD) && bwd_wbf_ns(p) == 0) return NLAM_EUNSUP;
     if (bwd_is_wide(p)) {
         const WideCfg cfg = wide_cfg(bwd_wide_maxw(p));
@@ -4624,6 +4700,22 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
         const int64_t need = nlam_mlp_bwd_wpack_floats(p);
         if (p->wpack == nullptr || p->wpack_floats < need) return NLAM_EINVAL;
         if (p->dz2_ld != nlam_mlp_bwd_dz2_ld(p)) return NLAM_EINVAL;   // the caller sized dz2 with nlam_mlp_bwd_dz2_ld
+    }
+    return 0;
+}
+#endif
+
+#if NLAM_IN_TU(1)
+extern "C" {
+
+
+int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
+    NLAM_RANGE("nlam_mlp_bwd");
+    const int32_t bad = nlam_detail::bwd_check(p);
+    if (bad != 0) return bad;
+    if (p->rows == 0) return 0;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (bwd_is_wide(p)) {
         if (bwd_wbf_ns(p) > 0) return nlam_detail::bwd_wbf(p, stream);   // split-bf16 matrix path (nlam_wbf.inc)
         return nlam_detail::bwd_wide(p, stream);
     }
@@ -4708,6 +4800,77 @@ int32_t nlam_detail::bwd_wide(const nlam_mlp_bwd_t* p, hipStream_t stream) {
 }
 #endif
 
+#if NLAM_IN_TU(3)
+// Grouped launches of the fp32 wide kernels (members checked by nlam_mlp_fwd_group / nlam_mlp_bwd_group: one shape, every one
+// of them this family).  Workgroups are dealt over the members in proportion to their tiles (wide_group_blocks).
+int32_t nlam_detail::fwd_wide_group(const nlam_mlp_fwd_t* ps, int n, hipStream_t stream) {
+    const WideCfg cfg = wide_cfg(ps[0].hid > ps[0].dout ? ps[0].hid : ps[0].dout);
+    fwd_wide_group_t G;
+    long tiles[NLAM_MAX_GROUP];
+    size_t lds = 0;
+    for (int k = 0; k < n; ++k) {
+        if ((ps[k].flags & NLAM_F_WPACK_READY) == 0) {
+            pack_jobs_t jobs;
+            build_fwd_wide_jobs(&ps[k], jobs);
+            launch_pack(jobs, stream);
+        }
+        G.g[k] = ps[k];
+        tiles[k] = (long)ps[k].ntiles * ps[k].batch;
+        const size_t l = fwd_wide_lds(&ps[k], cfg.nwv);
+        if (l > lds) lds = l;
+    }
+    int blocks[NLAM_MAX_GROUP];
+    wide_group_blocks(tiles, n, wide_grid(1L << 40, lds, cfg.nwv), blocks);
+    G.n = n;
+    G.first[0] = 0;
+    for (int k = 0; k < n; ++k) G.first[k + 1] = G.first[k] + blocks[k];
+    for (int k = n + 1; k <= NLAM_MAX_GROUP; ++k) G.first[k] = G.first[n];
+#define NLAM_LAUNCH_FWD_WIDE_G(NWV_, FB_)                                                                              \
+    do {                                                                                                               \
+        int rc = set_lds(mlp_fwd_wide_group_kernel<NWV_, FB_>, lds);                                                   \
+        if (rc != 0) return rc;                                                                                        \
+        hipLaunchKernelGGL((mlp_fwd_wide_group_kernel<NWV_, FB_>), dim3(G.first[n]), dim3(NWV_ * 64), lds, stream, G); \
+    } while (0)
+    if (cfg.nwv == 4) NLAM_LAUNCH_FWD_WIDE_G(4, 1);
+    else if (cfg.fb == 1) NLAM_LAUNCH_FWD_WIDE_G(8, 1);
+    else NLAM_LAUNCH_FWD_WIDE_G(8, 2);
+    return (int32_t)hipGetLastError();
+}
+
+int32_t nlam_detail::bwd_wide_group(const nlam_mlp_bwd_t* ps, int n, hipStream_t stream) {
+    const WideCfg cfg = wide_cfg(bwd_wide_maxw(&ps[0]));
+    bwd_wide_group_t G;
+    int blocks[NLAM_MAX_GROUP];
+    const int32_t rc0 = nlam_mlp_bwd_group_blocks(ps, n, blocks);
+    if (rc0 != 0) return rc0;
+    size_t lds = 0;
+    for (int k = 0; k < n; ++k) {
+        if ((ps[k].flags & NLAM_F_WPACK_READY) == 0) {
+            pack_jobs_t jobs;
+            build_bwd_wide_jobs(&ps[k], jobs);
+            launch_pack(jobs, stream);
+        }
+        G.g[k] = ps[k];
+        const size_t l = bwd_wide_lds(&ps[k], cfg.nwv);
+        if (l > lds) lds = l;
+    }
+    G.n = n;
+    G.first[0] = 0;
+    for (int k = 0; k < n; ++k) G.first[k + 1] = G.first[k] + blocks[k];
+    for (int k = n + 1; k <= NLAM_MAX_GROUP; ++k) G.first[k] = G.first[n];
+#define NLAM_LAUNCH_BWD_WIDE_G(NWV_, FB_)                                                                              \
+    do {                                                                                                               \
+        int rc = set_lds(mlp_bwd_wide_group_kernel<NWV_, FB_>, lds);                                                   \
+        if (rc != 0) return rc;                                                                                        \
+        hipLaunchKernelGGL((mlp_bwd_wide_group_kernel<NWV_, FB_>), dim3(G.first[n]), dim3(NWV_ * 64), lds, stream, G); \
+    } while (0)
+    if (cfg.nwv == 4) NLAM_LAUNCH_BWD_WIDE_G(4, 1);
+    else if (cfg.fb == 1) NLAM_LAUNCH_BWD_WIDE_G(8, 1);
+    else NLAM_LAUNCH_BWD_WIDE_G(8, 2);
+    return (int32_t)hipGetLastError();
+}
+#endif
+
 #if NLAM_IN_TU(1)
 extern "C" {
 
@@ -4722,6 +4885,16 @@ int32_t nlam_mlp_group_blocks(const int64_t* tiles, int32_t n, int32_t* blocks) 
 int32_t nlam_mlp_fwd_group(const nlam_mlp_fwd_t* ps, int32_t n, void* hip_stream) {
     NLAM_RANGE("nlam_mlp_fwd_group");
     if (ps == nullptr || n < 1 || n > NLAM_MAX_GROUP) return NLAM_EINVAL;
+    if (fwd_is_wide(&ps[0])) {   // members of the fp32 wide family (the chunks of a SplitMLPs layer at d = 128): any source / flag set, one shape
+        for (int k = 0; k < n; ++k) {
+            const nlam_mlp_fwd_t& p = ps[k];
+            const int32_t bad = nlam_detail::fwd_check(&p);
+            if (bad != 0) return bad;
+            if (p.rows < 1) return NLAM_EINVAL;
+            if (nlam_mlp_fwd_family(&p) != 1 || !same_fwd_shape(p, ps[0])) return NLAM_EUNSUP;
+        }
+        return nlam_detail::fwd_wide_group(ps, n, (hipStream_t)hip_stream);
+    }
     const int HB = (ps[0].hid + 31) / 32, OB = (ps[0].dout + 31) / 32;
     const int ns = (int)((ps[0].flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
     if (ns == 0 || HB != OB || HB > 2) return NLAM_EUNSUP;
@@ -4774,6 +4947,15 @@ int32_t nlam_mlp_fwd_group(const nlam_mlp_fwd_t* ps, int32_t n, void* hip_stream
 extern "C" int32_t nlam_mlp_bwd_group(const nlam_mlp_bwd_t* ps, int32_t n, void* hip_stream) {
     NLAM_RANGE("nlam_mlp_bwd_group");
     if (ps == nullptr || n < 1 || n > NLAM_MAX_GROUP) return NLAM_EINVAL;
+    if (bwd_is_wide(&ps[0])) {   // fp32 wide family: see nlam_mlp_fwd_group
+        if (ps[0].flags & NLAM_F_LEAF_WGRAD) return NLAM_EUNSUP;   // weight gradients inside the kernel: narrow members only
+        int blocks[NLAM_MAX_GROUP];
+        const int32_t rcb = nlam_mlp_bwd_group_blocks(ps, n, blocks);   // checks the members
+        if (rcb != 0) return rcb;
+        for (int k = 0; k < n; ++k)
+            if (ps[k].vec_partials != nullptr && ps[k].vec_partials_rows < blocks[k]) return NLAM_EINVAL;
+        return nlam_detail::bwd_wide_group(ps, n, (hipStream_t)hip_stream);
+    }
     const int HB = (ps[0].hid + 31) / 32, OB = (ps[0].dout + 31) / 32;
     const int ns = (int)((ps[0].flags & NLAM_F_MM_MASK) >> NLAM_F_MM_SHIFT);
     if (ns == 0 || HB != OB || HB > 2) return NLAM_EUNSUP;

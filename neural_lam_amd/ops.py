@@ -915,6 +915,7 @@ class ChunkedMLPFunction(torch.autograd.Function):
         out = torch.empty((B, R, dout), device=dev, dtype=torch.float32)
         saved = []
         keep = []
+        launches = []
         for c, (r0, r1) in enumerate(geom.chunks):
             W1, b1, W2, b2, ln_w, ln_b = params[c]
             rows = r1 - r0
@@ -947,10 +948,18 @@ class ChunkedMLPFunction(torch.autograd.Function):
                     p.xhat, p.rstd = _ptr(xhat), _ptr(rstd)
             nwp = lib.nlam_mlp_fwd_wpack_floats(C.byref(p))
             if nwp > 0:
-                wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
-                p.wpack, p.wpack_floats = _ptr(wpack), nwp
-            L.check(lib.nlam_mlp_fwd(C.byref(p), _stream()), "nlam_mlp_fwd (chunk)")
+                wbuf = None
+                if PACKER is not None:   # packed once per step with every other wide MLP of the model (nlam_pack_records)
+                    wbuf = PACKER.get_wide("f", p, nwp, ("cf", W1c.data_ptr(), W2c.data_ptr(), tuple(widths), hid, dout, int(p.flags), rows, B))
+                if wbuf is not None:
+                    p.wpack, p.wpack_floats, p.flags = wbuf.data_ptr(), nwp, int(p.flags) | L.F_WPACK_READY
+                else:
+                    wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+                    keep.append(wpack)
+                    p.wpack, p.wpack_floats = _ptr(wpack), nwp
+            launches.append(p)
             saved.append((z1, xhat, rstd))
+        _launch_chunks(lib, "fwd", launches)
         aggr = None
         if geom.rowptr is not None:
             aggr = segment_sum(out, R * dout, geom.rowptr, geom.perm, geom.inv_deg if geom.mean else None, geom.num_rec, dout, B)
@@ -998,13 +1007,12 @@ class ChunkedMLPFunction(torch.autograd.Function):
                 nr = nrows_src[k] if geom.src_mode[k] == "slice" else R
                 dbuf[k] = torch.empty((B, nr, widths[k]), device=dev, dtype=torch.float32)
         tmp_chunks = [[] for _ in range(nsrc)]   # B > 1: per-chunk (B, rows_c, w) buffers of gathered sources
-        grads_params = []
+        launches, work = [], []
         for c, (r0, r1) in enumerate(geom.chunks):
             W1, b1, W2, b2, ln_w, ln_b = params[c]
             rows = r1 - r0
             needs = [ctx.needs_input_grad[2 + 6 * c + q] for q in range(6)]
             if rows == 0:
-                grads_params.extend([torch.zeros_like(q) if (q is not None and nd) else None for q, nd in zip(params[c], needs)])
                 continue
             z1, xhat, rstd = ctx.saved_acts[c]
             W1c, W2c = W1.contiguous(), W2.contiguous()
@@ -1046,16 +1054,39 @@ class ChunkedMLPFunction(torch.autograd.Function):
                         p.dsrc[k], p.dsrc_bstride[k] = _ptr(tc), rows * widths[k]
             dz2, dpad = _alloc_dz2(lib, p, B * rows, dout, dev)
             nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
+            wpack = None
             if nwp > 0:
-                wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
-                p.wpack, p.wpack_floats = _ptr(wpack), nwp
+                wbuf = None
+                if PACKER is not None:
+                    wbuf = PACKER.get_wide("b", p, nwp, ("cb", W1c.data_ptr(), W2c.data_ptr(), tuple(widths), hid, dout, int(p.flags), rows, B,
+                                                          tuple(int(p.dmode[k]) for k in range(nsrc)), int(p.dz2_ld)))
+                if wbuf is not None:
+                    p.wpack, p.wpack_floats, p.flags = wbuf.data_ptr(), nwp, int(p.flags) | L.F_WPACK_READY
+                else:
+                    wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+                    p.wpack, p.wpack_floats = _ptr(wpack), nwp
             nblk = lib.nlam_mlp_bwd_blocks(C.byref(p))
             vs = _vec_stride(hid, dout)
             vecp = torch.empty((nblk, 4, vs), device=dev, dtype=torch.float32)
             p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(vecp), nblk, vs
-            L.check(lib.nlam_mlp_bwd(C.byref(p), _stream()), "nlam_mlp_bwd (chunk)")
-
-            # ---- weight gradients of this chunk's MLP (deterministic two-stage reduction) ----
+            launches.append(p)
+            work.append((c, r0, rows, z1, dz1, dz2, vecp, vs, needs, (wpack, W1c, W2c)))
+        # data gradients: the chunks of the fp32 wide family in one grid, the others one launch each; `nblks` = the rows of
+        # vec_partials every launch wrote
+        nblks = _launch_chunks(lib, "bwd", launches)
+        # ---- weight gradients per chunk (deterministic two-stage reductions; under a trainer on the side streams: the
+        # optimizer is their only reader, and in one stream they were 2/3 of a chunk's backward chain) ----
+        done = {}
+        for (c, r0, rows, z1, dz1, dz2, vecp, vs, needs, _alive), nblk in zip(work, nblks):
+            prm = params[c]
+            direct_all = DIRECT_PARAM_GRADS and all(q is None or not nd or (q.grad is not None and q.grad.is_contiguous()) for q, nd in zip(prm, needs))
+            on_side = OVERLAP.active and direct_all
+            streams = contextlib.ExitStack()
+            if on_side:
+                side = OVERLAP.stream_for(prm[0])
+                side.wait_stream(torch.cuda.current_stream())
+                OVERLAP.hold(side, dz1, dz2, vecp, z1, *ctx.bases)
+                streams.enter_context(torch.cuda.stream(side))
             src_list = []
             for k in range(nsrc):
                 b_, bstride = ctx.win_meta[k]
@@ -1065,8 +1096,16 @@ class ChunkedMLPFunction(torch.autograd.Function):
                     src_list.append((t.data_ptr() + 4 * r0 * widths[k], bs, widths[k], None))
                 else:
                     src_list.append((t.data_ptr(), bs, widths[k], geom.src_idx[k].data_ptr() + 4 * r0))
-            grads_params.extend(_chunk_weight_grads(lib, B, rows, hid, dout, kin, ctx.mm_flags, dz1, dz2, z1, vecp, nblk, vs,
-                                                    src_list, params[c], needs, ctx.has_ln))
+            with streams:
+                done[c] = _chunk_weight_grads(lib, B, rows, hid, dout, kin, ctx.mm_flags, dz1, dz2, z1, vecp, nblk, vs,
+                                              src_list, prm, needs, ctx.has_ln)
+        grads_params = []
+        for c, (r0, r1) in enumerate(geom.chunks):
+            if c in done:
+                grads_params.extend(done[c])
+            else:   # an empty chunk
+                needs = [ctx.needs_input_grad[2 + 6 * c + q] for q in range(6)]
+                grads_params.extend([torch.zeros_like(q) if (q is not None and nd) else None for q, nd in zip(params[c], needs)])
         # ---- finish the gathered sources: one segment sum over all chunks' rows ----
         grads_src = []
         for k in range(nsrc):
@@ -1087,6 +1126,44 @@ class ChunkedMLPFunction(torch.autograd.Function):
                 g = g.reshape(shape)
             grads_src.append(g)
         return (None, None, *grads_params, *grads_src)
+
+
+# chunks of the fp32 wide family (d = 128 below the super-tile threshold) share one grid per direction
+GROUP_CHUNKS = os.environ.get("NLAM_GROUP_CHUNKS", "1") == "1"
+
+
+def _launch_chunks(lib, which, launches):
+    """Launch the fused kernels of a chunked MLP (``launches``: filled MlpFwd / MlpBwd structs): members of the fp32 wide
+    family go <= NLAM_MAX_GROUP at a time into ONE grid (nlam_mlp_*_group; every other chunk of hi_lam_parallel.py:127-143
+    at d = 128 is 3 .. 206 tiles -- a launch apiece leaves most of the chip idle for one tile's latency), the others one
+    launch each.  Returns, per launch, the rows of ``vec_partials`` it wrote (backward; None forward)."""
+    fwd = which == "fwd"
+    family = lib.nlam_mlp_fwd_family if fwd else lib.nlam_mlp_bwd_family
+    single = lib.nlam_mlp_fwd if fwd else lib.nlam_mlp_bwd
+    group = lib.nlam_mlp_fwd_group if fwd else lib.nlam_mlp_bwd_group
+    typ = L.MlpFwd if fwd else L.MlpBwd
+    nblks = [None if fwd else int(p.vec_partials_rows) for p in launches]
+    wide = [i for i, p in enumerate(launches) if GROUP_CHUNKS and int(family(C.byref(p))) == 1]
+    grouped = set()
+    for g0 in range(0, len(wide), L.NLAM_MAX_GROUP):
+        members = wide[g0 : g0 + L.NLAM_MAX_GROUP]
+        if len(members) < 2:
+            continue
+        m = len(members)
+        arr = (typ * m)(*[launches[i] for i in members])
+        if not fwd:
+            blocks = (C.c_int32 * m)()
+            L.check(lib.nlam_mlp_bwd_group_blocks(arr, m, blocks), "nlam_mlp_bwd_group_blocks")
+            for j, i in enumerate(members):
+                nblks[i] = int(blocks[j])
+        rows_all = sum(int(arr[j].rows) * int(arr[j].batch) for j in range(m))
+        rc = PROFILE.launch((f"mlp_{which}_group_wide", rows_all, m, int(arr[0].hid), int(arr[0].dout)), lambda: group(arr, m, _stream()))
+        L.check(rc, f"nlam_mlp_{which}_group (chunks)")
+        grouped.update(members)
+    for i, p in enumerate(launches):
+        if i not in grouped:
+            L.check(single(C.byref(p), _stream()), f"nlam_mlp_{which} (chunk)")
+    return nblks
 
 
 def _chunk_weight_grads(lib, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, vecp, nblk, vs, src_list, params, needs, has_ln):
@@ -1242,7 +1319,7 @@ class GroupedMLPFunction(torch.autograd.Function):
             return {"flops": fl, "bytes": by, "mm": name, "mfmas_per_block": mf, "what": f"{n} static-feature embedders in one grouped launch"}
 
         rc = PROFILE.launch(("mlp_fwd_group", rows_all, n, int(arr[0].hid), int(arr[0].dout)),
-                            lambda: lib.nlam_mlp_fwd_group(arr, n, _stream()), grp_meta) if n > 1 else -2
+                            lambda: lib.nlam_mlp_fwd_group(arr, n, _stream()), grp_meta) if (n > 1 and lib.nlam_mlp_fwd_family(arr) == 0) else -2
         if rc == -2:   # NLAM_EUNSUP: members of different kernel shapes -> one launch each
             for k in range(n):
                 p = arr[k]
@@ -1320,7 +1397,7 @@ class GroupedMLPFunction(torch.autograd.Function):
                     "what": f"backward of {m} static-feature embedders in one grouped launch (no data gradients; writes dz1, dz2)"}
 
         rc = PROFILE.launch(("mlp_bwd_group", rows_all, m, int(arr[0].hid), int(arr[0].dout)),
-                            lambda: lib.nlam_mlp_bwd_group(arr, m, _stream()), grp_meta) if m > 1 else -2
+                            lambda: lib.nlam_mlp_bwd_group(arr, m, _stream()), grp_meta) if (m > 1 and lib.nlam_mlp_bwd_family(arr) == 0) else -2
         if rc == -2:
             for i in range(m):
                 p = arr[i]
@@ -1405,6 +1482,8 @@ def _grouped_backward_fused(ctx, g_outs, live, grads):
         return {"flops": fl, "bytes": by, "mm": name, "mfmas_per_block": mf,
                 "what": f"backward of {m} static-feature embedders in one grouped launch, weight gradients accumulated in the kernel"}
 
+    if lib.nlam_mlp_bwd_family(arr) != 0:   # the fused-weight-gradient kernel is a narrow one
+        return False
     rc = PROFILE.launch(("mlp_bwd_group_lw", rows_all, m, int(arr[0].hid), int(arr[0].dout)), lambda: lib.nlam_mlp_bwd_group(arr, m, _stream()), meta)
     if rc == -2:
         return False

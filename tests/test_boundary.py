@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()  # raises if the .so is missing
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nlam_abi_version() == L.ABI_VERSION == 5
+    assert lib.nlam_abi_version() == L.ABI_VERSION == 6
     assert lib.nlam_max_width() >= 64
     assert lib.nlam_num_blocks(1) == 1 and lib.nlam_num_blocks(10**6) == 256
     # tuning knob: known key accepted (and restored), unknown key / negative value rejected
@@ -277,6 +277,55 @@ def test_backward_planning_queries():
     assert nb(desc(d, 255136, 3)) == 256                      # 64-row super tiles, one row group
     assert nb(desc(128, 255136, 3)) == 512                    # d <= 128: two row groups per workgroup
     assert nb(desc(d, 32 * 10, 3)) == 10                      # small launch: fp32 one-tile kernels, one workgroup per tile
+
+
+def test_kernel_family_and_grouped_backward_planning():
+    """nlam_mlp_*_family (0 narrow / 1 fp32 wide / 2 split-bf16 super tiles) and nlam_mlp_bwd_group_blocks: the chunks of a
+    SplitMLPs layer at d = 128 (hi_lam_parallel.py:127-143) are fp32-wide members of one grid, dealt workgroups in proportion
+    to their tiles; a member of another family or shape is refused before anything is launched."""
+    import ctypes as C
+
+    lib = L.load()
+    assert lib.nlam_mlp_fwd_family(None) == -1 and lib.nlam_mlp_bwd_family(None) == -1
+    fam = lambda p: lib.nlam_mlp_fwd_family(C.byref(p))  # noqa: E731
+    assert fam(_fwd_desc([64, 64, 64], 64, 64, 255136, 3)) == 0
+    assert fam(_fwd_desc([128, 128, 128], 128, 128, 32 * 206, 3)) == 1      # 206 tiles: below the super-tile threshold
+    assert fam(_fwd_desc([128, 128, 128], 128, 128, 255136, 3)) == 2
+    assert fam(_fwd_desc([128, 128, 128], 128, 128, 255136, 0)) == 1        # matrix mode f32
+
+    one = C.c_float(0.0)
+    ptr = C.cast(C.pointer(one), C.c_void_p)   # any non-null pointer: nothing below reaches a kernel
+
+    def bwd(d, rows, mm_bits=3):
+        p = L.MlpBwd()
+        p.nsrc, p.batch, p.rows, p.ntiles = 3, 1, rows, (rows + 31) // 32
+        for k in range(3):
+            p.src[k].width = d
+            p.dmode[k] = 0
+        p.hid, p.dout, p.flags = d, d, mm_bits << 8
+        p.W1 = p.W2 = p.z1 = p.wpack = ptr
+        p.wpack_floats = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
+        return p
+
+    tiles = [206, 23, 3, 173, 17]
+    arr = (L.MlpBwd * 5)(*[bwd(128, 32 * t) for t in tiles])
+    assert all(lib.nlam_mlp_bwd_family(C.byref(arr[k])) == 1 for k in range(5))
+    blocks = (C.c_int32 * 5)()
+    assert lib.nlam_mlp_bwd_group_blocks(arr, 5, blocks) == 0
+    assert list(blocks) == tiles                                # fewer tiles than resident workgroups: one workgroup per tile
+    big = [1500, 500, 3]
+    arr = (L.MlpBwd * 3)(*[bwd(128, 32 * t, mm_bits=0) for t in big])
+    assert lib.nlam_mlp_bwd_group_blocks(arr, 3, blocks) == 0
+    got = list(blocks)[:3]
+    single = lib.nlam_mlp_bwd_blocks(C.byref(arr[0]))           # what one launch keeps resident
+    assert sum(got) <= single and got[2] == 1 and abs(got[0] - 3 * got[1]) <= 3
+    # a member of another shape / family: refused
+    arr = (L.MlpBwd * 2)(bwd(128, 32 * 20), bwd(96, 32 * 20))
+    assert lib.nlam_mlp_bwd_group_blocks(arr, 2, blocks) == -2
+    arr = (L.MlpBwd * 2)(bwd(128, 32 * 20), bwd(128, 255136))
+    assert lib.nlam_mlp_bwd_group_blocks(arr, 2, blocks) == -2
+    assert lib.nlam_mlp_bwd_group_blocks(None, 2, blocks) == -1 and lib.nlam_mlp_bwd_group_blocks(arr, 9, blocks) == -1
+    assert lib.nlam_mlp_bwd_group(arr, 2, None) == -2           # the launch runs the same checks
 
 
 def test_argument_errors_are_reported_before_any_launch():

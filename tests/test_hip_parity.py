@@ -99,6 +99,47 @@ def test_layer_matches_reference_golden(dev, golden_layers, name, wide_family, f
         assert rel_err(p.grad.cpu(), case["ref_grad_params"][k]) < TOL, k
 
 
+@pytest.mark.parametrize("name", ["inet_chunked_b2_d128", "inet_chunked_noupdate_d128"])
+def test_chunks_of_the_wide_family_share_one_grid(dev, golden_layers, name):
+    """The chunks of a SplitMLPs layer at d = 128 (hi_lam_parallel.py:127-143) run as members of ONE launch each way
+    (nlam_mlp_fwd_group / nlam_mlp_bwd_group on the fp32 wide kernels): same results as a launch per chunk -- outputs and
+    data gradients bit for bit (a tile's arithmetic does not depend on which workgroup runs it), bias / LayerNorm sums to
+    rounding (their partial sums are grouped by workgroup)."""
+    from neural_lam_amd import ops
+
+    hl = _hl()
+    case = golden_layers[name]
+
+    def run(grouped):
+        old = ops.GROUP_CHUNKS
+        ops.GROUP_CHUNKS = grouped
+        ops.PROFILE.reset(True)
+        try:
+            net = hl.get_gnn_class(case["cls"])(case["edge_index"].to(torch.int64), case["d"], **case["kwargs"])
+            net.load_state_dict(case["state_dict"], strict=True)
+            net.to(dev)
+            send, rec, edge = (case[k].to(dev).requires_grad_() for k in ("send", "rec", "edge"))
+            out = net(send, rec, edge)
+            outs = out if isinstance(out, tuple) else (out,)
+            sum((o * c.to(dev)).sum() for o, c in zip(outs, case["cotangents"])).backward()
+            keys = set(k[0] for k in ops.PROFILE.collect())
+        finally:
+            ops.GROUP_CHUNKS = old
+            ops.PROFILE.reset(False)
+        return [o.detach() for o in outs], [send.grad, rec.grad, edge.grad], {k: p.grad for k, p in net.named_parameters()}, keys
+
+    o1, g1, p1, k1 = run(True)
+    o0, g0, p0, k0 = run(False)
+    assert "mlp_fwd_group_wide" in k1 and "mlp_bwd_group_wide" in k1
+    assert "mlp_fwd_group_wide" not in k0 and "mlp_bwd_group_wide" not in k0
+    for a, b in zip(o1 + g1, o0 + g0):
+        assert torch.equal(a, b)
+    for k in p1:
+        assert rel_err(p1[k].cpu(), p0[k].cpu()) < 1e-5, k
+    for o, r in zip(o1, case["ref_out"]):
+        assert rel_err(o.cpu(), r) < TOL
+
+
 MODEL_CASES = ["graphlam_30x27", "graphlam_30x27_variants", "graphlam_30x27_d128", "hilam_81x30", "hilam_parallel_81x30"]
 
 
