@@ -333,8 +333,9 @@ int32_t nlam_mlp_fwd_group(const nlam_mlp_fwd_t* ps, int32_t n, void* hip_stream
 int32_t nlam_mlp_bwd_group(const nlam_mlp_bwd_t* ps, int32_t n, void* hip_stream);
 /* Round 4: the grouped entry points also take members of the fp32 WIDE family (a width in 65 .. 128 columns below the
  * split-bf16 super-tile threshold, or matrix mode 0): the chunks of a `SplitMLPs` layer (gnn_layers.py:274-324 called from
- * hi_lam_parallel.py:127-143 -- 3 .. 206 tiles each at the bench size), any source / residual / aggregation set the single
- * launch takes, one shape (hid, dout, source widths, flags, dmode, LayerNorm) for all members.  nlam_mlp_*_family says which
+ * hi_lam_parallel.py:127-143 -- 3 .. 206 tiles each at the bench size) and the static-feature embedders at d = 128; any
+ * source / residual / aggregation set the single launch takes, one kernel shape (hid, dout, flags, LayerNorm or not; source
+ * counts and widths may differ) for all members, each with its own `wpack` scratch.  nlam_mlp_*_family says which
  * kernel family a launch runs on (0 narrow, 1 fp32 wide, 2 split-bf16 wide: members of family 2 are launched one by one);
  * nlam_mlp_bwd_group_blocks gives the workgroups (= vec_partials rows written) per member of a grouped backward of either
  * family, checking the members as the launch would. */

@@ -3990,20 +3990,17 @@ void group_blocks(const long* tiles, int n, int* blocks) {
     }
 }
 
-// members of one grouped wide launch run one kernel instantiation with one LDS layout
+// members of one grouped wide launch run one kernel instantiation (hid, dout, the widest gradient decide it); the kernel reads
+// source counts and widths per member, so those may differ (the static-feature embedders: 2 .. 17 input columns)
 bool same_fwd_shape(const nlam_mlp_fwd_t& a, const nlam_mlp_fwd_t& b) {
-    if (a.hid != b.hid || a.dout != b.dout || a.nsrc != b.nsrc || a.ncat != b.ncat) return false;
-    if ((a.flags & ~NLAM_F_WPACK_READY) != (b.flags & ~NLAM_F_WPACK_READY) || (a.ln_w == nullptr) != (b.ln_w == nullptr)) return false;
-    for (int s = 0; s < a.nsrc; ++s)
-        if (a.src[s].width != b.src[s].width) return false;
-    return true;
+    if (a.hid != b.hid || a.dout != b.dout || a.ncat != b.ncat) return false;
+    return (a.flags & ~NLAM_F_WPACK_READY) == (b.flags & ~NLAM_F_WPACK_READY) && (a.ln_w == nullptr) == (b.ln_w == nullptr);
 }
 bool same_bwd_shape(const nlam_mlp_bwd_t& a, const nlam_mlp_bwd_t& b) {
-    if (a.hid != b.hid || a.dout != b.dout || a.nsrc != b.nsrc) return false;
-    if ((a.flags & ~NLAM_F_WPACK_READY) != (b.flags & ~NLAM_F_WPACK_READY) || (a.ln_w == nullptr) != (b.ln_w == nullptr)) return false;
-    for (int s = 0; s < a.nsrc; ++s)
-        if (a.src[s].width != b.src[s].width || a.dmode[s] != b.dmode[s]) return false;
-    return true;
+    if (a.hid != b.hid || a.dout != b.dout) return false;
+    const WideCfg ca = wide_cfg(bwd_wide_maxw(&a)), cb = wide_cfg(bwd_wide_maxw(&b));
+    if (ca.nwv != cb.nwv || ca.fb != cb.fb) return false;
+    return (a.flags & ~NLAM_F_WPACK_READY) == (b.flags & ~NLAM_F_WPACK_READY) && (a.ln_w == nullptr) == (b.ln_w == nullptr);
 }
 
 // the same for the fp32 wide kernels: `cap` = the workgroups one launch keeps resident (wide_grid)

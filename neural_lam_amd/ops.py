@@ -1318,18 +1318,30 @@ class GroupedMLPFunction(torch.autograd.Function):
             name, mf = _mm_executed(mm_flags, arr[0].hid, arr[0].dout, [32])
             return {"flops": fl, "bytes": by, "mm": name, "mfmas_per_block": mf, "what": f"{n} static-feature embedders in one grouped launch"}
 
-        rc = PROFILE.launch(("mlp_fwd_group", rows_all, n, int(arr[0].hid), int(arr[0].dout)),
-                            lambda: lib.nlam_mlp_fwd_group(arr, n, _stream()), grp_meta) if (n > 1 and lib.nlam_mlp_fwd_family(arr) == 0) else -2
-        if rc == -2:   # NLAM_EUNSUP: members of different kernel shapes -> one launch each
-            for k in range(n):
-                p = arr[k]
-                nwp = lib.nlam_mlp_fwd_wpack_floats(C.byref(p))
-                if nwp > 0:
+        fams = {int(lib.nlam_mlp_fwd_family(C.byref(arr[k]))) for k in range(n)}
+        for k in range(n):   # wide members: the weights in MFMA A-operand order (packed once per step under a trainer)
+            p = arr[k]
+            nwp = lib.nlam_mlp_fwd_wpack_floats(C.byref(p))
+            if nwp > 0:
+                W1c, W2c = saved[k][4], saved[k][5]
+                wbuf = None
+                if PACKER is not None:
+                    wbuf = PACKER.get_wide("f", p, nwp, ("gf", W1c.data_ptr(), W2c.data_ptr(), int(p.src[0].width), int(p.hid), int(p.dout), int(p.flags),
+                                                          int(p.rows), int(p.batch)))
+                if wbuf is not None:
+                    p.wpack, p.wpack_floats, p.flags = wbuf.data_ptr(), nwp, int(p.flags) | L.F_WPACK_READY
+                else:
                     wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
                     keep.append(wpack)
                     p.wpack, p.wpack_floats = _ptr(wpack), nwp
-                    packs[k] = None
-                L.check(lib.nlam_mlp_fwd(C.byref(p), _stream()), "nlam_mlp_fwd (group member)")
+                packs[k] = None
+        # one grid for members of the narrow family, or of the fp32 wide one (the embedders at d = 128); mixed families and
+        # split-bf16 super-tile members run one launch each
+        rc = PROFILE.launch(("mlp_fwd_group", rows_all, n, int(arr[0].hid), int(arr[0].dout)),
+                            lambda: lib.nlam_mlp_fwd_group(arr, n, _stream()), grp_meta) if (n > 1 and fams in ({0}, {1})) else -2
+        if rc == -2:   # NLAM_EUNSUP: members of different kernel shapes -> one launch each
+            for k in range(n):
+                L.check(lib.nlam_mlp_fwd(C.byref(arr[k]), _stream()), "nlam_mlp_fwd (group member)")
         else:
             L.check(rc, "nlam_mlp_fwd_group")
         if need_grad:
@@ -1376,8 +1388,30 @@ class GroupedMLPFunction(torch.autograd.Function):
             dz2, _ = _alloc_dz2(lib, p, B * rows, dout, dev)
             tiles[i] = p.ntiles * B
             work.append([k, g, dz1, dz2, None, 0, None])
+        fams = {int(lib.nlam_mlp_bwd_family(C.byref(arr[i]))) for i in range(m)}
+        for i, k in enumerate(live):   # wide members: transposed weights in MFMA A-operand order
+            p = arr[i]
+            nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
+            if nwp > 0:
+                W1c, W2c = ctx.saved[k][4], ctx.saved[k][5]
+                wbuf = None
+                if PACKER is not None:
+                    wbuf = PACKER.get_wide("b", p, nwp, ("gb", W1c.data_ptr(), W2c.data_ptr(), int(p.src[0].width), int(p.hid), int(p.dout), int(p.flags),
+                                                          int(p.rows), int(p.batch), int(p.dz2_ld)))
+                if wbuf is not None:
+                    p.wpack, p.wpack_floats, p.flags = wbuf.data_ptr(), nwp, int(p.flags) | L.F_WPACK_READY
+                else:
+                    wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
+                    work[i][6] = wpack
+                    p.wpack, p.wpack_floats = _ptr(wpack), nwp
         blocks = (C.c_int32 * m)()
-        L.check(lib.nlam_mlp_group_blocks(tiles, m, blocks), "nlam_mlp_group_blocks")
+        can_group = m > 1 and fams in ({0}, {1})
+        if can_group:
+            rcb = lib.nlam_mlp_bwd_group_blocks(arr, m, blocks)
+            if rcb == -2:
+                can_group = False
+            else:
+                L.check(rcb, "nlam_mlp_bwd_group_blocks")
         for i, k in enumerate(live):
             p = arr[i]
             hid, dout = p.hid, p.dout
@@ -1397,15 +1431,10 @@ class GroupedMLPFunction(torch.autograd.Function):
                     "what": f"backward of {m} static-feature embedders in one grouped launch (no data gradients; writes dz1, dz2)"}
 
         rc = PROFILE.launch(("mlp_bwd_group", rows_all, m, int(arr[0].hid), int(arr[0].dout)),
-                            lambda: lib.nlam_mlp_bwd_group(arr, m, _stream()), grp_meta) if (m > 1 and lib.nlam_mlp_bwd_family(arr) == 0) else -2
+                            lambda: lib.nlam_mlp_bwd_group(arr, m, _stream()), grp_meta) if can_group else -2
         if rc == -2:
             for i in range(m):
                 p = arr[i]
-                nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
-                if nwp > 0:
-                    wpack = torch.empty((nwp,), device=dev, dtype=torch.float32)
-                    work[i][6] = wpack
-                    p.wpack, p.wpack_floats = _ptr(wpack), nwp
                 work[i][5] = lib.nlam_mlp_bwd_blocks(C.byref(p))
                 L.check(lib.nlam_mlp_bwd(C.byref(p), _stream()), "nlam_mlp_bwd (group member)")
         else:
