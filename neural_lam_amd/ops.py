@@ -157,6 +157,18 @@ class _WgradOverlap:
             else:
                 t.record_stream(side)
 
+    def run(self, owner, hold, fn):
+        """``fn()`` (launches that read the tensors ``hold``) on ``owner``'s side stream, ordered behind everything enqueued on
+        the current stream so far.  (Issuing the fork only after the chain's NEXT kernel was enqueued -- so that a captured
+        graph keeps the chain on one hardware queue: the executor leaves a node's first child on the node's queue -- was
+        measured in round 4: the chain did stay on one queue and lost its 12 us hop gaps, but every fork landed on ONE other
+        queue in reverse order: cfg2 1.77 -> 2.08 ms; forks batched two to six at a time 1.89 - 2.02 ms.)"""
+        side = self.stream_for(owner)
+        side.wait_stream(torch.cuda.current_stream())
+        self.hold(side, *hold)
+        with torch.cuda.stream(side):
+            fn()
+
     def end(self):
         if self.active:
             for st in self.streams:
@@ -688,9 +700,6 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     vecp = torch.empty((nblk, 4, vs), device=dev, dtype=torch.float32)
     p.vec_partials, p.vec_partials_rows, p.vec_stride = _ptr(vecp), nblk, vs
 
-    # ---- where the launches go.  Weight gradients (needed only by the optimizer) run on a side stream when the
-    # trainer owns the parameter gradients (see _WgradOverlap); an MLP none of whose inputs needs a gradient is a
-    # dead end of backward, so its data-gradient kernel goes there as well ----
     prm = ctx.param_refs
 
     def is_direct(param, shape):
@@ -707,12 +716,6 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     ]
     on_side = OVERLAP.active and all(is_direct(pp, sh) for _, need, pp, sh in wanted if need)
     whole_side = on_side and not any(needs[n_fixed:])
-    streams = contextlib.ExitStack()
-    side = OVERLAP.stream_for(prm[0]) if on_side else None
-    if whole_side:
-        side.wait_stream(torch.cuda.current_stream())
-        OVERLAP.hold(side, g_out, g_aggr, xhat, rstd, wpack)
-        streams.enter_context(torch.cuda.stream(side))
     key = ("mlp_bwd", rows * B, kin, hid, dout, nsrc, g_aggr is not None)
 
     def bwd_meta():
@@ -724,7 +727,11 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
         return {"flops": 2.0 * rows * B * (kin_live * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
                 "what": "LayerNorm/SiLU backward + dh = dz2 W2 + dx = dz1 W1 (data gradients; writes dz1, dz2 for the weight gradients)"}
 
-    L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_bwd(C.byref(p), _stream()), bwd_meta), "nlam_mlp_bwd")
+    def launch_data():
+        L.check(PROFILE.launch(key, lambda: lib.nlam_mlp_bwd(C.byref(p), _stream()), bwd_meta), "nlam_mlp_bwd")
+
+    if not whole_side:
+        launch_data()
     if geom.comb is not None:   # receiver gradients of split receivers: sum their pieces, drop the virtual rows
         for k in range(nsrc):
             if dsrc[k] is not None and p.dmode[k] == 3:
@@ -755,13 +762,6 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
                 )
 
     # ---- weight gradients: TN GEMMs with a deterministic two-stage reduction ----
-    if on_side:
-        if not whole_side:
-            side.wait_stream(torch.cuda.current_stream())
-            streams.enter_context(torch.cuda.stream(side))
-        OVERLAP.hold(side, dz1, dz2, vecp, z1, *bases)
-    side_ctx = streams
-
     def wgrad(A, m, src_list, n, flags):
         q = L.Wgrad()
         q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(src_list), flags | ctx.mm_flags, n
@@ -789,7 +789,8 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
         src_list.append((bases[k], bstride if b_ == B or B == 1 else 0, widths[k], geom.src_idx[k]))
     kin1 = widths[0] if pre else kin
     results = [None] * 6   # dW1, db1, dW2, db2, dgamma, dbeta
-    with side_ctx:
+
+    def launch_weights():
         part1 = wgrad(dz1, hid, src_list, kin1, L.F_A_BF16 if sbf else 0) if needs[1] else None
         part2 = wgrad(dz2, dpad, [(z1, rows * hid, hid, None)], hid, L.F_SILU_B | ((L.F_A_BF16 | L.F_S_BF16) if sbf else 0)) if needs[3] else None
 
@@ -830,9 +831,19 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
         if jobs.njobs > 0:
             L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
         if on_side:
-            OVERLAP.hold(side, part1, part2)
+            OVERLAP.hold(torch.cuda.current_stream(), part1, part2)
         if GRAD_LISTENER is not None:   # inside the side-stream context: a collective launched from here waits on it
             GRAD_LISTENER.note_done([pp for _, need, pp, sh in wanted if need and is_direct(pp, sh)])
+
+    # Where the launches go: weight gradients (needed only by the optimizer) on a side stream when the trainer owns the
+    # parameter gradients (see _WgradOverlap); an MLP none of whose inputs needs a gradient is a dead end of backward, so
+    # its data-gradient kernel goes there as well.
+    if whole_side:
+        OVERLAP.run(prm[0], (g_out, g_aggr, xhat, rstd, wpack, dz1, dz2, vecp, z1, *bases), lambda: (launch_data(), launch_weights()))
+    elif on_side:
+        OVERLAP.run(prm[0], (dz1, dz2, vecp, z1, *bases), launch_weights)
+    else:
+        launch_weights()
     dW1, db1, dW2, db2, dg, dbt = results
 
     grads_src = []
@@ -1081,12 +1092,6 @@ class ChunkedMLPFunction(torch.autograd.Function):
             prm = params[c]
             direct_all = DIRECT_PARAM_GRADS and all(q is None or not nd or (q.grad is not None and q.grad.is_contiguous()) for q, nd in zip(prm, needs))
             on_side = OVERLAP.active and direct_all
-            streams = contextlib.ExitStack()
-            if on_side:
-                side = OVERLAP.stream_for(prm[0])
-                side.wait_stream(torch.cuda.current_stream())
-                OVERLAP.hold(side, dz1, dz2, vecp, z1, *ctx.bases)
-                streams.enter_context(torch.cuda.stream(side))
             src_list = []
             for k in range(nsrc):
                 b_, bstride = ctx.win_meta[k]
@@ -1096,9 +1101,12 @@ class ChunkedMLPFunction(torch.autograd.Function):
                     src_list.append((t.data_ptr() + 4 * r0 * widths[k], bs, widths[k], None))
                 else:
                     src_list.append((t.data_ptr(), bs, widths[k], geom.src_idx[k].data_ptr() + 4 * r0))
-            with streams:
-                done[c] = _chunk_weight_grads(lib, B, rows, hid, dout, kin, ctx.mm_flags, dz1, dz2, z1, vecp, nblk, vs,
-                                              src_list, prm, needs, ctx.has_ln)
+            args = (lib, B, rows, hid, dout, kin, ctx.mm_flags, dz1, dz2, z1, vecp, nblk, vs, src_list, prm, needs, ctx.has_ln)
+            if on_side:   # (every gradient lands in the flat views: nothing to return)
+                OVERLAP.run(prm[0], (dz1, dz2, vecp, z1, *ctx.bases), lambda a=args: _chunk_weight_grads(*a))
+                done[c] = [None] * 6
+            else:
+                done[c] = _chunk_weight_grads(*args)
         grads_params = []
         for c, (r0, r1) in enumerate(geom.chunks):
             if c in done:
@@ -1450,17 +1458,12 @@ class GroupedMLPFunction(torch.autograd.Function):
             has_ln = prm[4] is not None
             direct_all = DIRECT_PARAM_GRADS and all(q is None or not nd or (q.grad is not None and q.grad.is_contiguous()) for q, nd in zip(prm, needs))
             on_side = OVERLAP.active and direct_all
-            streams = contextlib.ExitStack()
+            src_list = [(t.data_ptr(), bstride, kin, None)]
+            args = (lib, B, rows, hid, dout, kin, ctx.mm_flags, dz1, dz2, z1, vecp, nblk, _vec_stride(hid, dout), src_list, prm, needs, has_ln)
             if on_side:
-                side = OVERLAP.stream_for(prm[0])
-                side.wait_stream(torch.cuda.current_stream())
-                OVERLAP.hold(side, g, dz1, dz2, vecp, z1, t, wpack)
-                streams.enter_context(torch.cuda.stream(side))
-            with streams:
-                src_list = [(t.data_ptr(), bstride, kin, None)]
-                res = _chunk_weight_grads(lib, B, rows, hid, dout, kin, ctx.mm_flags, dz1, dz2, z1, vecp, nblk, _vec_stride(hid, dout),
-                                          src_list, prm, needs, has_ln)
-            grads[6 * k : 6 * k + 6] = res
+                OVERLAP.run(prm[0], (g, dz1, dz2, vecp, z1, t, wpack), lambda a=args: _chunk_weight_grads(*a))
+            else:
+                grads[6 * k : 6 * k + 6] = _chunk_weight_grads(*args)
         return (None, *grads, *([None] * n))
 
 
@@ -1663,14 +1666,9 @@ def _node_linear_wgrad(prm, g_cols, x2d, mm):
     direct = (DIRECT_PARAM_GRADS and prm.grad is not None and prm.grad.is_contiguous()
               and tuple(prm.grad.shape) == (hid, kin) and prm.grad.dtype == torch.float32)
     on_side = OVERLAP.active and direct
-    streams = contextlib.ExitStack()
-    if on_side:
-        side = OVERLAP.stream_for(prm)
-        side.wait_stream(torch.cuda.current_stream())
-        OVERLAP.hold(side, x2d, *[g for g, _ in g_cols])
-        streams.enter_context(torch.cuda.stream(side))
-    with streams:
-        out = prm.grad if direct else torch.zeros((hid, kin), device=dev, dtype=torch.float32)
+    out = prm.grad if direct else torch.zeros((hid, kin), device=dev, dtype=torch.float32)
+
+    def launch():
         jobs = L.ReduceJobs()
         keep = []
         for g2d, col0 in g_cols:
@@ -1693,9 +1691,14 @@ def _node_linear_wgrad(prm, g_cols, x2d, mm):
             jobs.njobs += 1
         L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
         if on_side:
-            OVERLAP.hold(side, *keep)
+            OVERLAP.hold(torch.cuda.current_stream(), *keep)
         if GRAD_LISTENER is not None and direct:
             GRAD_LISTENER.note_done([prm])
+
+    if on_side:
+        OVERLAP.run(prm, (x2d, *[g for g, _ in g_cols]), launch)
+    else:
+        launch()
     return None if direct else out
 
 
