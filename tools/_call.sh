@@ -1,4 +1,8 @@
-mkdir -p gpurun_out/dot && cd gpurun_out/dot
-NLAM_DEFER_X=1 DEBUG_HIP_GRAPH_DOT_PRINT=1 AMD_LOG_LEVEL=0 python $GRAFT_REPO_ROOT/bench.py --config cfg2 --steps 3 --warmup 1 --no-cpu-baseline --no-gpu-baseline --no-roofline --no-data-path > run.log 2>&1
-ls -la . /tmp | head -40
-find / -name "*.dot" -mmin -5 2>/dev/null | head
+mkdir -p gpurun_out/round4
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gpu-baseline --no-data-path > gpurun_out/round4/bench_cfg2_driver_cmdline.json 2>/dev/null
+python bench.py > gpurun_out/round4/bench_cfg2.json 2> gpurun_out/round4/bench_cfg2.err
+python - <<PY
+import json
+d = json.load(open('gpurun_out/round4/bench_cfg2.json'))
+r = d['roofline']; print(d['ms_per_step'], {k: r[k] for k in ('bound','achieved','peak','unit','frac','traffic','traffic_source')})
+PY

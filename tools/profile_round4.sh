@@ -11,7 +11,7 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gpu-baseline --no-d
 python bench.py > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
 python bench.py --config cfg3 --steps 12 --warmup 2 --no-data-path > $OUT/bench_cfg3.json 2>/dev/null
 python bench.py --config cfg4 --steps 30 --warmup 3 --no-data-path > $OUT/bench_cfg4.json 2>/dev/null
-python bench.py --config cfg4p --steps 30 --warmup 3 --no-cpu-baseline --no-gpu-baseline --no-data-path > $OUT/bench_cfg4p.json 2>/dev/null
+python bench.py --config cfg4p --steps 30 --warmup 3 --no-data-path > $OUT/bench_cfg4p.json 2>/dev/null
 python bench.py --config cfg5 --precision bf16 --steps 4 --warmup 2 --no-data-path > $OUT/bench_cfg5_bf16.json 2>/dev/null
 python bench.py --config cfg3 --precision bf16 --steps 12 --warmup 2 --no-cpu-baseline --no-data-path > $OUT/bench_cfg3_bf16.json 2>/dev/null
 for w in m2g g2m m2m; do python tools/kernel_bench.py $w 12 64 2>&1 | grep -v amdgpu.ids; done > $OUT/kernel_bench_d64.log
@@ -33,6 +33,13 @@ for c in cfg3 cfg5; do
   grep "^#" $OUT/${c}_step_timeline_full.txt > $OUT/${c}_step_kernel_totals.txt
   cp $(find $OUT/tr_$c -name "*kernel_stats.csv" | head -1) $OUT/bench_${c}_kernel_stats.csv
   rm -rf $OUT/tr_$c $OUT/${c}_step_timeline_full.txt
+done
+for c in cfg4 cfg4p; do   # per-queue timelines of the Hi-LAM steps (grouped chunk / embedder launches, finding 37)
+  cd /tmp
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/tr_$c -o t -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --no-gpu-baseline --no-roofline --no-data-path > /dev/null 2>&1
+  cd $GRAFT_REPO_ROOT
+  python tools/queue_timeline.py $(find $OUT/tr_$c -name "*kernel_trace.csv" | head -1) $OUT/${c}_step_queue_timeline.txt
+  rm -rf $OUT/tr_$c
 done
 # PMC passes (counters only + kernel trace, one pass per counter group): HBM traffic of the cfg2 edge stage's kernels (-> bench.py's
 # roofline.traffic, stamped with the hash of the kernel sources), wave / instruction counters of the replayed cfg2 step and of the
