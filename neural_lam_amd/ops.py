@@ -1509,7 +1509,10 @@ def _grouped_backward_fused(ctx, g_outs, live, grads):
 
     def meta():
         fl = sum(4.0 * arr[i].rows * arr[i].batch * arr[i].hid * arr[i].dout for i in range(m))
-        by = sum(4.0 * arr[i].rows * arr[i].batch * (2 * arr[i].dout + arr[i].hid + 1) for i in range(m))
+        # reads g_out, xhat, rstd and the <= 3 input columns (z1 is recomputed, dz1 / dz2 never leave the chip); writes one
+        # (dout x hid) partial + seven vector rows per workgroup
+        by = sum(4.0 * arr[i].rows * arr[i].batch * (2 * arr[i].dout + arr[i].src[0].width + 1) for i in range(m))
+        by += sum(4.0 * w[4] * (arr[0].dout * arr[0].hid + 7 * w[5]) for w in work)
         name, mf = _mm_executed(ctx.mm_flags, arr[0].hid, arr[0].dout, [32])
         return {"flops": fl, "bytes": by, "mm": name, "mfmas_per_block": mf,
                 "what": f"backward of {m} static-feature embedders in one grouped launch, weight gradients accumulated in the kernel"}

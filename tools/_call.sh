@@ -4,5 +4,6 @@ python bench.py > gpurun_out/round4/bench_cfg2.json 2> gpurun_out/round4/bench_c
 python - <<PY
 import json
 d = json.load(open('gpurun_out/round4/bench_cfg2.json'))
-r = d['roofline']; print(d['ms_per_step'], {k: r[k] for k in ('bound','achieved','peak','unit','frac','traffic','traffic_source')})
+r = d['roofline']; print(d['ms_per_step'], {k: r[k] for k in ('bound','achieved','frac','traffic','traffic_source')})
+for k in r['kernels']: print(k['launch'], round(k['avg_launch_ms']*1e3,1), 'us x', k['launches'], 'frac', round(k['frac'],3), k['bound'], 'alg MB', round(k['algorithmic_bytes']/1e6,1), 'traffic', k['traffic'])
 PY

@@ -26,10 +26,25 @@ out = {"note": "HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE KiB (gfx950 F
                "kernel trace only; one InteractionNet edge stage (forward in training mode, backward, both weight gradients)",
        "library_stamp": source_stamp(),   # bench.py refuses this file once the kernels' sources change
        "bytes_per_launch": {}, "counters": {}, "commands": []}
+# launches that only exist inside the whole step (`path:step`: a pmc_collect pass over the replayed cfg2 step, keyed by kernel AND
+# grid -- the node launches run the edge kernels on 206 workgroups): (kernel prefix, grid threads) -> launch key of bench.py
+STEP = {
+    ("mlp_bwd_fast_group_kernel<2, 2, 3, true>", None): "mlp_bwd_group_lw:398549:4:64",   # the four static-feature embedders
+    ("mlp_bwd_fast_kernel<2, 2, 3, false>", 206 * 512): f"mlp_bwd:6561:{2 * d}:{d}",        # node MLP backward, 6 561 mesh nodes
+    ("mlp_fwd_bf_kernel<2, 2, 3, false, true, false", 206 * 512): f"mlp_fwd:6561:{2 * d}:{d}",
+}
 for arg in sys.argv[1:]:
     path, rows = arg.split(":")
     js = json.load(open(path))
     out["commands"].append(js["command"])
+    if rows == "step":
+        for kg, c in js.get("by_grid", {}).items():
+            name, grid = kg.rsplit("|", 1)
+            for (prefix, g), key in STEP.items():
+                if name.startswith(prefix) and (g is None or str(g) == grid) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    out["bytes_per_launch"][key] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+                    out["counters"][key] = {"kernel": name, "grid": grid, **c}
+        continue
     for name, c in js["kernels"].items():
         for prefix, (kind, k, n) in NAMES.items():
             if name.startswith(prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:

@@ -69,7 +69,7 @@ def main():
     (root / "gpurun_out" / f"pmc_{tag}.md").write_text(text)
     import json
 
-    js = {}
+    js, by_grid = {}, {}
     for key in stats:
         if not key[0].startswith(("mlp_", "wgrad", "segment", "reduce", "pack", "adamw", "linear")):
             continue
@@ -77,7 +77,9 @@ def main():
         dd = [v for kk, v in dur.items() if kk[0] == key[0]]
         dmean = sum(sum(v) for v in dd) / max(1, sum(len(v) for v in dd)) if dd else None
         js[key[0]] = {"grid": key[1], "mean_duration_us": dmean, **{cn: sum(v) / len(v) for cn, v in c.items()}}
-    (root / "gpurun_out" / f"pmc_{tag}.json").write_text(json.dumps({"command": " ".join(cmd), "kernels": js}, indent=1))
+        # the same kernel launched on different grids (edge / node launches of a whole step) kept apart
+        by_grid[f"{key[0]}|{key[1].split()[0]}"] = {"dispatches": max(len(v) for v in c.values()), **{cn: sum(v) / len(v) for cn, v in c.items()}}
+    (root / "gpurun_out" / f"pmc_{tag}.json").write_text(json.dumps({"command": " ".join(cmd), "kernels": js, "by_grid": by_grid}, indent=1))
     print(text)
 
 

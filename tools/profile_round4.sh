@@ -46,10 +46,10 @@ done
 # one-term d = 512 and three-term d = 256 wide kernels
 python tools/pmc_collect.py m2g_edge fetch write wave insts -- python tools/kernel_bench.py m2g 3 64 edge > /dev/null 2>&1
 python tools/pmc_collect.py m2m_edge fetch write wave insts -- python tools/kernel_bench.py m2m 3 64 edge > /dev/null 2>&1
-python tools/make_pmc_traffic.py gpurun_out/pmc_m2g_edge.json:255136 gpurun_out/pmc_m2m_edge.json:57616 > $OUT/pmc_traffic.json
 cp gpurun_out/pmc_m2g_edge.md $OUT/pmc_m2g_edge.md; cp gpurun_out/pmc_m2m_edge.md $OUT/pmc_m2m_edge.md
-python tools/pmc_collect.py cfg2_step wave insts -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gpu-baseline --no-roofline --no-data-path > /dev/null 2>&1
+python tools/pmc_collect.py cfg2_step wave insts fetch write -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gpu-baseline --no-roofline --no-data-path > /dev/null 2>&1
 cp gpurun_out/pmc_cfg2_step.md $OUT/pmc_cfg2_step.md
+python tools/make_pmc_traffic.py gpurun_out/pmc_m2g_edge.json:255136 gpurun_out/pmc_m2m_edge.json:57616 gpurun_out/pmc_cfg2_step.json:step > $OUT/pmc_traffic.json
 NLAM_KB_AUTOCAST=1 python tools/pmc_collect.py wide_d512_bf16 wave insts fetch write -- python tools/kernel_bench.py m2m 4 512 edge > /dev/null 2>&1
 cp gpurun_out/pmc_wide_d512_bf16.md $OUT/pmc_wide_d512_bf16.md
 python tools/pmc_collect.py wide_d256_x3 wave insts fetch write -- python tools/kernel_bench.py m2m 4 256 edge > /dev/null 2>&1
