@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define NLAM_ABI_VERSION 6
+#define NLAM_ABI_VERSION 7
 #define NLAM_MAX_SRC 3
 #define NLAM_MAX_CAT 6
 
@@ -343,6 +343,10 @@ int32_t nlam_mlp_fwd_family(const nlam_mlp_fwd_t* p);
 int32_t nlam_mlp_bwd_family(const nlam_mlp_bwd_t* p);
 int32_t nlam_mlp_bwd_group_blocks(const nlam_mlp_bwd_t* ps, int32_t n, int32_t* blocks);
 int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream);
+/* n <= NLAM_MAX_GROUP weight gradients of one shape (m, source widths, flags) in ONE grid, each member with its own rows and
+ * `partials` (nparts = nlam_wgrad_nparts of that member): the chunks of a `SplitMLPs` layer (gnn_layers.py:311-324).  Members of
+ * the split-bf16 wide family with fp32 operands; NLAM_EUNSUP otherwise (launch them one by one). */
+int32_t nlam_wgrad_group(const nlam_wgrad_t* ps, int32_t n, void* hip_stream);
 
 /* out[b, s, :] = scale(s) * sum_{q in [ptr[s], ptr[s+1])} in[b, order[q], :]   (order NULL = q) */
 int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order,

@@ -66,6 +66,7 @@ EXPORTS = [
     "nlam_mlp_fwd_family",
     "nlam_mlp_bwd_family",
     "nlam_mlp_bwd_group_blocks",
+    "nlam_wgrad_group",
     "nlam_linear",
     "nlam_pre_add_supported",
     "nlam_step_tail_fwd",
@@ -293,7 +294,7 @@ class PackRec(C.Structure):
     _fields_ = [("bytes", C.c_ubyte * 64)]
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 
@@ -398,6 +399,8 @@ def load():
     lib.nlam_mlp_bwd_family.restype = i32
     lib.nlam_mlp_bwd_group_blocks.argtypes = [C.POINTER(MlpBwd), i32, C.POINTER(i32)]
     lib.nlam_mlp_bwd_group_blocks.restype = i32
+    lib.nlam_wgrad_group.argtypes = [C.POINTER(Wgrad), i32, vp]
+    lib.nlam_wgrad_group.restype = i32
     lib.nlam_pre_add_supported.argtypes = [C.POINTER(MlpFwd)]
     lib.nlam_pre_add_supported.restype = i32
     lib.nlam_linear.argtypes = [C.POINTER(Linear), vp]

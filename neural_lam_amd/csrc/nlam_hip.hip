@@ -93,6 +93,7 @@ int32_t wgrad_wide(const nlam_wgrad_t* p, hipStream_t stream);     // slice 3
 int32_t fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream);      // slice 4
 int32_t bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream);      // slice 4
 int32_t wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream);      // slice 4
+int32_t wgrad_wbf_group(const nlam_wgrad_t* ps, int n, hipStream_t stream);   // slice 4
 extern int wbf_min_supertiles;                                     // nlam_set_tuning (defined in slice 1)
 extern int wbf_half;                                               // nlam_set_tuning (defined in slice 1)
 extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
@@ -5100,6 +5101,28 @@ int32_t nlam_wgrad(const nlam_wgrad_t* p, void* hip_stream) {
     return nlam_detail::wgrad_narrow(p, stream);
 }
 
+// n <= NLAM_MAX_GROUP weight gradients of ONE shape (m, sources and their widths, flags) in one grid: member k's row slices are
+// workgroups first[k] .. first[k + 1) of gridDim.x and land in its own `partials`.  Members of the split-bf16 family with fp32
+// operands (NLAM_EUNSUP otherwise: launch them one by one).
+int32_t nlam_wgrad_group(const nlam_wgrad_t* ps, int32_t n, void* hip_stream) {
+    NLAM_RANGE("nlam_wgrad_group");
+    if (ps == nullptr || n < 1 || n > NLAM_MAX_GROUP) return NLAM_EINVAL;
+    for (int k = 0; k < n; ++k) {
+        const nlam_wgrad_t* p = &ps[k];
+        if (p->A == nullptr || p->partials == nullptr || p->nsrc < 1 || p->nsrc > NLAM_MAX_SRC) return NLAM_EINVAL;
+        int w = 0;
+        for (int s = 0; s < p->nsrc; ++s) w += p->src[s].width;
+        if (w != p->n || p->m < 1 || p->nparts < 1 || p->nparts != nlam_wgrad_nparts(p)) return NLAM_EINVAL;
+        if ((p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) || !wgrad_is_wide(p) || wgrad_wbf_ns(p) == 0) return NLAM_EUNSUP;
+        if (p->flags & (NLAM_F_A_BF16 | NLAM_F_S_BF16)) return NLAM_EUNSUP;
+        if (p->m != ps[0].m || p->n != ps[0].n || p->nsrc != ps[0].nsrc || p->flags != ps[0].flags || wgrad_wbf_big(p) != wgrad_wbf_big(&ps[0]))
+            return NLAM_EUNSUP;
+        for (int s = 0; s < p->nsrc; ++s)
+            if (p->src[s].width != ps[0].src[s].width) return NLAM_EUNSUP;
+    }
+    return nlam_detail::wgrad_wbf_group(ps, n, (hipStream_t)hip_stream);
+}
+
 }  // extern "C"
 #endif
 
@@ -5149,6 +5172,43 @@ int32_t nlam_detail::wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream) {
         else NLAM_LAUNCH_WG_WBF2(3, false);
         return (int32_t)hipGetLastError();
     }
+#endif
+
+#if NLAM_IN_TU(4)
+// members checked by nlam_wgrad_group: split-bf16 family, fp32 operands, one shape (m, sources, flags, window size)
+int32_t nlam_detail::wgrad_wbf_group(const nlam_wgrad_t* ps, int n, hipStream_t stream) {
+    const nlam_wgrad_t* p = &ps[0];
+    const int wns = wgrad_wbf_ns(p);
+    const bool big = wgrad_wbf_big(p);
+    const int winm = big ? 256 : 128, winn = big ? 256 : 128;
+    const size_t lds = (size_t)2 * ((winm + winn) / 32) * wns * 1024;
+    wgrad_group_t G;
+    G.n = n;
+    G.first[0] = 0;
+    for (int k = 0; k < n; ++k) {
+        G.g[k] = ps[k];
+        G.first[k + 1] = G.first[k] + ps[k].nparts;
+    }
+    for (int k = n + 1; k <= NLAM_MAX_GROUP; ++k) G.first[k] = G.first[n];
+    const dim3 grid(G.first[n], wgrad_windows_of(p, winm, winn));
+#define NLAM_LAUNCH_WG_WBF_G(NS_, S_, WM_, WN_, NBW_)                                                                       \
+    do {                                                                                                                    \
+        int rc = set_lds(wgrad_wbf_group_kernel<NS_, S_, WM_, WN_, NBW_>, lds);                                             \
+        if (rc != 0) return rc;                                                                                             \
+        hipLaunchKernelGGL((wgrad_wbf_group_kernel<NS_, S_, WM_, WN_, NBW_>), grid, dim3(WM_ * WN_ * 64), lds, stream, G);  \
+    } while (0)
+#define NLAM_LAUNCH_WG_WBF_G2(NS_, S_)                   \
+    do {                                                 \
+        if (big) NLAM_LAUNCH_WG_WBF_G(NS_, S_, 4, 2, 4); \
+        else NLAM_LAUNCH_WG_WBF_G(NS_, S_, 2, 2, 2);     \
+    } while (0)
+    const bool silu = (p->flags & NLAM_F_SILU_B) != 0;
+    if (wns == 1 && silu) NLAM_LAUNCH_WG_WBF_G2(1, true);
+    else if (wns == 1) NLAM_LAUNCH_WG_WBF_G2(1, false);
+    else if (silu) NLAM_LAUNCH_WG_WBF_G2(3, true);
+    else NLAM_LAUNCH_WG_WBF_G2(3, false);
+    return (int32_t)hipGetLastError();
+}
 #endif
 
 #if NLAM_IN_TU(3)

@@ -1085,13 +1085,16 @@ class ChunkedMLPFunction(torch.autograd.Function):
         # data gradients: the chunks of the fp32 wide family in one grid, the others one launch each; `nblks` = the rows of
         # vec_partials every launch wrote
         nblks = _launch_chunks(lib, "bwd", launches)
-        # ---- weight gradients per chunk (deterministic two-stage reductions; under a trainer on the side streams: the
-        # optimizer is their only reader, and in one stream they were 2/3 of a chunk's backward chain) ----
+        # ---- weight gradients per chunk (deterministic two-stage reductions).  Under a trainer they leave the chain: the
+        # optimizer is their only reader, and in one stream they were 2/3 of a chunk's backward chain.  ALL chunks go to ONE
+        # side stream in ONE fork: forked one by one, the seven forks of an edge stage are edges 0 .. 6 of the same chain kernel,
+        # the chain's next kernel is edge 7, and the graph executor (DESIGN finding 38) puts it on a hardware queue behind one
+        # chunk's weight gradients -- 150 us of waiting per processor layer in the replayed cfg4p step ----
         done = {}
+        jobs, here = [], []
         for (c, r0, rows, z1, dz1, dz2, vecp, vs, needs, _alive), nblk in zip(work, nblks):
             prm = params[c]
             direct_all = DIRECT_PARAM_GRADS and all(q is None or not nd or (q.grad is not None and q.grad.is_contiguous()) for q, nd in zip(prm, needs))
-            on_side = OVERLAP.active and direct_all
             src_list = []
             for k in range(nsrc):
                 b_, bstride = ctx.win_meta[k]
@@ -1102,11 +1105,13 @@ class ChunkedMLPFunction(torch.autograd.Function):
                 else:
                     src_list.append((t.data_ptr(), bs, widths[k], geom.src_idx[k].data_ptr() + 4 * r0))
             args = (lib, B, rows, hid, dout, kin, ctx.mm_flags, dz1, dz2, z1, vecp, nblk, vs, src_list, prm, needs, ctx.has_ln)
-            if on_side:   # (every gradient lands in the flat views: nothing to return)
-                OVERLAP.run(prm[0], (dz1, dz2, vecp, z1, *ctx.bases), lambda a=args: _chunk_weight_grads(*a))
+            if OVERLAP.active and direct_all:   # (every gradient lands in the flat views: nothing to return)
+                jobs.append((args, (dz1, dz2, vecp, z1)))
                 done[c] = [None] * 6
             else:
-                done[c] = _chunk_weight_grads(*args)
+                here.append((c, args))
+        for (c, _), res in zip(here, _chunks_weight_grads([a for _, a in here]) if here else []):
+            done[c] = res
         grads_params = []
         for c, (r0, r1) in enumerate(geom.chunks):
             if c in done:
@@ -1133,6 +1138,9 @@ class ChunkedMLPFunction(torch.autograd.Function):
                     g = g.sum(0) if B > 1 else g[0]
                 g = g.reshape(shape)
             grads_src.append(g)
+        if jobs:   # forked behind the segment sums: those are the chain, and the fork takes their hardware queue (finding 38)
+            OVERLAP.run(jobs[0][0][14][0], tuple(t for _, held in jobs for t in held) + tuple(ctx.bases),
+                        lambda: _chunks_weight_grads([a for a, _ in jobs]))
         return (None, None, *grads_params, *grads_src)
 
 
@@ -1174,64 +1182,121 @@ def _launch_chunks(lib, which, launches):
     return nblks
 
 
+GROUP_WGRADS = os.environ.get("NLAM_GROUP_WGRADS", "1") == "1"
+
+
 def _chunk_weight_grads(lib, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, vecp, nblk, vs, src_list, params, needs, has_ln):
     """dW1, db1, dW2, db2, dgamma, dbeta of one fused MLP from the saved row gradients: two TN GEMMs (nlam_wgrad) + one
     reduction launch; with a trainer's direct-gradient mode the sums land in the flat gradient views (returns None)."""
-    dev = dz1.device
+    return _chunks_weight_grads([(lib, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, vecp, nblk, vs, src_list, params, needs, has_ln)])[0]
+
+
+def _chunks_weight_grads(items):
+    """The weight gradients of several fused MLPs (``items``: argument tuples of ``_chunk_weight_grads``; the chunks of a
+    ``SplitMLPs`` layer, gnn_layers.py:311-324): every dW1 GEMM of one shape in ONE launch, every dW2 GEMM in one
+    (``nlam_wgrad_group``: members of the split-bf16 wide family; others one launch each), and the reductions of up to
+    NLAM_MAX_REDUCE_JOBS partial sums per launch -- 4 launches instead of 21 for the seven edge chunks of a Hi-LAM-Parallel
+    layer.  Per member the arithmetic is that of its own launch: the results are bit-identical.  Returns one 6-list per item."""
+    lib = items[0][0]
+    dev = items[0][7].device
 
     def is_direct(param, shape):
         return (DIRECT_PARAM_GRADS and param is not None and param.grad is not None and param.grad.is_contiguous()
                 and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32)
 
-    def wgrad(A, m, slist, n, flags):
+    def describe(A, m, slist, n, flags, B, rows):
         q = L.Wgrad()
-        q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(slist), flags | mm_flags, n
+        q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(slist), flags, n
         for k, (ptr, bstride, w, idx) in enumerate(slist):
             q.src[k].ptr, q.src[k].idx, q.src[k].bstride, q.src[k].width = ptr, idx, bstride, w
         nparts = lib.nlam_wgrad_nparts(C.byref(q))
         partials = torch.empty((nparts, m, n), device=dev, dtype=torch.float32)
         q.partials, q.nparts = _ptr(partials), nparts
-        L.check(lib.nlam_wgrad(C.byref(q), _stream()), "nlam_wgrad (chunk)")
-        return partials
+        return q, partials
 
-    part1 = wgrad(dz1, hid, src_list, kin, 0) if needs[0] else None
-    dpad = dz2.shape[1]   # dout, or 32-padded (zero columns) for a ragged output width: the first dout rows of the partials count
-    part2 = wgrad(dz2, dpad, [(z1.data_ptr(), rows * hid, hid, None)], hid, L.F_SILU_B) if needs[2] else None
-    results = [None] * 6
+    def launch(qs):
+        """members of one shape share a grid, NLAM_MAX_GROUP at a time"""
+        classes = {}
+        for q in qs:
+            key = (int(q.m), int(q.n), int(q.nsrc), int(q.flags), tuple(int(q.src[k].width) for k in range(int(q.nsrc))))
+            classes.setdefault(key, []).append(q)
+        for members in classes.values():
+            for g0 in range(0, len(members), L.NLAM_MAX_GROUP):
+                grp = members[g0 : g0 + L.NLAM_MAX_GROUP]
+                rc = -2
+                if GROUP_WGRADS and len(grp) > 1:
+                    arr = (L.Wgrad * len(grp))(*grp)
+                    rows_all = sum(int(q.rows) * int(q.batch) for q in grp)
+                    rc = PROFILE.launch(("wgrad_group", rows_all, len(grp), int(grp[0].m), int(grp[0].n)), lambda: lib.nlam_wgrad_group(arr, len(grp), _stream()))
+                if rc == -2:
+                    for q in grp:
+                        L.check(lib.nlam_wgrad(C.byref(q), _stream()), "nlam_wgrad (chunk)")
+                else:
+                    L.check(rc, "nlam_wgrad_group")
+
+    parts = []
+    q1s, q2s = [], []
+    for (_, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, vecp, nblk, vs, src_list, params, needs, has_ln) in items:
+        part1 = part2 = None
+        dpad = dz2.shape[1]   # dout, or 32-padded (zero columns) for a ragged output width: the first dout rows of the partials count
+        if needs[0]:
+            q, part1 = describe(dz1, hid, src_list, kin, mm_flags, B, rows)
+            q1s.append(q)
+        if needs[2]:
+            q, part2 = describe(dz2, dpad, [(z1.data_ptr(), rows * hid, hid, None)], hid, L.F_SILU_B | mm_flags, B, rows)
+            q2s.append(q)
+        parts.append((part1, part2, dpad))
+    launch(q1s)
+    launch(q2s)
+
+    all_results = []
     jobs = L.ReduceJobs()
     keep = []
 
-    def add_job(slot, partials_ptr, nparts, stride, shape, param):
-        n = 1
-        for d_ in shape:
-            n *= d_
-        direct = is_direct(param, shape)
-        out = param.grad if direct else torch.empty(shape, device=dev, dtype=torch.float32)
-        if not direct:
-            results[slot] = out
-        keep.append(out)
-        j = jobs.job[jobs.njobs]
-        j.partials, j.out, j.stride, j.nparts, j.n, j.accumulate = partials_ptr, _ptr(out), stride, nparts, n, 1 if direct else 0
-        jobs.njobs += 1
+    def flush():
+        if jobs.njobs > 0:
+            L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
+            jobs.njobs = 0
 
-    vbase = vecp.data_ptr()
-    if part1 is not None:
-        add_job(0, _ptr(part1), part1.shape[0], hid * kin, (hid, kin), params[0])
-    if needs[1]:
-        add_job(1, vbase + 0 * vs * 4, nblk, 4 * vs, (hid,), params[1])
-    if part2 is not None:
-        add_job(2, _ptr(part2), part2.shape[0], dpad * hid, (dout, hid), params[2])
-    if needs[3]:
-        add_job(3, vbase + 1 * vs * 4, nblk, 4 * vs, (dout,), params[3])
-    if has_ln and needs[4]:
-        add_job(4, vbase + 2 * vs * 4, nblk, 4 * vs, (dout,), params[4])
-    if has_ln and needs[5]:
-        add_job(5, vbase + 3 * vs * 4, nblk, 4 * vs, (dout,), params[5])
-    if jobs.njobs > 0:
-        L.check(lib.nlam_reduce_jobs(C.byref(jobs), _stream()), "nlam_reduce_jobs")
+    done = []
+    for (_, B, rows, hid, dout, kin, mm_flags, dz1, dz2, z1, vecp, nblk, vs, src_list, params, needs, has_ln), (part1, part2, dpad) in zip(items, parts):
+        results = [None] * 6
+        if jobs.njobs + 6 > L.NLAM_MAX_REDUCE_JOBS:
+            flush()
+
+        def add_job(slot, partials_ptr, nparts, stride, shape, param):
+            n = 1
+            for d_ in shape:
+                n *= d_
+            direct = is_direct(param, shape)
+            out = param.grad if direct else torch.empty(shape, device=dev, dtype=torch.float32)
+            if not direct:
+                results[slot] = out
+            keep.append(out)
+            j = jobs.job[jobs.njobs]
+            j.partials, j.out, j.stride, j.nparts, j.n, j.accumulate = partials_ptr, _ptr(out), stride, nparts, n, 1 if direct else 0
+            j.ncols, j.ld = 0, 0
+            jobs.njobs += 1
+
+        vbase = vecp.data_ptr()
+        if part1 is not None:
+            add_job(0, _ptr(part1), part1.shape[0], hid * kin, (hid, kin), params[0])
+        if needs[1]:
+            add_job(1, vbase + 0 * vs * 4, nblk, 4 * vs, (hid,), params[1])
+        if part2 is not None:
+            add_job(2, _ptr(part2), part2.shape[0], dpad * hid, (dout, hid), params[2])
+        if needs[3]:
+            add_job(3, vbase + 1 * vs * 4, nblk, 4 * vs, (dout,), params[3])
+        if has_ln and needs[4]:
+            add_job(4, vbase + 2 * vs * 4, nblk, 4 * vs, (dout,), params[4])
+        if has_ln and needs[5]:
+            add_job(5, vbase + 3 * vs * 4, nblk, 4 * vs, (dout,), params[5])
+        all_results.append(results)
+        done.extend(q for q, nd in zip(params, needs) if nd and q is not None and is_direct(q, q.shape))
+    flush()
     if GRAD_LISTENER is not None:
-        GRAD_LISTENER.note_done([q for q, nd in zip(params, needs) if nd and q is not None and is_direct(q, q.shape)])
-    return results
+        GRAD_LISTENER.note_done(done)
+    return all_results
 
 
 def _alloc_dz2(lib, p, nrows, dout, dev):

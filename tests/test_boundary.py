@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()  # raises if the .so is missing
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nlam_abi_version() == L.ABI_VERSION == 6
+    assert lib.nlam_abi_version() == L.ABI_VERSION == 7
     assert lib.nlam_max_width() >= 64
     assert lib.nlam_num_blocks(1) == 1 and lib.nlam_num_blocks(10**6) == 256
     # tuning knob: known key accepted (and restored), unknown key / negative value rejected
@@ -326,6 +326,25 @@ def test_kernel_family_and_grouped_backward_planning():
     assert lib.nlam_mlp_bwd_group_blocks(arr, 2, blocks) == -2
     assert lib.nlam_mlp_bwd_group_blocks(None, 2, blocks) == -1 and lib.nlam_mlp_bwd_group_blocks(arr, 9, blocks) == -1
     assert lib.nlam_mlp_bwd_group(arr, 2, None) == -2           # the launch runs the same checks
+    # grouped weight gradients: one shape, split-bf16 wide family, nparts as nlam_wgrad_nparts says
+    def wg(rows, m=128, mm_bits=3):
+        q = L.Wgrad()
+        q.A = q.partials = ptr
+        q.m, q.n, q.batch, q.rows, q.nsrc, q.flags = m, 384, 1, rows, 3, mm_bits << 8
+        for k in range(3):
+            q.src[k].width = 128
+            q.src[k].ptr = ptr
+        q.nparts = lib.nlam_wgrad_nparts(C.byref(q))
+        return q
+
+    assert lib.nlam_wgrad_group(None, 2, None) == -1
+    qs = (L.Wgrad * 2)(wg(32 * 20), wg(32 * 200, m=96))
+    assert lib.nlam_wgrad_group(qs, 2, None) == -2              # another shape
+    qs = (L.Wgrad * 2)(wg(32 * 20), wg(32 * 200, mm_bits=0))
+    assert lib.nlam_wgrad_group(qs, 2, None) == -2              # a member of the fp32 family
+    qs = (L.Wgrad * 2)(wg(32 * 20), wg(32 * 200))
+    qs[1].nparts += 1
+    assert lib.nlam_wgrad_group(qs, 2, None) == -1              # partials sized for another launch shape
 
 
 def test_argument_errors_are_reported_before_any_launch():

@@ -111,8 +111,8 @@ def test_chunks_of_the_wide_family_share_one_grid(dev, golden_layers, name):
     case = golden_layers[name]
 
     def run(grouped):
-        old = ops.GROUP_CHUNKS
-        ops.GROUP_CHUNKS = grouped
+        old, old_w = ops.GROUP_CHUNKS, ops.GROUP_WGRADS
+        ops.GROUP_CHUNKS = ops.GROUP_WGRADS = grouped   # the chunks' weight gradients share launches too (nlam_wgrad_group)
         ops.PROFILE.reset(True)
         try:
             net = hl.get_gnn_class(case["cls"])(case["edge_index"].to(torch.int64), case["d"], **case["kwargs"])
@@ -124,14 +124,17 @@ def test_chunks_of_the_wide_family_share_one_grid(dev, golden_layers, name):
             sum((o * c.to(dev)).sum() for o, c in zip(outs, case["cotangents"])).backward()
             keys = set(k[0] for k in ops.PROFILE.collect())
         finally:
-            ops.GROUP_CHUNKS = old
+            ops.GROUP_CHUNKS, ops.GROUP_WGRADS = old, old_w
             ops.PROFILE.reset(False)
         return [o.detach() for o in outs], [send.grad, rec.grad, edge.grad], {k: p.grad for k, p in net.named_parameters()}, keys
 
     o1, g1, p1, k1 = run(True)
     o0, g0, p0, k0 = run(False)
-    assert "mlp_fwd_group_wide" in k1 and "mlp_bwd_group_wide" in k1
-    assert "mlp_fwd_group_wide" not in k0 and "mlp_bwd_group_wide" not in k0
+    assert "mlp_fwd_group_wide" in k1 and "mlp_bwd_group_wide" in k1 and "wgrad_group" in k1
+    assert "mlp_fwd_group_wide" not in k0 and "mlp_bwd_group_wide" not in k0 and "wgrad_group" not in k0
+    for k in p1:   # weight matrices: the same partial sums in the same order
+        if p1[k].dim() == 2:
+            assert torch.equal(p1[k], p0[k]), k
     for a, b in zip(o1 + g1, o0 + g0):
         assert torch.equal(a, b)
     for k in p1:
