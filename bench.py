@@ -260,6 +260,55 @@ def gpu_reference_equivalent(cfg, device, steps=20, autocast=False):
     return out
 
 
+def lightning_shaped(cfg, device, steps, precision="fp32"):
+    """The step a neural-lam maintainer gets after swapping the two import sites of INTEGRATION.md level 1 and nothing else:
+    the HIP modules driven the way ``pl.Trainer`` drives ``ForecasterModule`` (models/module.py:394-417, train_model.py:564-578) --
+    ``optimizer.zero_grad()``; ``loss = training_step(batch)``; ``loss.backward()``; ``torch.optim.AdamW(betas=(0.9, 0.95)).step()``
+    (module.py:293-304) -- every launch issued from Python, gradients owned by autograd (``AccumulateGrad`` hooks fire, which is
+    what torch DDP needs), no flat buffers, no fused optimizer.  Timed twice: as it is (``eager``), and with
+    ``trainer.graphed_training_step`` inside ``training_step`` (forward and backward each one HIP-graph replay; the optimizer
+    still torch's).  Reported beside ``value``, never as it."""
+    from neural_lam_amd.trainer import graphed_training_step
+
+    out = {"what": "HIP modules under a Lightning-shaped loop: zero_grad + training_step + loss.backward() + torch.optim.AdamW(lr=1e-3, betas=(0.9, 0.95)).step(), "
+                   "gradients through autograd; eager = every launch from Python; graphed = trainer.graphed_training_step (forward and backward one "
+                   "HIP-graph replay each, optimizer unchanged)"}
+    amp = lambda: torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16")   # noqa: E731
+    for name in ("eager", "graphed"):
+        _, _, _, _, step, batch = build(cfg, device)
+        opt = torch.optim.AdamW(step.parameters(), lr=1e-3, betas=(0.9, 0.95))
+        fn = step
+        if name == "graphed":
+            with amp():
+                fn = graphed_training_step(step, *batch)
+
+        def one():
+            opt.zero_grad(set_to_none=True)
+            with amp():
+                _, loss = fn(*batch)
+            loss.backward()
+            opt.step()
+            return loss
+
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        one()
+        torch.cuda.synchronize()
+        n = max(3, min(steps, int(2.0 / max(time.perf_counter() - t0, 1e-4))))   # ~2 s of timed steps
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = one()
+        torch.cuda.synchronize()
+        out[f"ms_per_step_{name}_torch_adamw"] = (time.perf_counter() - t0) / n * 1e3
+        out[f"steps_{name}"] = n
+        out[f"final_loss_{name}"] = float(loss)
+        del step, opt, fn
+        torch.cuda.empty_cache()
+    return out
+
+
 def oracle_loss_step0(cfg, device=None):
     """Loss of the oracle on the benchmark's own weights and batch (forward only, fp32): printed beside the HIP loss.  On the
     host for cfg1 / cfg2; the wide configurations (minutes and tens of GB on the host) run the same restatement on ``device``."""
@@ -323,6 +372,7 @@ def main():
     ap.add_argument("--no-gpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-data-path", action="store_true", help="skip the leg that trains from the HBM-resident dataset")
+    ap.add_argument("--no-lightning-leg", action="store_true", help="skip the Lightning-shaped (eager / graphed + torch AdamW) leg")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying a HIP graph")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = run the step inside torch.autocast(bfloat16), as Lightning --precision bf16-mixed does (cfg5)")
@@ -528,7 +578,12 @@ def main():
 
         traffic, traffic_src = None, "no profiles/round*/pmc_traffic.json"
         if args.config == "cfg2" and args.precision == "fp32":
-            for tfile in sorted((ROOT / "profiles").glob("round*/pmc_traffic.json"), reverse=True):
+            def round_no(f):
+                digits = "".join(ch for ch in f.parent.name if ch.isdigit())
+                return int(digits) if digits else -1
+
+            refused = []
+            for tfile in sorted((ROOT / "profiles").glob("round*/pmc_traffic.json"), key=round_no, reverse=True):   # newest round first
                 try:
                     js = json.loads(tfile.read_text())
                 except Exception:
@@ -536,8 +591,9 @@ def main():
                 if js.get("library_stamp") == _L.source_stamp():
                     traffic, traffic_src = js.get("bytes_per_launch"), str(tfile.relative_to(ROOT))
                     break
-                traffic_src = f"{tfile.relative_to(ROOT)} refused: collected on another build of the kernels (stamp {js.get('library_stamp')})"
-                break
+                refused.append(f"{tfile.relative_to(ROOT)} (stamp {js.get('library_stamp')})")
+            if traffic is None and refused:
+                traffic_src = "refused, collected on another build of the kernels: " + ", ".join(refused)
         rows = kernel_rooflines(recs, meta, ms_per_step, traffic)
         for r in rows:
             r["launches"] = r["launches"] / psteps
@@ -572,6 +628,11 @@ def main():
             }
 
     amp.__exit__(None, None, None)
+    drop_in = None
+    if world == 1 and not args.no_lightning_leg:
+        drop_in = lightning_shaped(cfg, device, args.steps, args.precision)
+        for k in ("eager", "graphed"):
+            drop_in[f"{k}_vs_value_step"] = drop_in[f"ms_per_step_{k}_torch_adamw"] / ms_per_step
     if rank == 0:
         out = {
             "metric": "training sample-steps/s (on_after_batch_transfer+fwd+wmse+bwd+allreduce+AdamW), GraphCast-LAM, MEPS-shaped grid",
@@ -605,6 +666,8 @@ def main():
         }
         if data_path is not None:
             out["from_device_dataset"] = data_path
+        if drop_in is not None:
+            out["lightning_shaped"] = drop_in
         if also is not None:
             out["also"] = also
         if world == 1 and not args.no_cpu_baseline:

@@ -100,6 +100,8 @@ extern int wgrad_chunks_per_wg;                                    // nlam_set_t
 extern int wgrad_min_parts;                                        // nlam_set_tuning (defined in slice 1)
 extern int wgrad_big_min_rows;                                     // nlam_set_tuning (defined in slice 1)
 extern int lin_resident_wgs;                                       // workgroups of a resident-weight nlam_linear launch (slice 1)
+extern int lin_gemm;                                               // nlam_linear on the LDS-tiled GEMM where it applies (NLAM_TUNE_LIN_GEMM)
+extern long lin_gemm_big_rows;                                     // rows from which it uses 128-row tiles
 }  // namespace nlam_detail
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -181,6 +183,24 @@ constexpr int kMaxGridBlocks = kNumCUs;            // one persistent workgroup p
 constexpr int kMaxWidth = 64;                      // widest hidden/output width of the narrow (weights-in-LDS) kernels
 
 __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// XCD-aware tile placement (round 5).  Workgroup b of a grid runs on XCD b % 8 (observed on gfx950, not promised: used for
+// speed only -- MI355X_MICROARCH.md "Workgroup dispatch") and every XCD has its own 4 MiB L2.  The tile schedules below deal
+// tile t to "slot" t % g; with slot == blockIdx.x consecutive tiles -- consecutive receivers of the CSR order, whose senders are
+// their neighbours on the mesh -- went to eight different L2s and every XCD fetched the whole node table (TCC_HIT 55 %, 1.36x the
+// algorithmic HBM bytes on the m2m edge backward).  xcd_slot gives the workgroups of XCD x the contiguous slot
+// range [x g / 8, (x + 1) g / 8): an XCD then works on an eighth of the receivers (per wave round).
+#ifndef NLAM_XCD_REMAP
+#define NLAM_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int xcd_slot(int b, int g) {
+#if NLAM_XCD_REMAP
+    const int x = b & 7, base = g >> 3, rem = g & 7;   // XCD y owns base + (y < rem) workgroups: b = y, y + 8, ...
+    return x * base + (x < rem ? x : rem) + (b >> 3);
+#else
+    return b;
+#endif
+}
 
 // Order the wave's own LDS traffic (cross-lane exchange through LDS inside one
 // wave; other waves of the block are at unrelated points, so no s_barrier).
@@ -1445,7 +1465,7 @@ __device__ __forceinline__ void mlp_fwd_bf_body(const nlam_mlp_fwd_t& p, const i
 
 template <int HB, int OB, int NS, bool RAG, bool RES, bool PRE = false, bool CAT = false>
 __global__ __launch_bounds__(kFwdThreads) void mlp_fwd_bf_kernel(const nlam_mlp_fwd_t p) {
-    mlp_fwd_bf_body<HB, OB, NS, RAG, RES, PRE, CAT>(p, (int)blockIdx.x, (int)gridDim.x);
+    mlp_fwd_bf_body<HB, OB, NS, RAG, RES, PRE, CAT>(p, xcd_slot((int)blockIdx.x, (int)gridDim.x), (int)gridDim.x);
 }
 
 struct fwd_group_t {
@@ -2548,7 +2568,7 @@ __device__ __forceinline__ void mlp_bwd_fast_body(const nlam_mlp_bwd_t& p, const
 
 template <int HB, int OB, int NS, bool RO = false>
 __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_fast_kernel(const nlam_mlp_bwd_t p) {
-    mlp_bwd_fast_body<HB, OB, NS, false, kWavesPerBlock, RO>(p, (int)blockIdx.x, (int)gridDim.x);
+    mlp_bwd_fast_body<HB, OB, NS, false, kWavesPerBlock, RO>(p, xcd_slot((int)blockIdx.x, (int)gridDim.x), (int)gridDim.x);
 }
 
 struct bwd_group_t {
@@ -2684,7 +2704,7 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_dma_kernel(const nlam_wgr
         }
     };
 
-    long ch = blockIdx.x;
+    long ch = xcd_slot((int)blockIdx.x, (int)gridDim.x);   // chunk c -> slot c % g: the rows an XCD gathers stay in an eighth of the tables
     int buf = 0;
     int ix[2][NLAM_MAX_SRC];
     if (ch < total_chunks) {
@@ -3724,6 +3744,197 @@ __device__ __forceinline__ void pack_item_store(u32x4* dst, const PackItem& it) 
     for (int p = 0; p < NS; ++p) dst[(size_t)p * it.tstride + it.slot] = f.t[p];
 }
 
+// ---------------------------------------------------------------------------
+// nlam_linear, widths above 64: an LDS-tiled GEMM (round 5; replaces linear_bfw_kernel wherever n % 128 == 0).
+//   out[r][h] (+)= sum_c x[r][c] A[h][c],   A[h][c] = W[h ldn + c ldk]
+// linear_bfw_kernel gave one wave a 32-row x 64-feature strip with its rows in registers and ONLY the weights in LDS: every
+// MFMA fetched its own 1-KiB A fragment (LDS 128 B/clk/CU at one term: half the array's rate for 8 % of the matrix peak,
+// 163 us for 63 784 x 512 x 512), x was re-read once per 64 output columns, and a launch of 6 561 rows was a latency chain
+// of 8 K chunks behind one staging barrier each.  Here:
+//  * a workgroup of 2 x 2 waves owns a tile of BN = 128 features x BM = 64 WN rows; wave (wm, wn) owns 2 feature blocks x WN
+//    row blocks of 32 x 32 (the weights stay the A operand and the rows the N side, as everywhere in this file);
+//  * BOTH operands go through LDS as split-bf16 fragments in fragment order (pack_item_load / pack_item_store: the routine
+//    that writes the weight images), so each A fragment feeds WN MFMAs per product and each B fragment two, and every fetch is
+//    a linear ds_read_b128;
+//  * K runs in chunks of 32 columns through two buffers: the next chunk's fp32 pieces are requested into registers AHEAD of
+//    this chunk's MFMAs and split + stored behind them; one barrier per chunk;
+//  * x is read once per 128 output columns, and the workgroups that share a row tile are dealt to ONE XCD (ids 8 apart), so
+//    the second to fourth of them find it in that XCD's L2;
+//  * WN = 2 (128 x 128 tiles) for the grid-level products (63 784 rows: HBM-bound on fp32 in / out), WN = 1 (64 rows) for the
+//    mesh-level ones (6 561 rows: 412 workgroups instead of 208 strips).
+// Rounding: the same split products in the same K order per 32-column chunk as the kernels it replaces; the fp32 sums are
+// grouped per chunk (two K steps), so results agree with linear_bfw_kernel to fp32 rounding, not bit for bit.
+// ---------------------------------------------------------------------------
+constexpr int kLinGemmThreads = 256;
+template <int NS, int WN>
+__host__ __device__ constexpr size_t lin_gemm_lds_bytes() {
+    return ((size_t)2 * NS * 4 * 2 * 64 + (size_t)2 * NS * (2 * WN) * 2 * 64) * 16 + (size_t)4 * 32 * kStgStride * sizeof(float);
+}
+
+// TA: the weight operand is read transposed (ldn == 1: the data-gradient product, A[h][c] = W[h + c ldk]: eight dword loads per
+// fragment slot, each coalesced across the 32 features of a block) instead of along K (ldk == 1: two 16-byte loads).
+template <int NS, int WN, bool TA>
+__global__ __launch_bounds__(kLinGemmThreads) void linear_gemm_kernel(const nlam_linear_t p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int WM = 2;                       // feature blocks per wave
+    constexpr int S = 2;                        // K = 16 steps per 32-column chunk
+    constexpr int MBA = 2 * WM, MBB = 2 * WN;   // 32-row fragment blocks of the workgroup's A (features) / B (rows) tile
+    constexpr int BN = 32 * MBA, BM = 32 * MBB;
+    constexpr size_t kAv = (size_t)NS * MBA * S * 64, kBv = (size_t)NS * MBB * S * 64;   // u32x4 per buffer
+    u32x4* As = reinterpret_cast<u32x4*>(smem);                    // [2][NS][MBA][S][64]
+    u32x4* Bs = As + 2 * kAv;                                      // [2][NS][MBB][S][64]
+    float* stg_all = reinterpret_cast<float*>(Bs + 2 * kBv);       // 4 x 32 x kStgStride
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int j = lane & 31, hi = lane >> 5;
+    float* stg = stg_all + (size_t)wave * 32 * kStgStride;
+
+    // workgroup id -> (row tile, feature tile): row tile = 8 * (id / (8 nftt)) + id % 8, so that the nftt workgroups of a row
+    // tile have ids 8 apart = the same XCD, and are dispatched within one wave of the grid
+    const int nft = p.n / BN;
+    const int nftt = nft * (p.W2 != nullptr ? 2 : 1);
+    const long id = blockIdx.x;
+    const long rt = 8 * (id / (8 * (long)nftt)) + (id & 7);
+    int ft = (int)((id >> 3) % nftt);
+    const long r0 = rt * BM;
+    if (r0 >= p.rows) return;   // the padding of the last group of eight row tiles
+    const float* Wm = p.W;
+    float* outm = p.out;
+    if (ft >= nft) {
+        ft -= nft;
+        Wm = p.W2;
+        outm = p.out2;
+    }
+    const int mrows = (int)min((long)BM, p.rows - r0);
+    const float* Wp = Wm + (long)(ft * BN) * p.ldn;
+    const float* xp = p.x + r0 * p.k;
+    const int KC = p.k >> 5;
+
+    // staging: thread -> fragment slot (block mb = wave / 2 + 2 q, K step st = wave % 2, lane) of the A tile and of the B
+    // tile: the slot's 8 floats are row (32 mb + j), columns 16 st + 8 hi .. + 7 of the chunk.  No branch anywhere: rows past
+    // the end of x read the last row and are zeroed by a select.
+    const int sst = wave & 1, smb = wave >> 1;
+    const float* a_src[WM];
+    const float* b_src[WN];
+    bool b_live[WN];
+#pragma unroll
+    for (int q = 0; q < WM; ++q) {
+        const int m = 32 * (smb + 2 * q) + j;
+        a_src[q] = TA ? Wp + m + (long)(16 * sst + 8 * hi) * p.ldk : Wp + (long)m * p.ldn + 16 * sst + 8 * hi;
+    }
+#pragma unroll
+    for (int q = 0; q < WN; ++q) {
+        const int r = 32 * (smb + 2 * q) + j;
+        b_live[q] = r < mrows;
+        b_src[q] = xp + (long)min(r, mrows - 1) * p.k + 16 * sst + 8 * hi;
+    }
+    float ia[WM][8], ib[WN][8];
+    auto request = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < WM; ++q) {
+            if constexpr (TA) {
+                const float* src = a_src[q] + (long)(32 * kc) * p.ldk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ia[q][e] = src[(long)e * p.ldk];
+            } else {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(a_src[q] + 32 * kc);
+                const f32x4 up = *reinterpret_cast<const f32x4*>(a_src[q] + 32 * kc + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ia[q][e] = lo[e], ia[q][4 + e] = up[e];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < WN; ++q) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(b_src[q] + 32 * kc);
+            const f32x4 up = *reinterpret_cast<const f32x4*>(b_src[q] + 32 * kc + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ib[q][e] = lo[e], ib[q][4 + e] = up[e];
+        }
+    };
+    auto publish = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < WM; ++q) {
+            const BfFrag<NS> f = split8<NS>(ia[q]);
+#pragma unroll
+            for (int t = 0; t < NS; ++t) As[(size_t)buf * kAv + (((size_t)t * MBA + (smb + 2 * q)) * S + sst) * 64 + lane] = f.t[t];
+        }
+#pragma unroll
+        for (int q = 0; q < WN; ++q) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = b_live[q] ? ib[q][e] : 0.f;
+            const BfFrag<NS> f = split8<NS>(x);
+#pragma unroll
+            for (int t = 0; t < NS; ++t) Bs[(size_t)buf * kBv + (((size_t)t * MBB + (smb + 2 * q)) * S + sst) * 64 + lane] = f.t[t];
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mb = 0; mb < WM; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < WN; ++nb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mb][nb][q] = 0.f;
+
+    request(0);
+    publish(0);
+    __syncthreads();
+    for (int kc = 0; kc < KC; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < KC) request(kc + 1);   // in flight during this chunk's MFMAs
+        const u32x4* Ab = As + (size_t)buf * kAv;
+        const u32x4* Bb = Bs + (size_t)buf * kBv;
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            // every fragment of the step in its own registers before the first MFMA (DESIGN finding 3), accumulators alternate
+            u32x4 a[NS][WM], b[NS][WN];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+#pragma unroll
+                for (int mb = 0; mb < WM; ++mb) a[t][mb] = Ab[(((size_t)t * MBA + (wm * WM + mb)) * S + st) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < WN; ++nb) b[t][nb] = Bb[(((size_t)t * MBB + (wn * WN + nb)) * S + st) * 64 + lane];
+            }
+#pragma unroll
+            for (int ord = NS - 1; ord >= 0; --ord)
+#pragma unroll
+                for (int pa = 0; pa <= ord; ++pa)
+#pragma unroll
+                    for (int nb = 0; nb < WN; ++nb)
+#pragma unroll
+                        for (int mb = 0; mb < WM; ++mb) acc[mb][nb] = MFMA_BF16(a[pa][mb], b[ord - pa][nb], acc[mb][nb]);
+        }
+        if (kc + 1 < KC) publish(buf ^ 1);   // the other buffer: everyone left it at the previous barrier
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulator blocks -> whole 128-B row pieces through the wave's staging block ----
+#pragma unroll
+    for (int nb = 0; nb < WN; ++nb) {
+        const long rb = r0 + (long)(wn * WN + nb) * 32;
+        const int nrows = (int)max((long)0, min((long)32, p.rows - rb));
+#pragma unroll
+        for (int mb = 0; mb < WM; ++mb) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(&stg[j * kStgStride + 8 * tt + 4 * hi]) = acc_chunk(acc[mb][nb], tt);
+            wave_lds_sync();
+            float* obase = outm + rb * p.n + (long)ft * BN + (wm * WM + mb) * 32;
+            for (int base = 0; base < nrows * 8; base += 64) {
+                const int item = base + lane;
+                if (item < nrows * 8) {
+                    const int rr = item >> 3, c4 = item & 7;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&stg[rr * kStgStride + 4 * c4]);
+                    float* d = obase + (size_t)rr * p.n + 4 * c4;
+                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(d);
+                    *reinterpret_cast<f32x4*>(d) = v;
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
 // thread `tid` of the job's grid takes lane item `tid` of every piece (<= 512 items each; nlam_mlp_pack launches 512 threads per job, as eight single-wave workgroups)
 template <int NS>
 __device__ void pack_job(const nlam_pack_job_t& j, const PackShape& sh, int tid, int nthr) {
@@ -4169,6 +4380,8 @@ __global__ void pack_bf_table_kernel(const nlam_pack_rec_t* recs) {
 int nlam_detail::wbf_min_supertiles = 192;
 int nlam_detail::wbf_half = 1;              // bit 0: forward, bit 1: backward on 4-wave workgroups, two per CU (NLAM_TUNE_WBF_HALF)
 int nlam_detail::lin_resident_wgs = 256;    // NLAM_LIN_WGS (experiments): one per CU
+int nlam_detail::lin_gemm = 1;              // nlam_linear: LDS-tiled GEMM for n % 128 == 0 (0: the strip kernel of rounds 2-4, for A/B)
+long nlam_detail::lin_gemm_big_rows = 32768;   // 128-row tiles from here (63 784 grid nodes), 64-row tiles below (6 561 mesh nodes)
 int nlam_detail::wgrad_big_min_rows = 0;    // rows from which a wide weight gradient uses 256 x 256 windows (0 = always, the round-2 behaviour)
 int nlam_detail::wgrad_min_parts = 128;     // row slices a weight gradient of more than that many 32-row chunks is cut into at least
 int nlam_detail::wgrad_chunks_per_wg = 8;   // A/B at cfg2 (tools/ab_bench.sh): 2.13 -> 2.06 ms per step against one chunk per workgroup
@@ -4222,6 +4435,12 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_WGRAD_CHUNKS) {
         if (value < 1) return NLAM_EINVAL;
         nlam_detail::wgrad_chunks_per_wg = value;
+        return 0;
+    }
+    if (key == NLAM_TUNE_LIN_GEMM) {
+        if (value < 0) return NLAM_EINVAL;
+        nlam_detail::lin_gemm = value != 0 ? 1 : 0;
+        if (value > 1) nlam_detail::lin_gemm_big_rows = value;   // values above 1: also the row count from which 128-row tiles are used
         return 0;
     }
     return NLAM_EINVAL;
@@ -5333,6 +5552,18 @@ int32_t nlam_pre_add_supported(const nlam_mlp_fwd_t* p) {
     return (k % 64 == 0 && p->hid % 64 == 0) ? 1 : 0;
 }
 
+// operand layout the LDS-tiled GEMM can read: 1 = along K (ldk == 1, 16-byte aligned rows: the forward product), 2 = transposed
+// (ldn == 1: the data-gradient product), 0 = neither (the strip kernel reads any strides)
+static int lin_gemm_layout(const nlam_linear_t* p) {
+    auto ok = [&](const float* W) {
+        if (p->ldk == 1) return (p->ldn % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) ? 1 : 0;
+        return p->ldn == 1 ? 2 : 0;
+    };
+    const int a = ok(p->W);
+    if (p->W2 != nullptr && ok(p->W2) != a) return 0;
+    return a;
+}
+
 int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream) {
     NLAM_RANGE("nlam_linear");
     if (p == nullptr || p->x == nullptr || p->W == nullptr || p->out == nullptr || p->rows < 0 || p->k < 1 || p->n < 1) return NLAM_EINVAL;
@@ -5363,7 +5594,37 @@ int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream) {
     else if (KB == 2 && MB == 1) NLAM_LAUNCH_LIN(2, 1);
     else if (KB == 1 && MB == 2) NLAM_LAUNCH_LIN(1, 2);
     else if (KB == 2 && MB == 2) NLAM_LAUNCH_LIN(2, 2);
-    else if (p->k % 64 == 0 && p->n % 64 == 0 && p->k <= kMaxWide && p->n <= kMaxWide) {
+    else if (nlam_detail::lin_gemm != 0 && p->n % 128 == 0 && p->k <= kMaxWide && p->n <= kMaxWide && lin_gemm_layout(p) != 0) {
+        // LDS-tiled GEMM (linear_gemm_kernel): 128 x 128 tiles from 32 768 rows, 64-row tiles below
+        const bool ta = lin_gemm_layout(p) == 2;
+        const bool big = p->rows >= nlam_detail::lin_gemm_big_rows;
+        const long bm = big ? 128 : 64;
+        const long nrt = (p->rows + bm - 1) / bm;
+        const long nftt = (long)(p->n / 128) * (p->W2 != nullptr ? 2 : 1);
+        const long nwg = (nrt + 7) / 8 * 8 * nftt;
+        if (nwg > 0x7fffffffL) return NLAM_EUNSUP;
+#define NLAM_LAUNCH_LING1(NS_, WN_, TA_)                                                                             \
+    do {                                                                                                             \
+        const size_t glds = lin_gemm_lds_bytes<NS_, WN_>();                                                          \
+        int rc = set_lds(linear_gemm_kernel<NS_, WN_, TA_>, glds);                                                   \
+        if (rc != 0) return rc;                                                                                      \
+        hipLaunchKernelGGL((linear_gemm_kernel<NS_, WN_, TA_>), dim3((unsigned)nwg), dim3(kLinGemmThreads), glds, stream, *p); \
+    } while (0)
+#define NLAM_LAUNCH_LING(NS_, WN_)                    \
+    do {                                              \
+        if (ta) NLAM_LAUNCH_LING1(NS_, WN_, true);    \
+        else NLAM_LAUNCH_LING1(NS_, WN_, false);      \
+    } while (0)
+        if (big) {
+            if (ns == 3) NLAM_LAUNCH_LING(3, 2);
+            else if (ns == 2) NLAM_LAUNCH_LING(2, 2);
+            else NLAM_LAUNCH_LING(1, 2);
+        } else {
+            if (ns == 3) NLAM_LAUNCH_LING(3, 1);
+            else if (ns == 2) NLAM_LAUNCH_LING(2, 1);
+            else NLAM_LAUNCH_LING(1, 1);
+        }
+    } else if (p->k % 64 == 0 && p->n % 64 == 0 && p->k <= kMaxWide && p->n <= kMaxWide) {
         // 64 x 64 weight blocks streamed through two LDS buffers (linear_bfw_kernel)
         const int kc_all = p->k / 64;
         const bool resident = kc_all <= kLinResidentChunks && nlam_detail::lin_resident_wgs > 0;   // the output pair's whole weight strip stays in LDS

@@ -151,10 +151,16 @@ class FusedMLP(nn.Sequential):
     _wpad = None
 
     def _padded_input(self, x):
-        key = (x.data_ptr(), tuple(x.shape), x._version)
-        if self._xpad is None or self._xpad[0] != key:
-            self._xpad = (key, torch.nn.functional.pad(x.detach(), (0, -x.shape[-1] % 4)).contiguous())
-        return self._xpad[1]
+        """Zero-padded copy of ``x``, cached for as long as the caller keeps handing in THE SAME tensor object unmodified (the
+        registered static-feature buffers: graph/base.py:286-295).  The key is object identity through a weak reference plus
+        the version counter -- never the address: a fresh activation that the caching allocator places where an earlier one
+        lived is another tensor and is padded again (advisor finding, round 4: 16 stale hits out of 20 tensors by address)."""
+        import weakref
+
+        c = self._xpad
+        if c is None or c[0]() is not x or c[2] != x._version:
+            c = self._xpad = (weakref.ref(x), torch.nn.functional.pad(x.detach(), (0, -x.shape[-1] % 4)).contiguous(), x._version)
+        return c[1]
 
     def _padded_weight(self, W):
         """Persistent (hid, padded width) buffer: its address is what the weight packer keys on."""
@@ -240,7 +246,10 @@ def _suffix_geometry(geom: MlpGeometry, srcs):
     if "suffix" not in cache:
         idx = [geom.src_idx[k] if k < len(geom.src_idx) else None for k in range(keep)] + [None]
         dm = [geom.dmode[k] for k in range(keep)] + [1]
-        g = dataclasses.replace(geom, nsrc=keep + 1, src_idx=idx + [None] * (3 - len(idx)), dmode=dm + [1] * (3 - len(dm)))
+        # residual sources ride along with a per-call zero-padded first weight (torch.cat in forward_fused): a temporary the
+        # trainer's weight packer must never register -- it keys on, and re-reads at the start of every later step, the address
+        g = dataclasses.replace(geom, nsrc=keep + 1, src_idx=idx + [None] * (3 - len(idx)), dmode=dm + [1] * (3 - len(dm)),
+                                no_pack=bool(geom.no_pack or keep > 0))
         g.__dict__.pop("_derived", None)
         cache["suffix"] = g
     return cache["suffix"], tuple(srcs[:keep])

@@ -36,6 +36,26 @@ def set_matmul_mode(mode: str):
     MATMUL_MODE = mode
 
 
+# Matrix mode of the BACKWARD launches (data-gradient kernels and wide weight gradients) when it differs from the forward's:
+# "bf16x3" forward + "bf16x2" backward or the reverse (NLAM_MATMUL_BWD; None = the forward's mode).  Outside autocast only.
+MATMUL_MODE_BWD = os.environ.get("NLAM_MATMUL_BWD") or None
+
+
+def _bwd_flags(mm_flags: int) -> int:
+    """Matrix-path bits of the backward launches of a forward that ran with ``mm_flags``."""
+    if MATMUL_MODE_BWD is None or mm_flags in (0, _MM_FLAGS["bf16"]) or torch.is_autocast_enabled("cuda"):
+        return mm_flags
+    return _MM_FLAGS[MATMUL_MODE_BWD]
+
+
+def _bwd_pack(pack, mm_flags, bflags, *key):
+    """The packer entry whose BACKWARD image has the backward's term count (``key`` = PACKER.get's arguments before the
+    flags): the forward's own entry unless the two modes differ."""
+    if pack is None or bflags == mm_flags or PACKER is None:
+        return pack
+    return PACKER.get(*key, bflags)
+
+
 def _mm_flags() -> int:
     """Matrix-path bits for a launch.  Under ``torch.autocast`` (Lightning ``--precision bf16-mixed``,
     SURVEY.md section 8b "precision contract") the fused MLPs do what autocast does to the reference's
@@ -124,13 +144,25 @@ class _WgradOverlap:
         self.capturing = False
         self.keep = []
 
-    def begin(self):
+    def begin(self, deferred=None):
+        """``deferred``: an object with ``fork(k, fn, dead_end)`` / ``finish()`` (trainer._SegmentedCapture).  With it the side
+        work is not launched here at all: every fork is handed over as (side-stream index, closure) and the trainer records
+        it into graphs of its own, replayed beside the chain's (DESIGN.md finding 39)."""
         if not self.streams:
             self.streams = [torch.cuda.Stream() for _ in range(max(1, self.NSTREAMS))]
         self.active = True
         self.assigned = {}
         self.keep = []
+        self.deferred = deferred
         self.capturing = torch.cuda.is_current_stream_capturing()
+
+    deferred = None
+
+    def index_for(self, owner):
+        k = self.assigned.get(id(owner))
+        if k is None:
+            k = self.assigned[id(owner)] = len(self.assigned) % len(self.streams)
+        return k
 
     def stream_for(self, owner):
         """Side streams are dealt round-robin over the fused MLPs in the order backward first meets them: on a single
@@ -139,10 +171,7 @@ class _WgradOverlap:
         a function of the MLP (``owner`` = its first weight), not of the call: in a rollout the same parameters are
         back-propagated once per AR step, and the read-modify-write accumulations into one ``.grad`` must stay ordered
         on one stream (two streams = lost updates)."""
-        k = self.assigned.get(id(owner))
-        if k is None:
-            k = self.assigned[id(owner)] = len(self.assigned) % len(self.streams)
-        return self.streams[k]
+        return self.streams[self.index_for(owner)]
 
     def hold(self, side, *tensors):
         """Tensors the side stream reads must outlive its kernels.  Eager: ``record_stream`` hands that to the
@@ -157,12 +186,18 @@ class _WgradOverlap:
             else:
                 t.record_stream(side)
 
-    def run(self, owner, hold, fn):
+    def run(self, owner, hold, fn, dead_end=False):
         """``fn()`` (launches that read the tensors ``hold``) on ``owner``'s side stream, ordered behind everything enqueued on
         the current stream so far.  (Issuing the fork only after the chain's NEXT kernel was enqueued -- so that a captured
         graph keeps the chain on one hardware queue: the executor leaves a node's first child on the node's queue -- was
         measured in round 4: the chain did stay on one queue and lost its 12 us hop gaps, but every fork landed on ONE other
         queue in reverse order: cfg2 1.77 -> 2.08 ms; forks batched two to six at a time 1.89 - 2.02 ms.)"""
+        if self.deferred is not None:
+            # the tensors the closure reads stay referenced until every side graph has been recorded: inside the chain's
+            # private pool a released block would be handed to a later chain kernel while the side graph still reads it
+            self.keep.extend(t for t in hold if t is not None)
+            self.deferred.fork(self.index_for(owner), fn, dead_end)
+            return
         side = self.stream_for(owner)
         side.wait_stream(torch.cuda.current_stream())
         self.hold(side, *hold)
@@ -170,6 +205,14 @@ class _WgradOverlap:
             fn()
 
     def end(self):
+        if self.deferred is not None:
+            d, self.deferred = self.deferred, None
+            try:
+                d.finish()
+            finally:
+                self.keep = []
+                self.active = False
+            return
         if self.active:
             for st in self.streams:
                 torch.cuda.current_stream().wait_stream(st)
@@ -307,6 +350,9 @@ PACKER = None
 
 
 def _stream():
+    d = OVERLAP.deferred
+    if d is not None and d.cut_pending:   # trainer._SegmentedStep: a chain segment ends in front of this launch
+        d.do_cut()
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -513,7 +559,8 @@ class FusedMLPFunction(torch.autograd.Function):
         p.ln_w, p.ln_b = _ptr(ln_w), _ptr(ln_b)
         p.eps, p.hid, p.dout, p.flags = 1e-5, hid, dout, geom.flags | mm_flags
         p.ldw1 = kin if pre else 0
-        ctx.mm_flags = mm_flags
+        bflags = _bwd_flags(mm_flags)
+        ctx.mm_flags = bflags   # backward reads nothing else
         out = aggr = None
         if geom.want_out:
             out_rows = geom.out_rows if geom.out_rows is not None else rows
@@ -556,6 +603,7 @@ class FusedMLPFunction(torch.autograd.Function):
             pack = PACKER.get(W1c, W2c, widths, hid, dout, pre, kin if pre else 0, mm_flags)
             if pack is not None:
                 p.wpack, p.wpack_floats = pack.fwd.data_ptr(), pack.fwd.numel()
+            pack = _bwd_pack(pack, mm_flags, bflags, W1c, W2c, widths, hid, dout, pre, kin if pre else 0)
         ctx.pack = pack
         key = ("mlp_fwd", rows * B, kin, hid, dout, geom.nsrc, bool(geom.aggregate), need_grad)
 
@@ -839,7 +887,7 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     # parameter gradients (see _WgradOverlap); an MLP none of whose inputs needs a gradient is a dead end of backward, so
     # its data-gradient kernel goes there as well.
     if whole_side:
-        OVERLAP.run(prm[0], (g_out, g_aggr, xhat, rstd, wpack, dz1, dz2, vecp, z1, *bases), lambda: (launch_data(), launch_weights()))
+        OVERLAP.run(prm[0], (g_out, g_aggr, xhat, rstd, wpack, dz1, dz2, vecp, z1, *bases), lambda: (launch_data(), launch_weights()), dead_end=True)
     elif on_side:
         OVERLAP.run(prm[0], (dz1, dz2, vecp, z1, *bases), launch_weights)
     else:
@@ -975,7 +1023,7 @@ class ChunkedMLPFunction(torch.autograd.Function):
         if geom.rowptr is not None:
             aggr = segment_sum(out, R * dout, geom.rowptr, geom.perm, geom.inv_deg if geom.mean else None, geom.num_rec, dout, B)
         if need_grad:
-            ctx.geom, ctx.B, ctx.nchunks, ctx.mm_flags, ctx.has_ln = geom, B, nchunks, mm_flags, has_ln
+            ctx.geom, ctx.B, ctx.nchunks, ctx.mm_flags, ctx.has_ln = geom, B, nchunks, _bwd_flags(mm_flags), has_ln
             ctx.win_meta = [(w[1], w[2]) for w in win]
             ctx.src_shapes = [tuple(s.shape) for s in srcs]
             ctx.params = params
@@ -1369,6 +1417,7 @@ class GroupedMLPFunction(torch.autograd.Function):
                 pack = PACKER.get(W1c, W2c, [kin], hid, dout, False, 0, mm_flags)
                 if pack is not None:
                     p.wpack, p.wpack_floats = pack.fwd.data_ptr(), pack.fwd.numel()
+                pack = _bwd_pack(pack, mm_flags, _bwd_flags(mm_flags), W1c, W2c, [kin], hid, dout, False, 0)
             packs.append(pack)
             out = torch.empty((B, rows, dout), device=dev, dtype=torch.float32)
             p.out, p.out_bstride = _ptr(out), rows * dout
@@ -1420,7 +1469,7 @@ class GroupedMLPFunction(torch.autograd.Function):
         if need_grad:
             ctx.lw = lw
             ctx.packs = packs
-            ctx.n, ctx.params, ctx.saved, ctx.mm_flags = n, params, saved, mm_flags
+            ctx.n, ctx.params, ctx.saved, ctx.mm_flags = n, params, saved, _bwd_flags(mm_flags)
             ctx.set_materialize_grads(False)
             if GRAD_LISTENER is not None:
                 GRAD_LISTENER.note_use([q for pr in params for q in pr if q is not None and q.requires_grad])
@@ -2081,7 +2130,8 @@ class CatMLPFunction(torch.autograd.Function):
             ctx.twin_of = {}
             ctx.has_ln = ln_w is not None
             ctx.param_refs = (W1, b1, W2, b2, ln_w, ln_b)
-            ctx.mm_flags, ctx.pack = mm_flags, pack
+            bflags = _bwd_flags(mm_flags)
+            ctx.mm_flags, ctx.pack = bflags, _bwd_pack(pack, mm_flags, bflags, W1c, W2c, [kin], hid, dout, False, 0)
             ctx.widths, ctx.piece_shapes = widths, [tuple(x.shape) for x in pieces]
             if GRAD_LISTENER is not None:
                 GRAD_LISTENER.note_use([q_ for q_ in ctx.param_refs if q_ is not None and q_.requires_grad])

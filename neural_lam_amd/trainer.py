@@ -26,6 +26,8 @@ MI355X-first choices:
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -204,6 +206,174 @@ class GradBuckets:
         self._wait_all()
 
 
+class _SegmentedStep:
+    """The captured training step as a CHAIN of HIP graphs on one high-priority stream plus weight-gradient graphs on side
+    streams (DESIGN.md finding 39).
+
+    Why not one graph with forks: the HIP-graph executor of ROCm 7.2 gives the k-th child of a node hardware queue
+    ``(queue + k) mod 4`` (finding 38).  With the weight gradients of a fused MLP forked behind its data-gradient kernel the
+    backward chain changes queue at every MLP (a 12 us signal gap instead of a 5 us back-to-back launch: 1 275 us of backward
+    chain at cfg2 against 908 us on one queue), and every fork order that keeps the chain on one queue starts the side work
+    late and in reverse.  Here the executor never sees a fork:
+
+    * the chain -- zero-grad, weight packing, forward, loss, every data-gradient kernel -- is recorded as ``S`` LINEAR graphs
+      (segments), replayed back to back on ONE stream of high priority (its own hardware queue: ROCclr keeps a queue pool per
+      priority, so no side stream shares it);
+    * a fork point (``ops.OVERLAP.run``) records nothing: its closure is kept, and after ``K`` fork points (or behind a
+      dead-end MLP, whose data-gradient kernel is side work too) the chain segment is closed;
+    * after the chain has been recorded the closures of segment ``i`` are recorded into one linear graph per side stream
+      ``k`` (the side stream is a function of the MLP, so a rollout's read-modify-write accumulations stay ordered); at
+      replay stream ``k`` waits for the event recorded behind chain segment ``i`` and launches its graph: weight gradients
+      of segment ``i`` run beside chain segment ``i + 1``, in order, from ordinary stream / event semantics;
+    * the optimizer is a last graph behind the join (``1 / world`` folded in: at world > 1 the gradient all-reduce runs
+      between the join and it, bucket by bucket as the segments that complete a bucket finish).
+
+    Chain graphs share one private memory pool (they replay in recording order on one stream); the side graphs have
+    their own: they run concurrently with later chain segments, so a block the chain has released must not be theirs.
+    Everything a side closure reads is referenced until the last side graph is recorded (``ops.OVERLAP.keep``).
+    """
+
+    def __init__(self, trainer, forks_per_segment: int):
+        self.tr = trainer
+        self.K = max(1, int(forks_per_segment))
+        self.chain = []            # CUDAGraph per segment
+        self.jobs = [[]]           # per segment: [(side stream index, closure)]
+        self.side = []             # per segment: {stream index: CUDAGraph}
+        self.events = []           # per segment: event recorded behind the chain segment (None: no side work)
+        self.done_events = []      # per segment: {stream index: event recorded behind the side graph}
+        self.tail = None           # the optimizer's graph (world == 1 or a capturable optimizer), replayed behind the join
+        self.cur = None
+        self.nforks = 0
+        self.pool = torch.cuda.graph_pool_handle()
+        self.side_pool = torch.cuda.graph_pool_handle()
+        self.seg_params = []       # per segment: ids of the parameters whose gradients its side work completed
+        self.loss = None
+        self.mode = "relaxed"      # capture error mode: segments are closed / opened from inside autograd's backward
+
+    # ---- recording ----
+    def _begin_segment(self):
+        self.cur = torch.cuda.CUDAGraph()
+        self.cur.capture_begin(pool=self.pool, capture_error_mode=self.mode)
+
+    def _end_segment(self):
+        g, self.cur = self.cur, None
+        g.capture_end()
+        self.chain.append(g)
+
+    cut_pending = False
+
+    def fork(self, k, fn, dead_end=False):
+        self.jobs[-1].append((k, fn))
+        self.nforks += 1
+        if dead_end or len(self.jobs[-1]) >= self.K:
+            # the segment is closed in front of the chain's NEXT library launch (ops._stream calls do_cut): a cut behind the
+            # last launch of backward would leave an empty graph, and torch ops in between (gradient accumulation) stay with
+            # the segment that produced their operands
+            self.cut_pending = True
+
+    def do_cut(self):
+        self.cut_pending = False
+        self._end_segment()
+        self.jobs.append([])
+        self._begin_segment()
+
+    def finish(self):
+        """Called by ops.OVERLAP.end() right behind loss.backward(), still inside ops.direct_param_grads(): close the last
+        chain segment, then record the side graphs."""
+        self.cut_pending = False
+        self._end_segment()
+        from . import ops
+
+        streams = ops.OVERLAP.streams
+        listener = _DoneRecorder()
+        prev_listener, ops.GRAD_LISTENER = ops.GRAD_LISTENER, listener
+        try:
+            for seg in self.jobs:
+                graphs = {}
+                listener.cur = set()
+                for k in sorted({k for k, _ in seg}):
+                    with torch.cuda.stream(streams[k]):
+                        g = torch.cuda.CUDAGraph()
+                        g.capture_begin(pool=self.side_pool, capture_error_mode=self.mode)
+                        try:
+                            for kk, fn in seg:
+                                if kk == k:
+                                    fn()
+                        finally:
+                            g.capture_end()
+                    graphs[k] = g
+                self.side.append(graphs)
+                self.events.append(torch.cuda.Event())
+                self.done_events.append({k: torch.cuda.Event() for k in graphs})
+                self.seg_params.append(listener.cur)
+        finally:
+            ops.GRAD_LISTENER = prev_listener
+        self.jobs = None   # the closures (and what they reference) are not needed again
+        last = {}          # the join: behind the LAST graph of every side stream that runs one
+        for i, graphs in enumerate(self.side):
+            for k in graphs:
+                last[k] = self.done_events[i][k]
+        self.join_events = list(last.values())
+
+    def abort(self):
+        if self.cur is not None:
+            try:
+                self.cur.capture_end()
+            except Exception:
+                pass
+            self.cur = None
+
+    # ---- replay ----
+    def replay(self, between=None):
+        """``between(i)``: called behind the launch of segment ``i``'s side graphs (the trainer launches gradient buckets that
+        segment completes from it)."""
+        from . import ops
+
+        tr = self.tr
+        cs = tr._chain_stream
+        streams = ops.OVERLAP.streams
+        cur = torch.cuda.current_stream()
+        tr._entry_event.record(cur)
+        cs.wait_event(tr._entry_event)
+        with torch.cuda.stream(cs):
+            for i, g in enumerate(self.chain):
+                g.replay()
+                graphs = self.side[i]
+                if graphs or between is not None:
+                    self.events[i].record(cs)
+                for k, sg in graphs.items():
+                    st = streams[k]
+                    st.wait_event(self.events[i])
+                    with torch.cuda.stream(st):
+                        sg.replay()
+                        self.done_events[i][k].record(st)
+                if between is not None:
+                    between(i)
+            for ev in self.join_events:
+                cs.wait_event(ev)
+
+    def replay_tail(self):
+        cs = self.tr._chain_stream
+        with torch.cuda.stream(cs):
+            if self.tail is not None:
+                self.tail.replay()
+            self.tr._exit_event.record(cs)
+        torch.cuda.current_stream().wait_event(self.tr._exit_event)
+
+
+class _DoneRecorder:
+    """ops.GRAD_LISTENER stand-in while the side graphs are recorded: which parameters each segment's side work completes."""
+
+    def __init__(self):
+        self.cur = set()
+
+    def note_use(self, params):
+        pass
+
+    def note_done(self, params):
+        self.cur.update(id(p) for p in params)
+
+
 class Trainer:
     """``loss = module(*batch)[-1]``; backward; bucketed all-reduce; AdamW.
 
@@ -214,13 +384,20 @@ class Trainer:
 
     def __init__(self, module: nn.Module, lr=1e-3, betas=(0.9, 0.95), weight_decay=1e-2, eps=1e-8,
                  bucket_bytes: int = 32 << 20, optimizer_factory=None, group=None, use_graph: bool = False,
-                 overlap_wgrad: bool = True, early_leaf_backward: bool | None = None, grad_comm_dtype=None):
+                 overlap_wgrad: bool = True, early_leaf_backward: bool | None = None, grad_comm_dtype=None,
+                 executor: str | None = None, forks_per_segment: int | None = None):
+        import os
+
         self.module = module
         self.use_graph = use_graph
         self.overlap_wgrad = overlap_wgrad
+        # how a captured step is replayed: "segments" = a chain of linear graphs on one high-priority stream + weight-gradient
+        # graphs on side streams (_SegmentedStep); "forks" = ONE graph whose weight-gradient branches the executor places
+        self.executor = executor or os.environ.get("NLAM_EXEC", "forks")
+        if self.executor not in ("segments", "forks"):
+            raise ValueError(f"unknown executor {self.executor!r}: 'segments' or 'forks'")
+        self.forks_per_segment = int(forks_per_segment if forks_per_segment is not None else os.environ.get("NLAM_SEG_FORKS", "3"))
         if early_leaf_backward is None:
-            import os
-
             early_leaf_backward = os.environ.get("NLAM_EARLY_LEAF", "0") == "1"
         self.early_leaf_backward = early_leaf_backward
         self._graph = None
@@ -283,19 +460,32 @@ class Trainer:
             out = self.module(*batch, **self._module_kwargs)
             loss = out[-1] if isinstance(out, tuple) else out
             ov = ops.OVERLAP if self.overlap_wgrad else None
+            seg = self._recording   # a _SegmentedStep being recorded: the forks are handed to it instead of being launched
+            if seg is not None and ov is None:
+                raise RuntimeError("the segmented executor records the weight-gradient work through ops.OVERLAP (overlap_wgrad=True)")
             if ov is not None:
-                ov.begin()
+                ov.begin(deferred=seg)
+            # a recording closes / opens stream captures from inside backward: autograd must run it on THIS thread
+            threads = torch.autograd.set_multithreading_enabled(False) if seg is not None else contextlib.nullcontext()
             try:
-                if loss.dim() == 0 and loss.dtype == torch.float32:
-                    if self._unit is None or self._unit.device != loss.device:
-                        self._unit = torch.ones((), device=loss.device, dtype=torch.float32)
-                    loss.backward(gradient=self._unit)   # a resident seed: autograd's implicit ones_like is a fill launch per step
-                else:
-                    loss.backward()
+                with threads:
+                    if loss.dim() == 0 and loss.dtype == torch.float32:
+                        if self._unit is None or self._unit.device != loss.device:
+                            self._unit = torch.ones((), device=loss.device, dtype=torch.float32)
+                        loss.backward(gradient=self._unit)   # a resident seed: autograd's implicit ones_like is a fill launch per step
+                    else:
+                        loss.backward()
+            except BaseException:
+                if seg is not None:
+                    ov.deferred = None   # no side graphs for a failed recording
+                    ov.active = False
+                raise
             finally:
                 if ov is not None:
                     ov.end()
         return loss.detach()   # nothing that references the autograd graph survives this frame
+
+    _recording = None
 
     def _fwd_bwd(self):
         return self._fwd_bwd_on(self._static_in)
@@ -339,13 +529,16 @@ class Trainer:
         torch.cuda.synchronize()
         # the warm-up's autograd graph (and its AccumulateGrad nodes, bound to the side stream) is gone here, so the
         # capture creates its own on the capture stream and accumulates in place into the flat gradient views
+        t_before = getattr(self.opt, "t", None)
+        if self.executor == "segments" and self.overlap_wgrad:
+            self._capture_segments(t_before)
+            return
         self._graph = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread may query events while this thread captures
         # world == 1: nothing sits between backward and the optimizer, so AdamW (step count resident on the device) is captured
         # too -- one launch latency less per step than enqueueing it behind the replay.  With data parallelism the gradient
         # all-reduce separates the two and stays outside the capture.
-        self._opt_in_graph = self.world == 1 and bool(getattr(self.opt, "capturable", False))
-        t_before = getattr(self.opt, "t", None)
+        self._opt_in_graph = self.world == 1 and bool(getattr(self.opt, "capturable", False)) and not self._opt_eager
         try:
             with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                 self.fp.grad.zero_()
@@ -357,17 +550,114 @@ class Trainer:
                 self.opt.t = t_before   # the capture recorded the launches without running them (also when it failed half way)
         self._opt_sig = self._opt_signature()
 
+    _chain_stream = None
+    _entry_event = None
+    _exit_event = None
+    _opt_eager = False     # the optimizer's hyper-parameters keep changing (a schedule): it runs behind the replay, uncaptured
+    _bucket_plan = None
+
+    def _capture_segments(self, t_before):
+        """Record the step as a _SegmentedStep (see its docstring): chain segments on a high-priority stream, one
+        weight-gradient graph per (segment, side stream), the optimizer as a last graph behind the join."""
+        import os
+
+        if self._chain_stream is None:
+            self._chain_stream = torch.cuda.Stream(priority=int(os.environ.get("NLAM_CHAIN_PRIO", "-1")))
+            self._entry_event, self._exit_event = torch.cuda.Event(), torch.cuda.Event()
+        cs = self._chain_stream
+        seg = _SegmentedStep(self, self.forks_per_segment)
+        # the optimizer is captured whenever it can be -- at world > 1 too: the gradient all-reduce runs between the join
+        # and its graph, with 1 / world folded into the captured AdamW launch
+        self._opt_in_graph = bool(getattr(self.opt, "capturable", False)) and not self._opt_eager
+        cs.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(cs):
+                self._recording = seg
+                seg._begin_segment()
+                try:
+                    self.fp.grad.zero_()
+                    self._static_loss = self._fwd_bwd()   # ops.OVERLAP.end() -> seg.finish(): every graph but the optimizer's
+                except BaseException:
+                    seg.abort()
+                    raise
+                finally:
+                    self._recording = None
+                if self._opt_in_graph:
+                    seg.tail = torch.cuda.CUDAGraph()
+                    seg.tail.capture_begin(pool=seg.pool, capture_error_mode=seg.mode)
+                    try:
+                        self.opt.step(1.0 / self.world)
+                    finally:
+                        seg.tail.capture_end()
+        finally:
+            if t_before is not None:
+                self.opt.t = t_before
+        torch.cuda.current_stream().wait_stream(cs)
+        self._graph = seg
+        self._bucket_plan = self._plan_buckets(seg) if self.world > 1 else None
+        self._opt_sig = self._opt_signature()
+
+    def _plan_buckets(self, seg):
+        """world > 1: per chain segment the gradient buckets whose collective is launched behind it.  A bucket is complete when
+        the side work of the last segment that reported one of its parameters has run (a rollout back-propagates a parameter
+        once per AR step: the last report counts); a parameter no side graph reported -- accumulated by autograd, or by a
+        kernel of the chain itself -- is complete with the last segment.  Buckets go out in index order on every rank, so one
+        that is ready late holds back the ones behind it."""
+        nseg = len(seg.chain)
+        last_seg = {}
+        for i, ids in enumerate(seg.seg_params):
+            for pid in ids:
+                last_seg[pid] = i
+        out, cur = [[] for _ in range(nseg)], 0
+        for b, (_s0, _e0, members) in enumerate(self.buckets.bounds):
+            ready = max((last_seg.get(id(self.fp.params[i]), nseg - 1) for i in members), default=nseg - 1)
+            cur = max(cur, ready)
+            out[cur].append(b)
+        return out
+
     def _opt_signature(self):
         """The optimizer's hyper-parameters are launch arguments of the captured AdamW kernel: a change (a learning-rate
-        schedule) must re-capture, or the replays would keep applying the old values."""
+        schedule) must re-record it, or the replays would keep applying the old values."""
         o = self.opt
         return tuple(getattr(o, k, None) for k in ("lr", "betas", "eps", "wd")) if self._opt_in_graph else None
 
     _opt_sig = None
+    _opt_changes = 0
+
+    def _optimizer_changed(self):
+        """lr / betas / eps / weight decay differ from what the captured AdamW launch carries.  The first change re-records
+        (segmented executor: the optimizer's own two-launch graph; one-graph executor: the whole step).  A second change is a
+        schedule: from then on the optimizer runs uncaptured behind the replay -- two launches per step instead of a
+        re-recording per step (advisor finding, round 4)."""
+        self._opt_changes += 1
+        seg = self._graph if isinstance(self._graph, _SegmentedStep) else None
+        if self._opt_changes >= 2:
+            self._opt_eager = True
+            self._opt_in_graph = False
+            if seg is not None:
+                seg.tail = None
+            else:
+                self._graph = None   # recorded again, once, without the optimizer
+            self._opt_sig = None
+            return
+        if seg is None:
+            self._graph = None
+            return
+        t_before = getattr(self.opt, "t", None)
+        with torch.cuda.stream(self._chain_stream):
+            seg.tail = torch.cuda.CUDAGraph()
+            seg.tail.capture_begin(pool=seg.pool, capture_error_mode=seg.mode)
+            try:
+                self.opt.step(1.0 / self.world)
+            finally:
+                seg.tail.capture_end()
+        if t_before is not None:
+            self.opt.t = t_before
+        self._opt_sig = self._opt_signature()
 
     def _graph_step(self, *batch):
         if self._graph is not None and self._opt_in_graph and self._opt_signature() != self._opt_sig:
-            self._graph = None   # lr / betas / weight decay changed since the capture: record the step again
+            self._optimizer_changed()
         if self._graph is None:
             try:
                 self._capture(*batch)
@@ -396,14 +686,55 @@ class Trainer:
             self.module.standardize(*batch, out=self._static_in)
         else:
             torch._foreach_copy_(self._static_in, list(batch))   # one multi-tensor launch instead of one copy per input
-        self._graph.replay()
-        self._after_replay()
+        self._replay_step()
         return self._static_loss.clone()   # the static tensor is overwritten by the next replay
 
     _opt_in_graph = False
+    _comm_stream = None
+    bucket_launch_segments = None   # world > 1, segmented executor: (bucket, chain segment behind which it was launched), last step
+
+    def _replay_step(self):
+        """One replay of the recorded step + gradient exchange + optimizer."""
+        g = self._graph
+        if not isinstance(g, _SegmentedStep):
+            g.replay()
+            self._after_replay()
+            return
+        if self.world > 1:
+            # bucket collectives are launched from a communication stream that waits, on the device, for the chain segment and
+            # the weight-gradient graphs completing the bucket; the chain goes on meanwhile.  RCCL calls stay outside every
+            # capture: a communicator fault can never poison a graph.
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+            comm, bk = self._comm_stream, self.buckets
+            bk.handles, bk.launched = [], []
+            self.bucket_launch_segments = []
+
+            def between(i):
+                comm.wait_event(g.events[i])
+                for ev in g.done_events[i].values():
+                    comm.wait_event(ev)
+                for b in self._bucket_plan[i]:
+                    s0, e0, _ = bk.bounds[b]
+                    with torch.cuda.stream(comm):
+                        bk._reduce_slice(s0, e0)
+                    bk.launched.append(b)
+                    self.bucket_launch_segments.append((b, i))
+
+            g.replay(between=between)
+            with torch.cuda.stream(self._chain_stream):
+                bk._wait_all()    # the chain stream waits for the collectives (and writes back a reduced-precision exchange)
+        else:
+            g.replay()
+        g.replay_tail()           # the optimizer's graph (if recorded) on the chain stream; the caller's stream waits for it
+        if self._opt_in_graph:
+            self.opt.note_replayed()
+        else:
+            self.opt.step(1.0 / self.world)
 
     def _after_replay(self):
-        """Gradient exchange + optimizer behind a replayed step (the optimizer is part of the graph when world == 1)."""
+        """One-graph executor: gradient exchange + optimizer behind the replay (the optimizer is part of the graph when
+        world == 1)."""
         if self._opt_in_graph:
             self.opt.note_replayed()
             return
@@ -447,10 +778,134 @@ class Trainer:
                     self.batch_times = raw[3]
                 else:
                     dataset.batch(indices, standardize=standardize, out=(*self._static_in, self.batch_times))
-                self._graph.replay()
-                self._after_replay()
+                self._replay_step()
                 return self._static_loss.clone()
         init, target, forcing, self.batch_times = dataset.batch(indices, standardize=standardize)
         return self.step(init, target, forcing)
 
     batch_times = None
+
+
+# ---------------------------------------------------------------------------
+# The drop-in path: a captured forward + backward for a training loop that owns its optimizer (Lightning)
+# ---------------------------------------------------------------------------
+class _GraphedStep:
+    """See ``graphed_training_step``."""
+
+    def __init__(self, module: nn.Module, sample_args, warmup: int = 3, pack_weights: bool = True):
+        from . import ops
+
+        if not all(isinstance(a, torch.Tensor) and a.is_cuda for a in sample_args):
+            raise ValueError("graphed_training_step: the sample arguments must be tensors on the GPU")
+        self.module = module
+        self.params = tuple(p for p in module.parameters() if p.requires_grad)
+        if not self.params:
+            raise ValueError("module has no trainable parameters")
+        self.autocast = (torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"))
+        self.static_in = [a.detach().clone().requires_grad_(a.requires_grad) for a in sample_args]
+        self.sig = [(tuple(a.shape), a.dtype, a.requires_grad) for a in sample_args]
+        self.packer = ops.WeightPacker() if pack_weights else None
+        surface = tuple(a for a in self.static_in if a.requires_grad) + self.params
+        self.n_in_grads = sum(1 for a in self.static_in if a.requires_grad)
+
+        import gc
+
+        def forward():
+            prev, ops.PACKER = ops.PACKER, self.packer
+            try:
+                if self.packer is not None:
+                    self.packer.begin_step()   # the weight images, rewritten from the current weights: first kernels of the graph
+                out = module(*self.static_in)
+            finally:
+                ops.PACKER = prev
+            return out if isinstance(out, tuple) else (out,)
+
+        def backward(outs, gouts):
+            live = [(o, g) for o, g in zip(outs, gouts) if g is not None]
+            prev, ops.PACKER = ops.PACKER, self.packer
+            try:
+                return torch.autograd.grad(tuple(o for o, _ in live), surface, grad_outputs=tuple(g for _, g in live),
+                                           only_inputs=True, allow_unused=True)
+            finally:
+                ops.PACKER = prev
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):   # eager passes first: lazy graph layouts, LDS attributes, packer tables, allocator state
+            for _ in range(max(1, warmup)):
+                outs = forward()
+                backward(outs, [torch.zeros_like(o) if o.requires_grad else None for o in outs])
+            del outs
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()   # a CUDAGraph destructor synchronises the device: never inside a capture (see Trainer._capture)
+        try:
+            self.pool = torch.cuda.graph_pool_handle()
+            self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.fwd_graph, pool=self.pool, capture_error_mode="thread_local"):
+                self.static_out = forward()
+            self.static_gout = [torch.zeros_like(o) if o.requires_grad else None for o in self.static_out]
+            with torch.cuda.graph(self.bwd_graph, pool=self.pool, capture_error_mode="thread_local"):
+                self.static_grads = backward(self.static_out, self.static_gout)
+        finally:
+            if was_enabled:
+                gc.enable()
+        outer = self
+
+        class _Replay(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, *flat):
+                for dst, src in zip(outer.static_in, flat[: len(outer.static_in)]):
+                    if dst.data_ptr() != src.data_ptr():
+                        dst.copy_(src)
+                outer.fwd_graph.replay()
+                return tuple(o.detach() for o in outer.static_out)
+
+            @staticmethod
+            @torch.autograd.function.once_differentiable
+            def backward(ctx, *gouts):
+                for dst, g in zip(outer.static_gout, gouts):
+                    if dst is not None:
+                        if g is None:
+                            dst.zero_()
+                        elif dst.data_ptr() != g.data_ptr():
+                            dst.copy_(g)
+                outer.bwd_graph.replay()
+                grads = tuple(g.detach() if g is not None else None for g in outer.static_grads)
+                it = iter(grads)
+                res = [next(it) if a.requires_grad else None for a in outer.static_in]
+                return (*res, *it)
+
+        self._fn = _Replay
+
+    def __call__(self, *args):
+        sig = [(tuple(a.shape), a.dtype, a.requires_grad) for a in args]
+        ac = (torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"))
+        if sig != self.sig or (ac[0] != self.autocast[0]) or (ac[0] and ac[1] != self.autocast[1]):
+            return self.module(*args)   # another batch shape / autocast state: the module itself (eager launches)
+        out = self._fn.apply(*args, *self.params)
+        return out if len(out) > 1 else out[0]
+
+
+def graphed_training_step(module: nn.Module, *sample_args, warmup: int = 3, pack_weights: bool = True):
+    """``module`` (e.g. ``models.ForecasterStep``: batch -> (prediction, loss)) as a callable whose forward AND backward each
+    replay one HIP graph -- for a training loop that keeps its own optimizer and gradient handling, i.e. the reference's:
+    ``ForecasterModule.training_step`` called by ``pl.Trainer`` (models/module.py:394-417, train_model.py:564-578) returns the
+    loss, Lightning calls ``loss.backward()`` and ``torch.optim.AdamW.step()``, DDP's hooks see every ``.grad`` arrive.
+
+        step = graphed_training_step(forecaster_step, init, target, forcing)     # once, on a sample batch (it is not consumed)
+        ...
+        def training_step(self, batch):                                          # LightningModule
+            prediction, loss = step(*batch)
+            return loss
+
+    The same contract as ``torch.cuda.make_graphed_callables`` (static input / output / gradient buffers; a batch of another
+    shape or autocast state falls through to the module's eager launches; parameter gradients come back through autograd, so
+    ``AccumulateGrad`` hooks -- DDP -- fire as usual), plus what this library adds: the fused MLPs' weight images are rewritten
+    by the first kernels of the forward graph (``pack_weights``), and the capture is thread-local, so a live RCCL watchdog thread
+    does not disturb it.  ~330 launches of 3-150 us per cfg2 step become two graph launches; bench.py reports the step time of
+    this path beside the eager one (``lightning_shaped``).  Results are bit-identical to the eager module (test_boundary.py /
+    test_hip_parity.py::test_graphed_training_step_equals_eager)."""
+    return _GraphedStep(module, sample_args, warmup=warmup, pack_weights=pack_weights)

@@ -1158,7 +1158,7 @@ def test_node_linear_matches_torch(dev, k, n, rows, batched):
     assert float(W.grad[:, :col0].abs().max()) == 0.0 and float(W.grad[:, col0 + k :].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("d,rows", [(128, 6561), (256, 45)])
+@pytest.mark.parametrize("d,rows", [(128, 6561), (256, 45), (512, 6561), (256, 33001)])
 def test_node_linear_pair_matches_torch(dev, d, rows):
     """Both node-level products of a mesh <-> mesh layer in one launch (nlam_linear with W2 / out2)."""
     from neural_lam_amd.ops import NodeLinearPairFunction
@@ -1176,6 +1176,45 @@ def test_node_linear_pair_matches_torch(dev, d, rows):
     assert rel_err(x.grad.double().cpu(), xr.grad.cpu()) < 1e-5
     assert rel_err(W.grad.double().cpu(), Wr.grad.cpu()) < 1e-5
     assert float(W.grad[:, :d].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-5), ("bf16x2", 2e-4), ("bf16", 2e-2)])
+@pytest.mark.parametrize("k,n,rows", [(512, 512, 40003), (256, 128, 33000), (128, 512, 6561), (384, 256, 1), (512, 128, 65)])
+def test_node_linear_gemm_tiles_and_modes(dev, k, n, rows, mode, tol):
+    """nlam_linear on the LDS-tiled GEMM (round 5: linear_gemm_kernel, n % 128 == 0): 128-row tiles from 32 768 rows and
+    64-row tiles below, ragged last row tile (rows past the end are zero-filled operands and unwritten outputs: the output
+    buffer is poisoned first), K = 4 ... 16 chunks, forward layout and the transposed data-gradient layout, every split
+    mode, accumulate on top of existing values, and agreement with the strip kernel of rounds 2-4 on the same problem."""
+    from neural_lam_amd import _lib as L
+    from neural_lam_amd import ops
+
+    lib = L.load()
+    torch.manual_seed(5)
+    kin, col0 = 2 * k, k
+    W = torch.randn(n, kin, device=dev) / k ** 0.5
+    x = torch.randn(rows, k, device=dev)
+    mm = ops._MM_FLAGS[mode]
+    ref = x.double() @ W[:, col0:].double().T
+    guard = torch.full((rows + 200, n), float("nan"), device=dev)
+    out = guard[:rows]
+    ops._linear_launch(x, W.data_ptr() + 4 * col0, kin, 1, k, n, out=out, mm_flags=mm)
+    assert torch.isnan(guard[rows:]).all(), "rows past the end were written"
+    assert rel_err(out.double().cpu(), ref.cpu()) < tol
+    ops._linear_launch(x, W.data_ptr() + 4 * col0, kin, 1, k, n, out=out, accumulate=True, mm_flags=mm)
+    assert rel_err(out.double().cpu(), 2 * ref.cpu()) < tol
+    # the transposed product (data gradient): dx = g . W[:, col0:]
+    g = torch.randn(rows, n, device=dev)
+    n_t, k_t = k, n   # output width k, reduction over n -- the GEMM path needs n_t % 128 == 0
+    dx = ops._linear_launch(g, W.data_ptr() + 4 * col0, 1, kin, k_t, n_t, mm_flags=mm)
+    assert rel_err(dx.double().cpu(), (g.double() @ W[:, col0:].double()).cpu()) < tol
+    if k % 64 == 0 and n % 64 == 0:   # the strip kernel takes these shapes too: same split products, other summation grouping
+        try:
+            assert lib.nlam_set_tuning(L.TUNE_LIN_GEMM, 0) == 0
+            old = ops._linear_launch(x, W.data_ptr() + 4 * col0, kin, 1, k, n, mm_flags=mm)
+        finally:
+            assert lib.nlam_set_tuning(L.TUNE_LIN_GEMM, 1) == 0
+        new = ops._linear_launch(x, W.data_ptr() + 4 * col0, kin, 1, k, n, mm_flags=mm)
+        assert rel_err(new.cpu(), old.cpu()) < 1e-5
 
 
 class _NoLibraryGemm:
@@ -1412,3 +1451,146 @@ def test_split_receivers_are_reduced_deterministically(dev):
             torch.use_deterministic_algorithms(False)
     finally:
         G.VIRTUAL_SPLIT = True
+
+
+@pytest.mark.parametrize("K", [1, 3, 1000])
+@pytest.mark.parametrize("model,T", [("graph_lam", 3), ("hi_lam_parallel", 1)])
+def test_segmented_executor_equals_one_graph_and_eager(dev, tmp_path, model, T, K):
+    """trainer._SegmentedStep (a chain of linear graphs on one stream + weight-gradient graphs on side streams, tied by
+    events) against the one-graph executor (forks inside the capture) and the eager step: same bits over several optimizer
+    steps, for every segment length -- one fork per segment, the default, and a single segment -- on a rollout (every MLP
+    back-propagated once per AR step: the read-modify-write accumulations of a parameter must stay ordered across
+    segments) and on the chunked HiLAMParallel stack."""
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import models as hm
+    from neural_lam_amd.datastore import SyntheticDatastore
+    from neural_lam_amd.trainer import Trainer, _SegmentedStep
+
+    hier = model != "graph_lam"
+
+    def make(**kw):
+        ds = SyntheticDatastore(81 if hier else 60, 30 if hier else 54, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+        ext = ds.get_xy_extent("state")
+        raw = G.create_regular_grid_graph(ds.get_xy("state"), n_max_levels=3 if hier else None, hierarchical=hier)
+        graph = G.normalise_graph(raw, max(ext[1] - ext[0], ext[3] - ext[2]))
+        torch.manual_seed(1)
+        fc = hm.ARForecaster(hm.MODELS[model](ds, graph=graph, hidden_dim=32 if hier else 64, processor_layers=2), ds)
+        return ds, Trainer(hm.ForecasterStep(fc, ds).to(dev), lr=1e-3, **kw)
+
+    ds, t_seg = make(use_graph=True, executor="segments", forks_per_segment=K)
+    _, t_one = make(use_graph=True, executor="forks")
+    _, t_eager = make(use_graph=False)
+    N = ds.num_grid_points
+    g = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        batch = [torch.randn(1, 2, N, 5, generator=g).to(dev), torch.randn(1, T, N, 5, generator=g).to(dev),
+                 torch.randn(1, T, N, 6, generator=g).to(dev)]
+        ls, lo, le = float(t_seg.step(*batch)), float(t_one.step(*batch)), float(t_eager.step(*batch))
+        assert ls == lo == le
+        assert torch.equal(t_seg.fp.grad, t_eager.fp.grad) and torch.equal(t_seg.fp.flat, t_eager.fp.flat)
+        assert torch.equal(t_one.fp.flat, t_eager.fp.flat)
+    seg = t_seg._graph
+    assert isinstance(seg, _SegmentedStep) and not isinstance(t_one._graph, _SegmentedStep)
+    assert seg.nforks > 0 and len(seg.chain) == len(seg.side) and seg.tail is not None
+    if K == 1000:   # one segment per dead-end MLP at most: nothing else cuts the chain
+        assert len(seg.chain) <= 4
+    if K == 1:
+        assert len(seg.chain) >= min(seg.nforks, 4)
+
+
+def test_optimizer_schedule_does_not_rerecord_the_step(dev, tmp_path):
+    """A learning-rate schedule under the captured step (advisor finding, round 4): the first change re-records the
+    optimizer's own graph only, the second moves the optimizer behind the replay for good -- the chain is recorded once --
+    and the weights follow torch.optim.AdamW with the same schedule on the eager trainer."""
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import models as hm
+    from neural_lam_amd.datastore import SyntheticDatastore
+    from neural_lam_amd.trainer import Trainer
+
+    def make(use_graph):
+        ds = SyntheticDatastore(30, 27, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+        ext = ds.get_xy_extent("state")
+        graph = G.normalise_graph(G.create_regular_grid_graph(ds.get_xy("state")), max(ext[1] - ext[0], ext[3] - ext[2]))
+        torch.manual_seed(1)
+        fc = hm.ARForecaster(hm.GraphLAM(ds, graph=graph, hidden_dim=16, processor_layers=2), ds)
+        return ds, Trainer(hm.ForecasterStep(fc, ds).to(dev), lr=1e-3, use_graph=use_graph)
+
+    ds, tg = make(True)
+    _, te = make(False)
+    N = ds.num_grid_points
+    g = torch.Generator().manual_seed(0)
+    chain0 = None
+    for it, lr in enumerate([1e-3, 1e-3, 5e-4, 2.5e-4, 1.25e-4, 1e-4]):
+        tg.opt.lr = te.opt.lr = lr
+        batch = [torch.randn(1, 2, N, 5, generator=g).to(dev), torch.randn(1, 2, N, 5, generator=g).to(dev),
+                 torch.randn(1, 2, N, 6, generator=g).to(dev)]
+        assert float(tg.step(*batch)) == float(te.step(*batch))
+        assert torch.equal(tg.fp.flat, te.fp.flat), (it, lr)
+        if chain0 is None:
+            chain0 = tg._graph.chain[0]
+        assert tg._graph.chain[0] is chain0   # never recorded again
+    assert tg._opt_eager and tg._graph.tail is None
+
+
+@pytest.mark.parametrize("model,kw,autocast", [
+    ("graph_lam", dict(hidden_dim=16, processor_layers=2), False),
+    ("graph_lam", dict(hidden_dim=128, processor_layers=1), False),
+    ("graph_lam", dict(hidden_dim=128, processor_layers=1), True),
+    ("hi_lam", dict(hidden_dim=16, processor_layers=2), False),
+])
+def test_graphed_training_step_equals_eager(dev, tmp_path, model, kw, autocast):
+    """trainer.graphed_training_step -- the drop-in path: forward and backward each replay one HIP graph, the caller keeps
+    ``loss.backward()`` and ``torch.optim.AdamW`` (models/module.py:293-304, 394-417) -- against the same module launched
+    eagerly: loss, prediction, every ``.grad`` autograd delivers and the weights after three optimizer steps, bit for bit;
+    a batch of another shape falls through to the eager module."""
+    import contextlib
+
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import models as hm
+    from neural_lam_amd.datastore import SyntheticDatastore
+    from neural_lam_amd.trainer import graphed_training_step
+
+    hier = model != "graph_lam"
+
+    def make():
+        ds = SyntheticDatastore(81 if hier else 30, 30 if hier else 27, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+        ext = ds.get_xy_extent("state")
+        raw = G.create_regular_grid_graph(ds.get_xy("state"), n_max_levels=3 if hier else None, hierarchical=hier)
+        graph = G.normalise_graph(raw, max(ext[1] - ext[0], ext[3] - ext[2]))
+        torch.manual_seed(1)
+        fc = hm.ARForecaster(hm.MODELS[model](ds, graph=graph, **kw), ds)
+        step = hm.ForecasterStep(fc, ds).to(dev)
+        return ds, step, torch.optim.AdamW(step.parameters(), lr=1e-3, betas=(0.9, 0.95))
+
+    amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
+    ds, s_e, o_e = make()
+    _, s_g, o_g = make()
+    N = ds.num_grid_points
+    g = torch.Generator().manual_seed(0)
+
+    def batch(T=2):
+        return [torch.randn(1, 2, N, 5, generator=g).to(dev), torch.randn(1, T, N, 5, generator=g).to(dev), torch.randn(1, T, N, 6, generator=g).to(dev)]
+
+    with amp():
+        graphed = graphed_training_step(s_g, *batch())
+    for _ in range(3):
+        b = batch()
+        res = []
+        for fn, opt, mod in ((s_e, o_e, s_e), (graphed, o_g, s_g)):
+            opt.zero_grad(set_to_none=True)
+            with amp():
+                pred, loss = fn(*b)
+            loss.backward()
+            res.append((pred.detach().clone(), float(loss), [p.grad.clone() for p in mod.parameters()]))
+            opt.step()
+        assert res[0][1] == res[1][1]
+        assert torch.equal(res[0][0], res[1][0])
+        for a, c in zip(res[0][2], res[1][2]):
+            assert torch.equal(a, c)
+        for a, c in zip(s_e.parameters(), s_g.parameters()):
+            assert torch.equal(a, c)
+    b = batch(T=1)   # another rollout length: not the captured shape
+    with amp():
+        _, l_e = s_e(*b)
+        _, l_g = graphed(*b)
+    assert float(l_e) == float(l_g)
