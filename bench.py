@@ -647,7 +647,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16",
-            "matmul_mode": ops.MATMUL_MODE if args.precision == "fp32" else "bf16 (autocast)",
+            "matmul_mode": ops.matmul_mode_name() if args.precision == "fp32" else "bf16 (autocast)",
             "data": "synthetic",
             "launch_mode": "eager" if args.eager else "hip_graph (zero-grad + fwd + loss + bwd captured once; on_after_batch_transfer writes the graph's inputs before, all-reduce + AdamW run after each replay)",
             "forecast_steps_per_s": forecast_steps_per_s,

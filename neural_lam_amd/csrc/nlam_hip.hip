@@ -190,8 +190,13 @@ __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m -
 // their neighbours on the mesh -- went to eight different L2s and every XCD fetched the whole node table (TCC_HIT 55 %, 1.36x the
 // algorithmic HBM bytes on the m2m edge backward).  xcd_slot gives the workgroups of XCD x the contiguous slot
 // range [x g / 8, (x + 1) g / 8): an XCD then works on an eighth of the receivers (per wave round).
+// MEASURED AND SWITCHED OFF (round 5, A/B of two builds inside one gpurun call, profiles/round5/ab_xcd_gemm_modes.log): cfg2
+// 1.749 / 1.750 ms without against 1.751 / 1.760 with, cfg3 47.6 against 48.5, cfg4 11.25 against 11.30, cfg5 143.6 against 144.5 --
+// no gain anywhere, a little loss at the wide widths (an eighth of the receivers per XCD is also an eighth of the senders'
+// rows per L2: the node tables of these graphs, 1.7 - 13 MB, mostly fit the 4 MiB L2s or the Infinity Cache either way, and the
+// kernels are latency-bound, not L2-fill-bound).  -DNLAM_XCD_REMAP=1 rebuilds with it.
 #ifndef NLAM_XCD_REMAP
-#define NLAM_XCD_REMAP 1
+#define NLAM_XCD_REMAP 0
 #endif
 __device__ __forceinline__ int xcd_slot(int b, int g) {
 #if NLAM_XCD_REMAP

@@ -539,16 +539,36 @@ class Trainer:
         # too -- one launch latency less per step than enqueueing it behind the replay.  With data parallelism the gradient
         # all-reduce separates the two and stays outside the capture.
         self._opt_in_graph = self.world == 1 and bool(getattr(self.opt, "capturable", False)) and not self._opt_eager
+        self._tail_graph = None
         try:
             with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                 self.fp.grad.zero_()
                 self._static_loss = self._fwd_bwd()
                 if self._opt_in_graph:
                     self.opt.step(1.0)
+            self._capture_tail()
         finally:
             if t_before is not None:
                 self.opt.t = t_before   # the capture recorded the launches without running them (also when it failed half way)
         self._opt_sig = self._opt_signature()
+
+    _tail_graph = None
+
+    def _capture_tail(self):
+        """world > 1, one-graph executor: the gradient all-reduce separates backward from the optimizer, so the optimizer is a
+        second graph, replayed behind the collective (``1 / world`` folded into the captured AdamW launch; step count and bias
+        corrections live on the device) -- no per-step launch arguments, one replay instead of two eager launches."""
+        self._tail_graph = None
+        if self.world > 1 and bool(getattr(self.opt, "capturable", False)) and not self._opt_eager:
+            t_before = getattr(self.opt, "t", None)
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.opt.step(1.0 / self.world)
+            finally:
+                if t_before is not None:
+                    self.opt.t = t_before
+            self._tail_graph = g
 
     _chain_stream = None
     _entry_event = None
@@ -619,7 +639,8 @@ class Trainer:
         """The optimizer's hyper-parameters are launch arguments of the captured AdamW kernel: a change (a learning-rate
         schedule) must re-record it, or the replays would keep applying the old values."""
         o = self.opt
-        return tuple(getattr(o, k, None) for k in ("lr", "betas", "eps", "wd")) if self._opt_in_graph else None
+        captured = self._opt_in_graph or self._tail_graph is not None
+        return tuple(getattr(o, k, None) for k in ("lr", "betas", "eps", "wd")) if captured else None
 
     _opt_sig = None
     _opt_changes = 0
@@ -633,15 +654,20 @@ class Trainer:
         seg = self._graph if isinstance(self._graph, _SegmentedStep) else None
         if self._opt_changes >= 2:
             self._opt_eager = True
-            self._opt_in_graph = False
             if seg is not None:
                 seg.tail = None
-            else:
+            elif self._opt_in_graph:
                 self._graph = None   # recorded again, once, without the optimizer
+            self._opt_in_graph = False
+            self._tail_graph = None
             self._opt_sig = None
             return
         if seg is None:
-            self._graph = None
+            if self._tail_graph is not None:   # the optimizer's own graph: only that is recorded again
+                self._capture_tail()
+                self._opt_sig = self._opt_signature()
+            else:
+                self._graph = None
             return
         t_before = getattr(self.opt, "t", None)
         with torch.cuda.stream(self._chain_stream):
@@ -656,7 +682,7 @@ class Trainer:
         self._opt_sig = self._opt_signature()
 
     def _graph_step(self, *batch):
-        if self._graph is not None and self._opt_in_graph and self._opt_signature() != self._opt_sig:
+        if self._graph is not None and (self._opt_in_graph or self._tail_graph is not None) and self._opt_signature() != self._opt_sig:
             self._optimizer_changed()
         if self._graph is None:
             try:
@@ -740,7 +766,11 @@ class Trainer:
             return
         if self.world > 1:   # one flat buffer: a single collective (0.86 MB at cfg2, 20.6 MB at cfg3; half of that with bf16 exchange)
             self.buckets.all_reduce_whole()
-        self.opt.step(1.0 / self.world)
+        if self._tail_graph is not None:
+            self._tail_graph.replay()
+            self.opt.note_replayed()
+        else:
+            self.opt.step(1.0 / self.world)
 
     def step(self, *batch):
         if self.use_graph:

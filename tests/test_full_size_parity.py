@@ -356,47 +356,111 @@ def test_cfg5_full_rollout_under_bf16_autocast_against_the_oracle_on_the_gpu(dev
     gc.collect()
     torch.cuda.empty_cache()
 
-    # ---- oracle, full rollout, on the device
+    # ---- oracle, full rollout, on the device: fp32 (the reference) and under torch.autocast (what --precision bf16-mixed makes of it)
     cfg = dict(bench.CONFIGS["cfg5"])
+    report = _bf16_noise_against_reference_autocast(dev, cfg, "cfg5 (T=8)")
+    e_pred, e_loss, worst_l2, worst_cos = report["hip"]["pred"], report["hip"]["loss"], report["hip"]["worst_l2"], report["hip"]["worst_cos"]
+    print(f"oracle fp32-vs-fp64 layer error {oracle_err:.2e}")
+    assert e_pred < 3e-2 and e_loss < 1e-2
+    assert worst_l2 < 6e-2 and worst_cos > 0.998, (worst_l2, worst_cos)
+
+
+def _gpu_oracle_step(cfg, dev, autocast):
+    """Prediction, loss and parameter gradients of the oracle restatement run on the GPU through stock PyTorch ops (test
+    infrastructure, as bench.py's gpu_reference_equivalent), in fp32 or inside torch.autocast(bfloat16)."""
+    import gc
+
+    import bench
+    from oracle import models as om
+
     ds, _, _, o_fc, _, batch_cpu = bench.build(cfg, torch.device("cpu"), oracle=True)
-    o_sd = {k: v.clone() for k, v in o_fc.state_dict().items()}
+    sd = {k: v.clone() for k, v in o_fc.state_dict().items()}
     o_fc = o_fc.to(dev)
     pvs, mask = om.per_var_std_uniform(ds).to(dev), om.interior_mask_bool(ds).to(dev)
     o_batch = tuple(b.to(dev) for b in om.standardize_batch(ds, *batch_cpu))
-    o_pred, o_loss_t = om.training_loss(o_fc, o_batch, pvs, mask)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        o_pred, o_loss_t = om.training_loss(o_fc, o_batch, pvs, mask)
     o_loss_t.backward()
     torch.cuda.synchronize()
-    o_pred, o_loss = o_pred.detach().cpu(), float(o_loss_t)
-    o_grads = {k: p.grad.detach().cpu() for k, p in o_fc.named_parameters()}
-    del o_fc, o_batch, o_loss_t, pvs, mask
+    res = {"pred": o_pred.detach().float().cpu(), "loss": float(o_loss_t), "grads": {k: p.grad.detach().float().cpu() for k, p in o_fc.named_parameters()}, "sd": sd}
+    del o_fc, o_batch, o_loss_t, o_pred, pvs, mask
     gc.collect()
     torch.cuda.empty_cache()
+    return res
 
-    # ---- product: captured trainer step under autocast, lr = 0 (the weights stay at their seed-42 values)
+
+def _errors_against(ref, pred, loss, grads):
+    """max-norm relative error of the prediction, relative error of the loss, per-parameter relative L2 error and cosine."""
+    out = {"pred": rel_err(pred, ref["pred"]), "loss": abs(loss - ref["loss"]) / abs(ref["loss"]), "l2": {}, "cos": {}}
+    for k, g in ref["grads"].items():
+        g, h = g.double().reshape(-1), grads[k].double().reshape(-1)
+        assert bool(torch.isfinite(h).all()), k
+        out["l2"][k] = float((h - g).norm() / g.norm().clamp(min=1e-30))
+        out["cos"][k] = float((h @ g) / (h.norm() * g.norm()).clamp(min=1e-30))
+    out["worst_l2"], out["worst_cos"] = max(out["l2"].values()), min(out["cos"].values())
+    return out
+
+
+BF16_NOISE_FACTOR = 1.5    # HIP-under-autocast may be at most this much noisier than the reference-under-autocast ...
+BF16_NOISE_FLOOR = 1e-3    # ... plus this absolute allowance on a relative error (tensors the reference happens to get almost exactly)
+
+
+def _bf16_noise_against_reference_autocast(dev, cfg, tag):
+    """the bf16 tolerances of this file are stated against the fp32 oracle; what matters to a user of
+    ``--precision bf16-mixed`` (train_model.py:163-168) is whether this library is NOISIER than the reference's own
+    autocast run.  Three runs of bench.py's workload on the GPU -- oracle fp32, oracle inside torch.autocast(bfloat16), the
+    product's captured trainer step inside torch.autocast(bfloat16) (bf16 operands AND bf16 saved tensors) -- and per tensor
+    err(HIP vs fp32) <= 1.5 x err(reference-autocast vs fp32) + 1e-3."""
+    import gc
+
+    import bench
+    from neural_lam_amd.trainer import Trainer
+
+    ref = _gpu_oracle_step(cfg, dev, autocast=False)
+    amp = _gpu_oracle_step(cfg, dev, autocast=True)
+    e_ref = _errors_against(ref, amp["pred"], amp["loss"], amp["grads"])
+    del amp
     _, _, _, h_fc, step, batch = bench.build(cfg, dev)
     for k, v in h_fc.state_dict().items():
-        assert torch.equal(v.cpu(), o_sd[k]), k
+        assert torch.equal(v.cpu(), ref["sd"][k]), k
     with torch.autocast("cuda", dtype=torch.bfloat16):
         with torch.no_grad():
-            h_pred, h_loss0 = step(*batch)
-        e_pred = rel_err(h_pred.float().cpu(), o_pred)
-        del h_pred
+            h_pred, _ = step(*batch)
+        h_pred = h_pred.float().cpu()
         tr = Trainer(step, lr=0.0, use_graph=True)
         loss = tr.step(*batch)
         torch.cuda.synchronize()
-    e_loss = abs(float(loss) - o_loss) / abs(o_loss)
-    worst_l2, worst_cos = 0.0, 1.0
-    for k, p in h_fc.named_parameters():
-        g, h = o_grads[k].double().reshape(-1), p.grad.cpu().double().reshape(-1)
-        assert bool(torch.isfinite(h).all()), k
-        l2 = float((h - g).norm() / g.norm().clamp(min=1e-30))
-        cos = float((h @ g) / (h.norm() * g.norm()).clamp(min=1e-30))
-        worst_l2, worst_cos = max(worst_l2, l2), min(worst_cos, cos)
-    print(f"cfg5 (T=8) bf16 autocast vs fp32 oracle on the GPU: prediction {e_pred:.3e}, loss {e_loss:.3e} "
-          f"(no-grad forward {abs(float(h_loss0) - o_loss) / abs(o_loss):.3e}), worst gradient rel-L2 {worst_l2:.3e}, "
-          f"worst cosine {worst_cos:.6f}; oracle fp32-vs-fp64 layer error {oracle_err:.2e}")
-    assert e_pred < 3e-2 and e_loss < 1e-2
-    assert worst_l2 < 6e-2 and worst_cos > 0.998, (worst_l2, worst_cos)
+    e_hip = _errors_against(ref, h_pred, float(loss), {k: p.grad.detach().float().cpu() for k, p in h_fc.named_parameters()})
+    worst_ratio, worst_k = 0.0, ""
+    for k in e_hip["l2"]:
+        r = e_hip["l2"][k] / max(e_ref["l2"][k], 1e-30)
+        if e_hip["l2"][k] > BF16_NOISE_FLOOR and r > worst_ratio:
+            worst_ratio, worst_k = r, k
+    print(f"{tag} under bf16 autocast, errors against the fp32 oracle (GPU): HIP prediction {e_hip['pred']:.3e} / loss {e_hip['loss']:.3e} / worst gradient "
+          f"rel-L2 {e_hip['worst_l2']:.3e} / worst cosine {e_hip['worst_cos']:.6f}; reference-under-autocast {e_ref['pred']:.3e} / {e_ref['loss']:.3e} / "
+          f"{e_ref['worst_l2']:.3e} / {e_ref['worst_cos']:.6f}; worst per-tensor ratio HIP / reference {worst_ratio:.2f} ({worst_k})")
+    assert e_hip["pred"] <= BF16_NOISE_FACTOR * e_ref["pred"] + BF16_NOISE_FLOOR
+    assert e_hip["loss"] <= BF16_NOISE_FACTOR * e_ref["loss"] + BF16_NOISE_FLOOR
+    for k in e_hip["l2"]:
+        assert e_hip["l2"][k] <= BF16_NOISE_FACTOR * e_ref["l2"][k] + BF16_NOISE_FLOOR, (k, e_hip["l2"][k], e_ref["l2"][k])
+    del tr, step, h_fc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"hip": e_hip, "ref": e_ref}
+
+
+def test_hilam_d128_bf16_noise_is_not_above_the_reference_under_autocast(dev):
+    """One Hi-LAM (BASELINE configs[3]: d = 128, 3 levels) training step under bf16 autocast: the fp32 one-tile wide kernels of
+    the small launches run with bf16 operands, the big edge sets on the split-bf16 super-tile kernels with bf16 saved tensors."""
+    import bench
+
+    _bf16_noise_against_reference_autocast(dev, dict(bench.CONFIGS["cfg4"]), "cfg4 (Hi-LAM d = 128)")
+
+
+def test_cfg1_training_step_matches_oracle_as_configured(dev):
+    """BASELINE configs[0] AS CONFIGURED (missing 7): Keisler 1-level mesh on the 64 x 64 dummy grid,
+    hidden_dim 16, batch 2, ar_steps 1 -- bench.CONFIGS["cfg1"], the reference's own CPU-runnable case."""
+    _model_parity(dev, "cfg1")
 
 
 def test_cfg2_hip_graph_trainer_step_matches_oracle_adamw(dev):

@@ -1498,7 +1498,8 @@ def test_segmented_executor_equals_one_graph_and_eager(dev, tmp_path, model, T, 
         assert len(seg.chain) >= min(seg.nforks, 4)
 
 
-def test_optimizer_schedule_does_not_rerecord_the_step(dev, tmp_path):
+@pytest.mark.parametrize("executor", ["forks", "segments"])
+def test_optimizer_schedule_does_not_rerecord_the_step(dev, tmp_path, executor):
     """A learning-rate schedule under the captured step (advisor finding, round 4): the first change re-records the
     optimizer's own graph only, the second moves the optimizer behind the replay for good -- the chain is recorded once --
     and the weights follow torch.optim.AdamW with the same schedule on the eager trainer."""
@@ -1513,23 +1514,25 @@ def test_optimizer_schedule_does_not_rerecord_the_step(dev, tmp_path):
         graph = G.normalise_graph(G.create_regular_grid_graph(ds.get_xy("state")), max(ext[1] - ext[0], ext[3] - ext[2]))
         torch.manual_seed(1)
         fc = hm.ARForecaster(hm.GraphLAM(ds, graph=graph, hidden_dim=16, processor_layers=2), ds)
-        return ds, Trainer(hm.ForecasterStep(fc, ds).to(dev), lr=1e-3, use_graph=use_graph)
+        return ds, Trainer(hm.ForecasterStep(fc, ds).to(dev), lr=1e-3, use_graph=use_graph, executor=executor)
 
     ds, tg = make(True)
     _, te = make(False)
     N = ds.num_grid_points
     g = torch.Generator().manual_seed(0)
-    chain0 = None
+    recorded = []
     for it, lr in enumerate([1e-3, 1e-3, 5e-4, 2.5e-4, 1.25e-4, 1e-4]):
         tg.opt.lr = te.opt.lr = lr
         batch = [torch.randn(1, 2, N, 5, generator=g).to(dev), torch.randn(1, 2, N, 5, generator=g).to(dev),
                  torch.randn(1, 2, N, 6, generator=g).to(dev)]
         assert float(tg.step(*batch)) == float(te.step(*batch))
         assert torch.equal(tg.fp.flat, te.fp.flat), (it, lr)
-        if chain0 is None:
-            chain0 = tg._graph.chain[0]
-        assert tg._graph.chain[0] is chain0   # never recorded again
-    assert tg._opt_eager and tg._graph.tail is None
+        recorded.append(tg._graph.chain[0] if executor == "segments" else tg._graph)
+    assert tg._opt_eager and not tg._opt_in_graph
+    if executor == "segments":
+        assert all(r is recorded[0] for r in recorded) and tg._graph.tail is None   # the chain was recorded once
+    else:   # one graph: the first change re-records it with the new values, the second once more without the optimizer -- and never again
+        assert recorded[1] is recorded[0] and recorded[4] is recorded[3] and recorded[5] is recorded[3]
 
 
 @pytest.mark.parametrize("model,kw,autocast", [
