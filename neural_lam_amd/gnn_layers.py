@@ -470,7 +470,7 @@ class InteractionNet(nn.Module):
         if edge_rep.shape[-2] != self._edge_index_local.shape[1]:
             raise RuntimeError("edge_rep rows do not match the number of edges")
 
-    def _messages_and_aggregate(self, send_rep, rec_rep, edge_rep, want_out: bool, add_edge: bool):
+    def _messages_and_aggregate(self, send_rep, rec_rep, edge_rep, want_out: bool, add_edge: bool, rec_alias: bool = False):
         """-> (aggr, edge_out | None); edge_out = msg (+ edge_rep if add_edge), original edge order."""
         self._check_inputs(send_rep, rec_rep, edge_rep)
         csr = self._csr(send_rep.device, send_rep.shape[-2])
@@ -495,11 +495,16 @@ class InteractionNet(nn.Module):
         if self._factorise(csr, send_rep, rec_rep, edge_rep):
             W1 = self.edge_mlp[0].weight
             d = edge_rep.shape[-1]
+            # mail: the product of the RECEIVER table accumulates its data gradient onto the node MLP's (ops.mail_scope; the
+            # caller -- forward() -- has made rec_rep a private alias, so no other gradient meets these two)
+            mail = rec_alias
             if send_rep is rec_rep and d > 64:   # mesh <-> mesh: both products of the one node table in a single launch
-                p_send, p_rec = NodeLinearPairFunction.apply(send_rep, W1, d, 2 * d)
+                p_send, p_rec = NodeLinearPairFunction.apply(send_rep, W1, d, 2 * d, mail)
             else:
-                p_send = NodeLinearFunction.apply(send_rep, W1, d)          # (W1_j x) per sender node
-                p_rec = NodeLinearFunction.apply(rec_rep, W1, 2 * d)        # (W1_i x) per receiver node
+                # (a table that is sender AND receiver: whichever product's backward runs first takes the posted buffer, the other
+                # reports its gradient to autograd as usual -- correct in either order)
+                p_send = NodeLinearFunction.apply(send_rep, W1, d, mail and send_rep is rec_rep)   # (W1_j x) per sender node
+                p_rec = NodeLinearFunction.apply(rec_rep, W1, 2 * d, mail)                          # (W1_i x) per receiver node
             geom = self._edge_geom(csr, want_out, add_edge, key, pre=True)
             edge_out, aggr = self.edge_mlp.forward_fused(geom, edge_rep, p_send, p_rec)
             return aggr, edge_out
@@ -611,6 +616,10 @@ class InteractionNet(nn.Module):
         if isinstance(self.aggr_mlp, SplitMLPs):
             rec_diff = self.aggr_mlp(torch.cat((rec_rep, aggr), dim=-1))
             return self.node_residual_target(rec_rep, aggr) + rec_diff
+        if self.aggr_mlp.fully_fused:   # ONE launch: its dense gradient of rec_rep may be posted for the node-level product's backward
+            with ops.mail_post():
+                out, _ = self.aggr_mlp.forward_fused(self._node_geom(), rec_rep, aggr)
+            return out
         out, _ = self.aggr_mlp.forward_fused(self._node_geom(), rec_rep, aggr)
         return out
 
@@ -620,8 +629,17 @@ class InteractionNet(nn.Module):
         the edge output (graph_lam.py:185) skip writing it."""
         if need_edges is None:
             need_edges = self.update_edges
-        aggr, edge_out = self._messages_and_aggregate(send_rep, rec_rep, edge_rep, need_edges, True)
-        rec_out = self._node_update(rec_rep, aggr)
+        with ops.mail_scope() as tok:
+            alias = tok is not None and rec_rep.is_cuda and rec_rep.requires_grad
+            if alias:
+                # a private alias of the receiver table for THIS layer's two consumers of it (node-level product, node MLP):
+                # their gradients meet in the alias' own autograd node, where the second can be accumulated onto the first
+                same = send_rep is rec_rep
+                rec_rep = rec_rep.view_as(rec_rep)
+                if same:
+                    send_rep = rec_rep
+            aggr, edge_out = self._messages_and_aggregate(send_rep, rec_rep, edge_rep, need_edges, True, rec_alias=alias)
+            rec_out = self._node_update(rec_rep, aggr)
         if self.update_edges:
             return rec_out, edge_out
         return rec_out

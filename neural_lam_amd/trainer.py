@@ -822,7 +822,7 @@ class Trainer:
 class _GraphedStep:
     """See ``graphed_training_step``."""
 
-    def __init__(self, module: nn.Module, sample_args, warmup: int = 3, pack_weights: bool = True):
+    def __init__(self, module: nn.Module, sample_args, warmup: int = 3, pack_weights: bool = True, overlap_wgrad: bool = True):
         from . import ops
 
         if not all(isinstance(a, torch.Tensor) and a.is_cuda for a in sample_args):
@@ -837,6 +837,19 @@ class _GraphedStep:
         self.packer = ops.WeightPacker() if pack_weights else None
         surface = tuple(a for a in self.static_in if a.requires_grad) + self.params
         self.n_in_grads = sum(1 for a in self.static_in if a.requires_grad)
+        # overlap_wgrad: inside the captured backward the fused MLPs own the parameter gradients the way they do under
+        # trainer.Trainer -- partial sums reduced straight into views of ONE static staging buffer, the weight-gradient kernels
+        # forked onto side streams (parallel branches of the backward graph) -- and the staging views are what the replay hands to
+        # autograd as the parameters' gradients.  Same bits as the eager module (0 + x = x; accumulation order = backward order).
+        self.gflat, self.gviews = None, None
+        if overlap_wgrad:
+            offs, off = [], 0
+            for p in self.params:
+                offs.append(off)
+                off += (p.numel() + 3) // 4 * 4
+            self.gflat = torch.zeros(off, device=self.params[0].device, dtype=torch.float32)
+            self.goffs = offs
+            self.gviews = [self.gflat[o : o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
 
         import gc
 
@@ -850,12 +863,36 @@ class _GraphedStep:
                 ops.PACKER = prev
             return out if isinstance(out, tuple) else (out,)
 
-        def backward(outs, gouts):
+        def backward(outs, gouts, direct=False):
             live = [(o, g) for o, g in zip(outs, gouts) if g is not None]
             prev, ops.PACKER = ops.PACKER, self.packer
             try:
-                return torch.autograd.grad(tuple(o for o, _ in live), surface, grad_outputs=tuple(g for _, g in live),
-                                           only_inputs=True, allow_unused=True)
+                if not direct:
+                    return torch.autograd.grad(tuple(o for o, _ in live), surface, grad_outputs=tuple(g for _, g in live),
+                                               only_inputs=True, allow_unused=True)
+                fp32 = [p.dtype == torch.float32 for p in self.params]
+                held = [p.grad for p in self.params]
+                state = (ops.DIRECT_PARAM_GRADS, ops.GRAD_LISTENER, ops.EARLY_LEAF_BACKWARD)
+                self.gflat.zero_()
+                for p, v, ok in zip(self.params, self.gviews, fp32):
+                    if ok:
+                        p.grad = v
+                ops.DIRECT_PARAM_GRADS, ops.GRAD_LISTENER, ops.EARLY_LEAF_BACKWARD = True, None, False
+                ops.OVERLAP.begin()
+                try:
+                    got = torch.autograd.grad(tuple(o for o, _ in live), surface, grad_outputs=tuple(g for _, g in live),
+                                              only_inputs=True, allow_unused=True)
+                finally:
+                    ops.OVERLAP.end()   # the side streams join the capture here
+                    ops.DIRECT_PARAM_GRADS, ops.GRAD_LISTENER, ops.EARLY_LEAF_BACKWARD = state
+                    for p, g in zip(self.params, held):
+                        p.grad = g
+                got = list(got)
+                for i, (v, ok) in enumerate(zip(self.gviews, fp32)):
+                    k = self.n_in_grads + i
+                    if ok:   # what the fused MLPs accumulated themselves (+ whatever came back through autograd for this parameter)
+                        got[k] = v if got[k] is None else v + got[k]
+                return tuple(got)
             finally:
                 ops.PACKER = prev
 
@@ -878,7 +915,7 @@ class _GraphedStep:
                 self.static_out = forward()
             self.static_gout = [torch.zeros_like(o) if o.requires_grad else None for o in self.static_out]
             with torch.cuda.graph(self.bwd_graph, pool=self.pool, capture_error_mode="thread_local"):
-                self.static_grads = backward(self.static_out, self.static_gout)
+                self.static_grads = backward(self.static_out, self.static_gout, direct=self.gflat is not None)
         finally:
             if was_enabled:
                 gc.enable()
@@ -903,7 +940,20 @@ class _GraphedStep:
                         elif dst.data_ptr() != g.data_ptr():
                             dst.copy_(g)
                 outer.bwd_graph.replay()
-                grads = tuple(g.detach() if g is not None else None for g in outer.static_grads)
+                if outer.gflat is not None:
+                    # the staging buffer is copied once (one launch) and autograd gets views of the COPY: AccumulateGrad keeps
+                    # (steals) what it is handed as ``.grad``, and a ``.grad`` that aliased the staging buffer would be added
+                    # to itself by the next backward under ``zero_grad(set_to_none=False)``
+                    fresh = outer.gflat.clone()
+                    grads = []
+                    for k, g in enumerate(outer.static_grads):
+                        i = k - outer.n_in_grads
+                        if i >= 0 and g is outer.gviews[i]:
+                            grads.append(fresh[outer.goffs[i] : outer.goffs[i] + g.numel()].view(g.shape))
+                        else:
+                            grads.append(g.detach().clone() if g is not None else None)
+                else:   # torch.cuda.make_graphed_callables' contract: the static gradient tensors themselves
+                    grads = [g.detach() if g is not None else None for g in outer.static_grads]
                 it = iter(grads)
                 res = [next(it) if a.requires_grad else None for a in outer.static_in]
                 return (*res, *it)
@@ -919,7 +969,7 @@ class _GraphedStep:
         return out if len(out) > 1 else out[0]
 
 
-def graphed_training_step(module: nn.Module, *sample_args, warmup: int = 3, pack_weights: bool = True):
+def graphed_training_step(module: nn.Module, *sample_args, warmup: int = 3, pack_weights: bool = True, overlap_wgrad: bool = True):
     """``module`` (e.g. ``models.ForecasterStep``: batch -> (prediction, loss)) as a callable whose forward AND backward each
     replay one HIP graph -- for a training loop that keeps its own optimizer and gradient handling, i.e. the reference's:
     ``ForecasterModule.training_step`` called by ``pl.Trainer`` (models/module.py:394-417, train_model.py:564-578) returns the
@@ -934,8 +984,8 @@ def graphed_training_step(module: nn.Module, *sample_args, warmup: int = 3, pack
     The same contract as ``torch.cuda.make_graphed_callables`` (static input / output / gradient buffers; a batch of another
     shape or autocast state falls through to the module's eager launches; parameter gradients come back through autograd, so
     ``AccumulateGrad`` hooks -- DDP -- fire as usual), plus what this library adds: the fused MLPs' weight images are rewritten
-    by the first kernels of the forward graph (``pack_weights``), and the capture is thread-local, so a live RCCL watchdog thread
-    does not disturb it.  ~330 launches of 3-150 us per cfg2 step become two graph launches; bench.py reports the step time of
+    by the first kernels of the forward graph (``pack_weights``), the weight-gradient kernels run on side streams inside the
+    backward graph (``overlap_wgrad``), and the capture is thread-local, so a live RCCL watchdog thread does not disturb it.  ~330 launches of 3-150 us per cfg2 step become two graph launches; bench.py reports the step time of
     this path beside the eager one (``lightning_shaped``).  Results are bit-identical to the eager module (test_boundary.py /
     test_hip_parity.py::test_graphed_training_step_equals_eager)."""
-    return _GraphedStep(module, sample_args, warmup=warmup, pack_weights=pack_weights)
+    return _GraphedStep(module, sample_args, warmup=warmup, pack_weights=pack_weights, overlap_wgrad=overlap_wgrad)

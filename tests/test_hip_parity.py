@@ -1541,7 +1541,8 @@ def test_optimizer_schedule_does_not_rerecord_the_step(dev, tmp_path, executor):
     ("graph_lam", dict(hidden_dim=128, processor_layers=1), True),
     ("hi_lam", dict(hidden_dim=16, processor_layers=2), False),
 ])
-def test_graphed_training_step_equals_eager(dev, tmp_path, model, kw, autocast):
+@pytest.mark.parametrize("overlap", [True, False])
+def test_graphed_training_step_equals_eager(dev, tmp_path, model, kw, autocast, overlap):
     """trainer.graphed_training_step -- the drop-in path: forward and backward each replay one HIP graph, the caller keeps
     ``loss.backward()`` and ``torch.optim.AdamW`` (models/module.py:293-304, 394-417) -- against the same module launched
     eagerly: loss, prediction, every ``.grad`` autograd delivers and the weights after three optimizer steps, bit for bit;
@@ -1575,7 +1576,7 @@ def test_graphed_training_step_equals_eager(dev, tmp_path, model, kw, autocast):
         return [torch.randn(1, 2, N, 5, generator=g).to(dev), torch.randn(1, T, N, 5, generator=g).to(dev), torch.randn(1, T, N, 6, generator=g).to(dev)]
 
     with amp():
-        graphed = graphed_training_step(s_g, *batch())
+        graphed = graphed_training_step(s_g, *batch(), overlap_wgrad=overlap)
     for _ in range(3):
         b = batch()
         res = []
@@ -1597,3 +1598,64 @@ def test_graphed_training_step_equals_eager(dev, tmp_path, model, kw, autocast):
         _, l_e = s_e(*b)
         _, l_g = graphed(*b)
     assert float(l_e) == float(l_g)
+
+
+@pytest.mark.parametrize("d,same", [(64, True), (64, False), (128, True), (256, False)])
+def test_gradient_mailbox_equals_autograd_accumulation(dev, d, same):
+    """A factorised layer hands the data gradient of its receiver table from the node MLP's backward to the node-level
+    product's backward (ops.mail_scope: accumulated in place by nlam_linear, one autograd `add` launch less per layer and AR
+    step) instead of returning two tensors for autograd to add.  Two stacked layers (the second one's table is a non-leaf with a
+    residual consumer outside the layer): same gradients with the hand-over on and off, and against the oracle; the hand-over
+    really happened (one post + one consume per layer and backward)."""
+    from neural_lam_amd import _lib as L
+    from neural_lam_amd import ops
+    from oracle import gnn_layers as og
+
+    hl = _hl()
+    ns, nr, e, B = (61, 61, 1500, 2) if same else (70, 45, 1400, 1)
+    ei = _rand_ei(ns, nr, e, seed=11)
+    torch.manual_seed(11)
+    refs = [og.InteractionNet(ei, d), og.InteractionNet(ei, d)]
+    nets = [hl.InteractionNet(ei, d), hl.InteractionNet(ei, d)]
+    for r, n in zip(refs, nets):
+        n.load_state_dict(r.state_dict())
+        n.to(dev)
+    send, rec, edge = torch.randn(B, ns, d), torch.randn(B, nr, d), torch.randn(B, e, d)
+
+    def run(layers, s, r, ed):
+        if same:
+            x, ed1 = layers[0](r, r, ed)
+            x = x + 0.5 * r                      # a consumer of the table outside the layer
+            x2, ed2 = layers[1](x, x, ed1)
+            return (x2 * x2).sum() + (ed2 * ed2).sum() + (x * x).sum()
+        r1, ed1 = layers[0](s, r, ed)
+        r2, ed2 = layers[1](s, r1 + 0.5 * r, ed1)
+        return (r2 * r2).sum() + (ed2 * ed2).sum() + (r1 * r1).sum()
+
+    s0, r0, e0 = (t.clone().requires_grad_() for t in (send, rec, edge))
+    run(refs, s0, r0, e0).backward()
+    old = (hl.FACTORISE_MIN_EDGES, hl.FACTORISE_MIN_WORK_WIDE, hl.FACTORISE_MIN_WIDTH_WIDE, hl.FACTORISE_MIN_EDGES_WIDE, ops.GRAD_MAILBOX_ON)
+    hl.FACTORISE_MIN_EDGES = hl.FACTORISE_MIN_WORK_WIDE = hl.FACTORISE_MIN_WIDTH_WIDE = hl.FACTORISE_MIN_EDGES_WIDE = 0
+    lib = L.load()
+    res = {}
+    try:
+        assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 0) == 0
+        for on in (True, False):
+            ops.GRAD_MAILBOX_ON = on
+            ops.MAIL_STATS["posted"] = ops.MAIL_STATS["consumed"] = 0
+            for n in nets:
+                n.zero_grad()
+            s1, r1, e1 = (t.to(dev).requires_grad_() for t in (send, rec, edge))
+            run(nets, s1, r1, e1).backward()
+            res[on] = ([t.grad.clone() for t in ((r1, e1) if same else (s1, r1, e1))], [p.grad.clone() for n in nets for p in n.parameters()],
+                       dict(ops.MAIL_STATS))
+    finally:
+        hl.FACTORISE_MIN_EDGES, hl.FACTORISE_MIN_WORK_WIDE, hl.FACTORISE_MIN_WIDTH_WIDE, hl.FACTORISE_MIN_EDGES_WIDE, ops.GRAD_MAILBOX_ON = old
+        assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
+    assert res[True][2] == {"posted": 2, "consumed": 2} and res[False][2] == {"posted": 0, "consumed": 0}, (res[True][2], res[False][2])   # one per layer
+    for a, b in zip(res[True][0] + res[True][1], res[False][0] + res[False][1]):
+        assert rel_err(a, b) < 1e-6
+    for a, b in zip(res[True][0], ((r0, e0) if same else (s0, r0, e0))):
+        assert rel_err(a.cpu(), b.grad) < TOL
+    for a, (k, q) in zip(res[True][1], [kv for r in refs for kv in r.named_parameters()]):
+        assert rel_err(a.cpu(), q.grad) < TOL, k

@@ -18,7 +18,7 @@ d = 64
 NAMES = {   # kernel name prefix -> (kind, k, n) of the launch key at hidden_dim 64
     "mlp_fwd_bf_kernel<2, 2, 3, false, false, false": ("mlp_fwd", 3 * d, d),   # prefixes: later template arguments (CAT, RO) follow
     "mlp_fwd_bf_kernel<2, 2, 3, false, true, false": ("mlp_fwd", 3 * d, d),
-    "mlp_bwd_fast_kernel<2, 2, 3": ("mlp_bwd", 3 * d, d),
+    "mlp_bwd_fast_kernel<2, 2, ": ("mlp_bwd", 3 * d, d),   # any term count (round 5: the narrow backward runs two-term by default)
     "wgrad_dma_kernel<3, false>": ("wgrad", d, 3 * d),
     "wgrad_dma_kernel<1, true>": ("wgrad", d, d),
 }
@@ -29,8 +29,8 @@ out = {"note": "HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE KiB (gfx950 F
 # launches that only exist inside the whole step (`path:step`: a pmc_collect pass over the replayed cfg2 step, keyed by kernel AND
 # grid -- the node launches run the edge kernels on 206 workgroups): (kernel prefix, grid threads) -> launch key of bench.py
 STEP = {
-    ("mlp_bwd_fast_group_kernel<2, 2, 3, true>", None): "mlp_bwd_group_lw:398549:4:64",   # the four static-feature embedders
-    ("mlp_bwd_fast_kernel<2, 2, 3, false>", 206 * 512): f"mlp_bwd:6561:{2 * d}:{d}",        # node MLP backward, 6 561 mesh nodes
+    ("mlp_bwd_fast_group_kernel<2, 2, ", None): "mlp_bwd_group_lw:398549:4:64",   # the four static-feature embedders
+    ("mlp_bwd_fast_kernel<2, 2, ", 206 * 512): f"mlp_bwd:6561:{2 * d}:{d}",        # node MLP backward, 6 561 mesh nodes
     ("mlp_fwd_bf_kernel<2, 2, 3, false, true, false", 206 * 512): f"mlp_fwd:6561:{2 * d}:{d}",
 }
 for arg in sys.argv[1:]:
