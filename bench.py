@@ -651,7 +651,13 @@ def main():
             "dtype": "f32" if args.precision == "fp32" else "bf16",
             "matmul_mode": ops.matmul_mode_name() if args.precision == "fp32" else "bf16 (autocast)",
             "data": "synthetic",
-            "launch_mode": "eager" if args.eager else "hip_graph (zero-grad + fwd + loss + bwd captured once; on_after_batch_transfer writes the graph's inputs before, all-reduce + AdamW run after each replay)",
+            "launch_mode": "eager" if args.eager else (
+                "hip_graph, one-graph executor (zero-grad + fwd + loss + bwd [+ AdamW at world 1] captured once, weight gradients as forked branches; "
+                "on_after_batch_transfer writes the graph's inputs before; at world > 1 the all-reduce and the optimizer's own graph follow each replay)"
+                if trainer.executor == "forks" else
+                "hip_graph, segmented executor (the chain -- zero-grad, fwd, loss, data gradients -- as linear graphs replayed back to back on one stream, "
+                f"weight gradients as graphs on side streams behind per-segment events, {trainer.forks_per_segment} fork points per segment; the optimizer's "
+                "graph behind the join; at world > 1 gradient buckets are all-reduced per segment)"),
             "forecast_steps_per_s": forecast_steps_per_s,
             "rccl_ranks_seen": ranks_seen,
             "final_loss": float(loss),

@@ -266,8 +266,9 @@ int32_t nlam_max_width(void);
  *   workgroup's load / store phases overlap the other's matrix phases (bit 0: forward, bit 1: backward; shapes without a
  *   half-size instantiation keep the 8-wave kernels). */
 #define NLAM_TUNE_WBF_HALF 6
-/*   NLAM_TUNE_LIN_GEMM: nlam_linear with n % 128 == 0 on the LDS-tiled GEMM (default 1; 0 = the strip kernel of rounds 2-4,
- *   kept for A/B runs; a value above 1 also sets the row count from which its tiles are 128 rows high, default 32 768). */
+/*   NLAM_TUNE_LIN_GEMM: nlam_linear with n % 128 == 0 on the LDS-tiled GEMM: 1 (default) = where it beats the strip kernel of
+ *   rounds 2-4 (one term: everywhere; two / three terms: 6 561-row class up to K = 256, 63 784-row class from K = 512), 0 = never,
+ *   2 = wherever it applies (tests); a value above 2 sets the row count from which its tiles are 128 rows high (default 32 768). */
 #define NLAM_TUNE_LIN_GEMM 7
 int32_t nlam_set_tuning(int32_t key, int32_t value);
 /* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this

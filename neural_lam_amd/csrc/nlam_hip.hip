@@ -3815,23 +3815,43 @@ __global__ __launch_bounds__(kLinGemmThreads) void linear_gemm_kernel(const nlam
     const float* xp = p.x + r0 * p.k;
     const int KC = p.k >> 5;
 
-    // staging: thread -> fragment slot (block mb = wave / 2 + 2 q, K step st = wave % 2, lane) of the A tile and of the B
-    // tile: the slot's 8 floats are row (32 mb + j), columns 16 st + 8 hi .. + 7 of the chunk.  No branch anywhere: rows past
-    // the end of x read the last row and are zeroed by a select.
-    const int sst = wave & 1, smb = wave >> 1;
+    // staging.  A fragment slot = 8 consecutive K values (32 bytes) of one tile row; a tile row's 32-column chunk = 4 slots =
+    // one 128-byte line.  Rows read along K (x, and the weights in the forward layout): thread -> (row = tid / 4 + 64 q, slot
+    // s = tid % 4), so four neighbouring lanes fetch one whole line and a wave instruction 16 lines (the first version gave a
+    // lane a row and a half wave a slot: 32 bytes of each of 32 lines per instruction, a quarter of every line: 137 us for the
+    // 63 784 x 512 x 512 one-term product, 1.9 TB/s).  Transposed weights (TA): thread -> (feature = lane % 32, slot from wave
+    // and half wave): eight dword loads per slot, each coalesced across the 32 features of a block.
+    // LDS: slot (row j, K step st, half hi) of a 32-row block lives at fragment (st, hi) position (j + 2 (2 st + hi)) % 32 --
+    // the rotation spreads the four slots of a line, which one wave instruction writes, over all 32 banks (unrotated they are
+    // 512 bytes apart: a 4-way conflict), and the MFMA loop's reads stay one contiguous (rotated) 16-slot window per lane group.
+    // No branch anywhere: rows past the end of x read the last row and are zeroed by a select.
+    const int ss = tid & 3, srow = tid >> 2;                 // row-major staging: slot (st = ss / 2, hi = ss % 2), row srow + 64 q
+    const int t_st = wave & 1, t_mb = wave >> 1;             // transposed staging: K step, block t_mb + 2 q, slot half hi, feature j
+    auto frag_index = [&](int mb_, int st_, int hi_, int j_, int MB_) {   // u32x4 index inside one term of one buffer
+        return (mb_ * S + st_) * 64 + hi_ * 32 + ((j_ + 2 * (2 * st_ + hi_)) & 31);
+    };
     const float* a_src[WM];
     const float* b_src[WN];
+    int a_dst[WM], b_dst[WN];
     bool b_live[WN];
 #pragma unroll
     for (int q = 0; q < WM; ++q) {
-        const int m = 32 * (smb + 2 * q) + j;
-        a_src[q] = TA ? Wp + m + (long)(16 * sst + 8 * hi) * p.ldk : Wp + (long)m * p.ldn + 16 * sst + 8 * hi;
+        if constexpr (TA) {
+            const int m = 32 * (t_mb + 2 * q) + j;
+            a_src[q] = Wp + m + (long)(16 * t_st + 8 * hi) * p.ldk;
+            a_dst[q] = frag_index(t_mb + 2 * q, t_st, hi, j, MBA);
+        } else {
+            const int m = srow + 64 * q;
+            a_src[q] = Wp + (long)m * p.ldn + 8 * ss;
+            a_dst[q] = frag_index(m >> 5, ss >> 1, ss & 1, m & 31, MBA);
+        }
     }
 #pragma unroll
     for (int q = 0; q < WN; ++q) {
-        const int r = 32 * (smb + 2 * q) + j;
+        const int r = srow + 64 * q;
         b_live[q] = r < mrows;
-        b_src[q] = xp + (long)min(r, mrows - 1) * p.k + 16 * sst + 8 * hi;
+        b_src[q] = xp + (long)min(r, mrows - 1) * p.k + 8 * ss;
+        b_dst[q] = frag_index(r >> 5, ss >> 1, ss & 1, r & 31, MBB);
     }
     float ia[WM][8], ib[WN][8];
     auto request = [&](int kc) {
@@ -3861,7 +3881,7 @@ __global__ __launch_bounds__(kLinGemmThreads) void linear_gemm_kernel(const nlam
         for (int q = 0; q < WM; ++q) {
             const BfFrag<NS> f = split8<NS>(ia[q]);
 #pragma unroll
-            for (int t = 0; t < NS; ++t) As[(size_t)buf * kAv + (((size_t)t * MBA + (smb + 2 * q)) * S + sst) * 64 + lane] = f.t[t];
+            for (int t = 0; t < NS; ++t) As[(size_t)buf * kAv + (size_t)t * MBA * S * 64 + a_dst[q]] = f.t[t];
         }
 #pragma unroll
         for (int q = 0; q < WN; ++q) {
@@ -3870,7 +3890,7 @@ __global__ __launch_bounds__(kLinGemmThreads) void linear_gemm_kernel(const nlam
             for (int e = 0; e < 8; ++e) x[e] = b_live[q] ? ib[q][e] : 0.f;
             const BfFrag<NS> f = split8<NS>(x);
 #pragma unroll
-            for (int t = 0; t < NS; ++t) Bs[(size_t)buf * kBv + (((size_t)t * MBB + (smb + 2 * q)) * S + sst) * 64 + lane] = f.t[t];
+            for (int t = 0; t < NS; ++t) Bs[(size_t)buf * kBv + (size_t)t * MBB * S * 64 + b_dst[q]] = f.t[t];
         }
     };
 
@@ -3897,9 +3917,9 @@ __global__ __launch_bounds__(kLinGemmThreads) void linear_gemm_kernel(const nlam
 #pragma unroll
             for (int t = 0; t < NS; ++t) {
 #pragma unroll
-                for (int mb = 0; mb < WM; ++mb) a[t][mb] = Ab[(((size_t)t * MBA + (wm * WM + mb)) * S + st) * 64 + lane];
+                for (int mb = 0; mb < WM; ++mb) a[t][mb] = Ab[(size_t)t * MBA * S * 64 + frag_index(wm * WM + mb, st, hi, j, MBA)];
 #pragma unroll
-                for (int nb = 0; nb < WN; ++nb) b[t][nb] = Bb[(((size_t)t * MBB + (wn * WN + nb)) * S + st) * 64 + lane];
+                for (int nb = 0; nb < WN; ++nb) b[t][nb] = Bb[(size_t)t * MBB * S * 64 + frag_index(wn * WN + nb, st, hi, j, MBB)];
             }
 #pragma unroll
             for (int ord = NS - 1; ord >= 0; --ord)
@@ -4385,7 +4405,7 @@ __global__ void pack_bf_table_kernel(const nlam_pack_rec_t* recs) {
 int nlam_detail::wbf_min_supertiles = 192;
 int nlam_detail::wbf_half = 1;              // bit 0: forward, bit 1: backward on 4-wave workgroups, two per CU (NLAM_TUNE_WBF_HALF)
 int nlam_detail::lin_resident_wgs = 256;    // NLAM_LIN_WGS (experiments): one per CU
-int nlam_detail::lin_gemm = 1;              // nlam_linear: LDS-tiled GEMM for n % 128 == 0 (0: the strip kernel of rounds 2-4, for A/B)
+int nlam_detail::lin_gemm = 1;              // nlam_linear: LDS-tiled GEMM for n % 128 == 0 where it wins (0: the strip kernel of rounds 2-4; 2: wherever it applies)
 long nlam_detail::lin_gemm_big_rows = 32768;   // 128-row tiles from here (63 784 grid nodes), 64-row tiles below (6 561 mesh nodes)
 int nlam_detail::wgrad_big_min_rows = 0;    // rows from which a wide weight gradient uses 256 x 256 windows (0 = always, the round-2 behaviour)
 int nlam_detail::wgrad_min_parts = 128;     // row slices a weight gradient of more than that many 32-row chunks is cut into at least
@@ -4444,8 +4464,8 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     }
     if (key == NLAM_TUNE_LIN_GEMM) {
         if (value < 0) return NLAM_EINVAL;
-        nlam_detail::lin_gemm = value != 0 ? 1 : 0;
-        if (value > 1) nlam_detail::lin_gemm_big_rows = value;   // values above 1: also the row count from which 128-row tiles are used
+        nlam_detail::lin_gemm = value >= 2 ? (value == 2 ? 2 : 1) : value;   // 0 off, 1 where it wins, 2 wherever it applies
+        if (value > 2) nlam_detail::lin_gemm_big_rows = value;   // values above 2: the row count from which 128-row tiles are used
         return 0;
     }
     return NLAM_EINVAL;
@@ -5599,7 +5619,13 @@ int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream) {
     else if (KB == 2 && MB == 1) NLAM_LAUNCH_LIN(2, 1);
     else if (KB == 1 && MB == 2) NLAM_LAUNCH_LIN(1, 2);
     else if (KB == 2 && MB == 2) NLAM_LAUNCH_LIN(2, 2);
-    else if (nlam_detail::lin_gemm != 0 && p->n % 128 == 0 && p->k <= kMaxWide && p->n <= kMaxWide && lin_gemm_layout(p) != 0) {
+    else if (nlam_detail::lin_gemm != 0 && p->n % 128 == 0 && p->k <= kMaxWide && p->n <= kMaxWide && lin_gemm_layout(p) != 0 &&
+             // where it wins (profiles/round5/linear_bench.log, isolated launches): one term everywhere (1.3-2.1x); two / three terms
+             // -- 114 KB of LDS, one workgroup per CU -- on the mesh-level products up to K = 256 (1.4-1.5x) and on the grid-level
+             // ones from K = 512 (1.1x); the strip kernel keeps three-term 63 784 x 256 (0.9x) and 6 561 x 512 (0.9x).
+             // nlam_set_tuning(NLAM_TUNE_LIN_GEMM, 2) forces it everywhere it applies (tests).
+             (ns == 1 || nlam_detail::lin_gemm == 2 ||
+              (p->rows >= nlam_detail::lin_gemm_big_rows ? p->k >= 512 : p->k <= 256))) {
         // LDS-tiled GEMM (linear_gemm_kernel): 128 x 128 tiles from 32 768 rows, 64-row tiles below
         const bool ta = lin_gemm_layout(p) == 2;
         const bool big = p->rows >= nlam_detail::lin_gemm_big_rows;

@@ -207,7 +207,7 @@ class GradBuckets:
 
 
 class _SegmentedStep:
-    """The captured training step as a CHAIN of HIP graphs on one high-priority stream plus weight-gradient graphs on side
+    """The captured training step as a CHAIN of HIP graphs on one stream plus weight-gradient graphs on side
     streams (DESIGN.md finding 39).
 
     Why not one graph with forks: the HIP-graph executor of ROCm 7.2 gives the k-th child of a node hardware queue
@@ -217,8 +217,8 @@ class _SegmentedStep:
     late and in reverse.  Here the executor never sees a fork:
 
     * the chain -- zero-grad, weight packing, forward, loss, every data-gradient kernel -- is recorded as ``S`` LINEAR graphs
-      (segments), replayed back to back on ONE stream of high priority (its own hardware queue: ROCclr keeps a queue pool per
-      priority, so no side stream shares it);
+      (segments), replayed back to back on ONE stream (normal priority: on a high-priority stream -- its own hardware queue,
+      ROCclr keeps a queue pool per priority -- the step took 4-5 ms instead of 1.9: the priority starves the side queues);
     * a fork point (``ops.OVERLAP.run``) records nothing: its closure is kept, and after ``K`` fork points (or behind a
       dead-end MLP, whose data-gradient kernel is side work too) the chain segment is closed;
     * after the chain has been recorded the closures of segment ``i`` are recorded into one linear graph per side stream
@@ -391,12 +391,19 @@ class Trainer:
         self.module = module
         self.use_graph = use_graph
         self.overlap_wgrad = overlap_wgrad
-        # how a captured step is replayed: "segments" = a chain of linear graphs on one high-priority stream + weight-gradient
+        # how a captured step is replayed: "segments" = a chain of linear graphs on one stream + weight-gradient
         # graphs on side streams (_SegmentedStep); "forks" = ONE graph whose weight-gradient branches the executor places
-        self.executor = executor or os.environ.get("NLAM_EXEC", "forks")
-        if self.executor not in ("segments", "forks"):
-            raise ValueError(f"unknown executor {self.executor!r}: 'segments' or 'forks'")
-        self.forks_per_segment = int(forks_per_segment if forks_per_segment is not None else os.environ.get("NLAM_SEG_FORKS", "3"))
+        # "auto" (default): measured, round 5 (profiles/round5/ab_segmented_executor_wide.log, same box each): the segmented
+        # executor wins where the kernels are long against a graph-launch boundary -- cfg3 (d = 256) 46.8 -> 43.7 ms, cfg5
+        # (d = 512) 139.7 -> 129.8 ms, cfg4 (Hi-LAM d = 128) 11.18 -> 10.72 ms -- and loses where they are not: cfg2 (d = 64)
+        # 1.75 -> 1.94 ms, cfg4p (chunked Hi-LAM-Parallel) 6.43 -> 6.51 ms.  So: segments for modules with a fused width above 64
+        # and no chunked (SplitMLPs) stage, the one-graph executor otherwise.
+        self.executor = executor or os.environ.get("NLAM_EXEC", "auto")
+        if self.executor not in ("segments", "forks", "auto"):
+            raise ValueError(f"unknown executor {self.executor!r}: 'segments', 'forks' or 'auto'")
+        if self.executor == "auto":
+            self.executor = self._pick_executor(module)
+        self.forks_per_segment = int(forks_per_segment if forks_per_segment is not None else os.environ.get("NLAM_SEG_FORKS", "12"))
         if early_leaf_backward is None:
             early_leaf_backward = os.environ.get("NLAM_EARLY_LEAF", "0") == "1"
         self.early_leaf_backward = early_leaf_backward
@@ -414,6 +421,12 @@ class Trainer:
             self.opt = AdamWFlat(self.fp.flat, self.fp.grad, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         else:
             self.opt = optimizer_factory(self.fp.flat, self.fp.grad)
+
+    @staticmethod
+    def _pick_executor(module) -> str:
+        wide = any(p.dim() == 2 and p.shape[0] > 64 for p in module.parameters())
+        chunked = any(type(m).__name__ == "SplitMLPs" for m in module.modules())
+        return "segments" if (wide and not chunked) else "forks"
 
     # ---- HIP-graph step: zero-grad + forward + loss + backward are ~330 launches of 3-150 us at cfg2,
     # which eager Python cannot issue as fast as the GPU retires them; captured once, replayed per step ----
@@ -577,12 +590,14 @@ class Trainer:
     _bucket_plan = None
 
     def _capture_segments(self, t_before):
-        """Record the step as a _SegmentedStep (see its docstring): chain segments on a high-priority stream, one
+        """Record the step as a _SegmentedStep (see its docstring): chain segments on one stream, one
         weight-gradient graph per (segment, side stream), the optimizer as a last graph behind the join."""
         import os
 
         if self._chain_stream is None:
-            self._chain_stream = torch.cuda.Stream(priority=int(os.environ.get("NLAM_CHAIN_PRIO", "-1")))
+            # normal priority: a HIGH-priority chain stream does get a hardware queue of its own, but the queue priority starves
+            # and context-switches the side queues instead of sharing the chip with them: 4.0-4.9 ms per cfg2 step against 1.94
+            self._chain_stream = torch.cuda.Stream(priority=int(os.environ.get("NLAM_CHAIN_PRIO", "0")))
             self._entry_event, self._exit_event = torch.cuda.Event(), torch.cuda.Event()
         cs = self._chain_stream
         seg = _SegmentedStep(self, self.forks_per_segment)

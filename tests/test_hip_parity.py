@@ -1189,6 +1189,14 @@ def test_node_linear_gemm_tiles_and_modes(dev, k, n, rows, mode, tol):
     from neural_lam_amd import ops
 
     lib = L.load()
+    try:
+        _node_linear_gemm_body(dev, lib, L, ops, k, n, rows, mode, tol)
+    finally:
+        assert lib.nlam_set_tuning(L.TUNE_LIN_GEMM, 1) == 0
+
+
+def _node_linear_gemm_body(dev, lib, L, ops, k, n, rows, mode, tol):
+    assert lib.nlam_set_tuning(L.TUNE_LIN_GEMM, 2) == 0   # the GEMM wherever it applies (the default dispatch leaves two shapes to the strip kernel)
     torch.manual_seed(5)
     kin, col0 = 2 * k, k
     W = torch.randn(n, kin, device=dev) / k ** 0.5
@@ -1212,7 +1220,7 @@ def test_node_linear_gemm_tiles_and_modes(dev, k, n, rows, mode, tol):
             assert lib.nlam_set_tuning(L.TUNE_LIN_GEMM, 0) == 0
             old = ops._linear_launch(x, W.data_ptr() + 4 * col0, kin, 1, k, n, mm_flags=mm)
         finally:
-            assert lib.nlam_set_tuning(L.TUNE_LIN_GEMM, 1) == 0
+            assert lib.nlam_set_tuning(L.TUNE_LIN_GEMM, 2) == 0
         new = ops._linear_launch(x, W.data_ptr() + 4 * col0, kin, 1, k, n, mm_flags=mm)
         assert rel_err(new.cpu(), old.cpu()) < 1e-5
 

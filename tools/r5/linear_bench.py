@@ -41,7 +41,7 @@ for rows in (63784, 6561):
             for layout, fn in (("fwd", lambda: ops._linear_launch(x, W.data_ptr() + 4 * k, 3 * k, 1, k, n, out=out, mm_flags=mm)),
                                ("dgrad", lambda: ops._linear_launch(g, W.data_ptr() + 4 * k, 1, 3 * k, n, k, out=dx, mm_flags=mm))):
                 res = {}
-                for name, v in (("strip", 0), ("gemm", 1)):
+                for name, v in (("strip", 0), ("gemm", 2)):
                     assert lib.nlam_set_tuning(L.TUNE_LIN_GEMM, v) == 0
                     res[name] = timed(fn)
                 assert lib.nlam_set_tuning(L.TUNE_LIN_GEMM, 1) == 0
