@@ -268,6 +268,8 @@ def lightning_shaped(cfg, device, steps, precision="fp32"):
     what torch DDP needs), no flat buffers, no fused optimizer.  Timed twice: as it is (``eager``), and with
     ``trainer.graphed_training_step`` inside ``training_step`` (forward and backward each one HIP-graph replay; the optimizer
     still torch's).  Reported beside ``value``, never as it."""
+    import gc
+
     from neural_lam_amd.trainer import graphed_training_step
 
     out = {"what": "HIP modules under a Lightning-shaped loop: zero_grad + training_step + loss.backward() + torch.optim.AdamW(lr=1e-3, betas=(0.9, 0.95)).step(), "
@@ -306,7 +308,8 @@ def lightning_shaped(cfg, device, steps, precision="fp32"):
         out[f"ms_per_step_{name}_torch_adamw"] = (time.perf_counter() - t0) / n * 1e3
         out[f"steps_{name}"] = n
         out[f"final_loss_{name}"] = float(loss)
-        del step, opt, fn
+        del step, opt, fn, one, loss
+        gc.collect()   # the captured callable and its replay function reference each other
         torch.cuda.empty_cache()
     return out
 
@@ -630,6 +633,23 @@ def main():
             }
 
     amp.__exit__(None, None, None)
+    launch_mode = "eager" if args.eager else (
+        "hip_graph, one-graph executor (zero-grad + fwd + loss + bwd [+ AdamW at world 1] captured once, weight gradients as forked branches; "
+        "on_after_batch_transfer writes the graph's inputs before; at world > 1 the all-reduce and the optimizer's own graph follow each replay)"
+        if trainer.executor == "forks" else
+        "hip_graph, segmented executor (the chain -- zero-grad, fwd, loss, data gradients -- as linear graphs replayed back to back on one stream, "
+        f"weight gradients as graphs on side streams behind per-segment events, {trainer.forks_per_segment} fork points per segment; the optimizer's "
+        "graph behind the join; at world > 1 gradient buckets are all-reduced per segment)")
+    if world == 1:
+        # the baseline legs below build their own models: release the timed trainer first (its graphs' private pools hold every saved
+        # activation of the step -- ~160 GB at cfg5; the executor object and the trainer reference each other, hence the collection)
+        import gc
+
+        del trainer, step, forecaster
+        if not args.eager:
+            del fgraph, run_forecast
+        gc.collect()
+        torch.cuda.empty_cache()
     drop_in = None
     if world == 1 and not args.no_lightning_leg:
         drop_in = lightning_shaped(cfg, device, args.steps, args.precision)
@@ -651,13 +671,7 @@ def main():
             "dtype": "f32" if args.precision == "fp32" else "bf16",
             "matmul_mode": ops.matmul_mode_name() if args.precision == "fp32" else "bf16 (autocast)",
             "data": "synthetic",
-            "launch_mode": "eager" if args.eager else (
-                "hip_graph, one-graph executor (zero-grad + fwd + loss + bwd [+ AdamW at world 1] captured once, weight gradients as forked branches; "
-                "on_after_batch_transfer writes the graph's inputs before; at world > 1 the all-reduce and the optimizer's own graph follow each replay)"
-                if trainer.executor == "forks" else
-                "hip_graph, segmented executor (the chain -- zero-grad, fwd, loss, data gradients -- as linear graphs replayed back to back on one stream, "
-                f"weight gradients as graphs on side streams behind per-segment events, {trainer.forks_per_segment} fork points per segment; the optimizer's "
-                "graph behind the join; at world > 1 gradient buckets are all-reduced per segment)"),
+            "launch_mode": launch_mode,
             "forecast_steps_per_s": forecast_steps_per_s,
             "rccl_ranks_seen": ranks_seen,
             "final_loss": float(loss),
@@ -684,8 +698,6 @@ def main():
             out["loss_step0_rel_diff_vs_oracle"] = abs(loss_step0 - o0) / abs(o0)
             out["cpu_baseline"] = cpu_baseline(cfg)
         if world == 1 and not args.no_gpu_baseline:
-            del trainer, step, forecaster
-            torch.cuda.empty_cache()
             g = gpu_reference_equivalent(cfg, device, autocast=args.precision == "bf16")
             for k in ("nondeterministic", "deterministic"):
                 v = g.get(f"ms_per_step_{k}")

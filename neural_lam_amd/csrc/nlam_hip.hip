@@ -98,6 +98,7 @@ extern int wbf_min_supertiles;                                     // nlam_set_t
 extern int wbf_half;                                               // nlam_set_tuning (defined in slice 1)
 extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
 extern int wgrad_min_parts;                                        // nlam_set_tuning (defined in slice 1)
+extern int wgrad_min_parts_wide;                                   // the same for weight matrices of more than 128 rows
 extern int wgrad_big_min_rows;                                     // nlam_set_tuning (defined in slice 1)
 extern int lin_resident_wgs;                                       // workgroups of a resident-weight nlam_linear launch (slice 1)
 extern int lin_gemm;                                               // nlam_linear on the LDS-tiled GEMM where it applies (NLAM_TUNE_LIN_GEMM)
@@ -4409,6 +4410,7 @@ int nlam_detail::lin_gemm = 1;              // nlam_linear: LDS-tiled GEMM for n
 long nlam_detail::lin_gemm_big_rows = 32768;   // 128-row tiles from here (63 784 grid nodes), 64-row tiles below (6 561 mesh nodes)
 int nlam_detail::wgrad_big_min_rows = 0;    // rows from which a wide weight gradient uses 256 x 256 windows (0 = always, the round-2 behaviour)
 int nlam_detail::wgrad_min_parts = 128;     // row slices a weight gradient of more than that many 32-row chunks is cut into at least
+int nlam_detail::wgrad_min_parts_wide = 64; // ... when the weight matrix has more than 128 rows (nlam_set_tuning sets both)
 int nlam_detail::wgrad_chunks_per_wg = 8;   // A/B at cfg2 (tools/ab_bench.sh): 2.13 -> 2.06 ms per step against one chunk per workgroup
 #endif
 
@@ -4455,6 +4457,7 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_WGRAD_MIN_PARTS) {
         if (value < 1) return NLAM_EINVAL;
         nlam_detail::wgrad_min_parts = value;
+        nlam_detail::wgrad_min_parts_wide = value;
         return 0;
     }
     if (key == NLAM_TUNE_WGRAD_CHUNKS) {
@@ -4652,7 +4655,11 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     // with 512 partials per weight matrix those were ~0.7 GB of traffic per cfg2 step (reduce_jobs: 290 us of 3.7 ms of kernel time)
     const long cpw = nlam_detail::wgrad_chunks_per_wg < 1 ? 1 : nlam_detail::wgrad_chunks_per_wg;   // nlam_set_tuning
     long np = total_chunks <= 128 ? total_chunks : (total_chunks + cpw - 1) / cpw;
-    const long minp = nlam_detail::wgrad_min_parts < 1 ? 1 : nlam_detail::wgrad_min_parts;   // nlam_set_tuning (default 128)
+    // nlam_set_tuning; defaults 128, and 64 for weight matrices of more than 128 rows (d >= 256): re-measured under the segmented
+    // executor (profiles/round5/ab_wgrad_knobs_segmented.log: cfg3 44.1 -> 43.3 / 43.2 -> 42.5 ms, under autocast 29.4 -> 28.7;
+    // cfg5 unchanged; at d <= 128 the value 64 LOSES 1-2 %: cfg2 1.732 -> 1.745, cfg4 10.67 -> 10.86)
+    const int minp_cfg = p->m > 128 ? nlam_detail::wgrad_min_parts_wide : nlam_detail::wgrad_min_parts;
+    const long minp = minp_cfg < 1 ? 1 : minp_cfg;
     if (np < minp && total_chunks > minp) np = minp;
     long cap = 512;
     if (p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) np = (total_chunks + 3) / 4;   // streaming kernel: >= 128 rows per workgroup

@@ -62,3 +62,6 @@ for k in r['kernels']: print(k['launch'], round(k['avg_launch_ms']*1e3,1), 'us x
 PY
 timeout 1800 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1
 tail -3 $OUT/pytest_gpu.log
+# the printed errors of the bf16-noise tests (HIP under autocast and the reference under autocast, both against the fp32 oracle on the GPU)
+timeout 900 python -m pytest tests/test_full_size_parity.py -q -s -m gpu -k "noise or cfg5_full" 2>&1 | grep -E "under bf16 autocast|oracle fp32-vs-fp64|passed|failed" > $OUT/bf16_noise.log
+cat $OUT/bf16_noise.log
