@@ -234,7 +234,9 @@ class _SegmentedStep:
     """
 
     def __init__(self, trainer, forks_per_segment: int):
-        self.tr = trainer
+        import weakref
+
+        self.tr = weakref.proxy(trainer)   # (the trainer owns this object: no reference cycle, its graphs' pools go when it goes)
         self.K = max(1, int(forks_per_segment))
         self.chain = []            # CUDAGraph per segment
         self.jobs = [[]]           # per segment: [(side stream index, closure)]
@@ -247,7 +249,6 @@ class _SegmentedStep:
         self.pool = torch.cuda.graph_pool_handle()
         self.side_pool = torch.cuda.graph_pool_handle()
         self.seg_params = []       # per segment: ids of the parameters whose gradients its side work completed
-        self.loss = None
         self.mode = "relaxed"      # capture error mode: segments are closed / opened from inside autograd's backward
 
     # ---- recording ----
