@@ -271,6 +271,9 @@ int32_t nlam_max_width(void);
  *   rounds 2-4 (one term: everywhere; two / three terms: 6 561-row class up to K = 256, 63 784-row class from K = 512), 0 = never,
  *   2 = wherever it applies (tests); a value above 2 sets the row count from which its tiles are 128 rows high (default 32 768). */
 #define NLAM_TUNE_LIN_GEMM 7
+/*   NLAM_TUNE_WBF_V4: the split-bf16 wide kernels' instantiations with branch-free 16-byte chunk accesses for launches whose
+ *   widths are all multiples of 4 (default 1; 0 = the generic lane-predicated accessors everywhere, for A/B runs). */
+#define NLAM_TUNE_WBF_V4 8
 int32_t nlam_set_tuning(int32_t key, int32_t value);
 /* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this
  * call; 0 when the call runs on the narrow (weights-in-LDS) kernels. */

@@ -27,6 +27,7 @@ TUNE_WGRAD_MIN_PARTS = 4
 TUNE_WGRAD_BIG_MIN_ROWS = 5
 TUNE_WBF_HALF = 6
 TUNE_LIN_GEMM = 7
+TUNE_WBF_V4 = 8
 TILE_SPLIT = 1 << 30
 
 EXPORTS = [
@@ -418,6 +419,8 @@ def load():
         lib.nlam_set_tuning(TUNE_WGRAD_MIN_PARTS, int(os.environ["NLAM_WGRAD_MIN_PARTS"]))
     if os.environ.get("NLAM_WBF_HALF"):
         lib.nlam_set_tuning(TUNE_WBF_HALF, int(os.environ["NLAM_WBF_HALF"]))
+    if os.environ.get("NLAM_WBF_V4"):
+        lib.nlam_set_tuning(TUNE_WBF_V4, int(os.environ["NLAM_WBF_V4"]))
     if os.environ.get("NLAM_LIN_GEMM"):
         lib.nlam_set_tuning(TUNE_LIN_GEMM, int(os.environ["NLAM_LIN_GEMM"]))
     if os.environ.get("NLAM_WGRAD_CHUNKS"):

@@ -96,6 +96,7 @@ int32_t wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream);      // slice 4
 int32_t wgrad_wbf_group(const nlam_wgrad_t* ps, int n, hipStream_t stream);   // slice 4
 extern int wbf_min_supertiles;                                     // nlam_set_tuning (defined in slice 1)
 extern int wbf_half;                                               // nlam_set_tuning (defined in slice 1)
+extern int wbf_v4;                                                 // branch-free chunk accessors in the split-bf16 wide kernels (NLAM_TUNE_WBF_V4)
 extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
 extern int wgrad_min_parts;                                        // nlam_set_tuning (defined in slice 1)
 extern int wgrad_min_parts_wide;                                   // the same for weight matrices of more than 128 rows
@@ -311,6 +312,37 @@ __device__ __forceinline__ void store_chunk(float* row, int w, int t, int hi, bo
             for (int c = 0; c < 4; ++c)
                 if (c0 + c < w) row[c0 + c] = v[c];
         }
+    }
+}
+
+// 16 zero bytes: what an absent tensor / a lane outside its row reads, so that a load can stay unconditional (finding 26)
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// V4 = every width of the launch is a multiple of 4 (compile time, chosen by the launcher): a chunk is one 16-byte access and
+// the load is UNCONDITIONAL -- a lane outside its row, or whose tensor is absent, reads the zero buffer through a pointer select.
+// The generic load_chunk is a lane-predicated branch around the access with the element-wise fallback compiled into every call
+// site: an exec-mask save / restore per chunk, a join at which the wait-counter pass drains the load queue (finding 26), and
+// hundreds of hoisted scalar masks (finding 29).  Round 5, the split-bf16 wide kernels.
+template <bool V4>
+__device__ __forceinline__ f32x4 load_chunk_v(const float* row, int w, int t, int hi, bool valid) {
+    if constexpr (!V4) {
+        return load_chunk(row, w, t, hi, valid);
+    } else {
+        int c0 = 8 * t + 4 * hi;
+        asm volatile("" : "+v"(c0));
+        const float* q = (valid && c0 < w) ? row + c0 : g_zero16;
+        return *reinterpret_cast<const f32x4*>(q);
+    }
+}
+
+template <bool V4>
+__device__ __forceinline__ void store_chunk_v(float* row, int w, int t, int hi, bool valid, f32x4 v) {
+    if constexpr (!V4) {
+        store_chunk(row, w, t, hi, valid, v);
+    } else {
+        int c0 = 8 * t + 4 * hi;
+        asm volatile("" : "+v"(c0));
+        if (valid && c0 < w) *reinterpret_cast<f32x4*>(row + c0) = v;
     }
 }
 
@@ -1807,7 +1839,6 @@ __global__ __launch_bounds__(kBlockThreads) void mlp_bwd_kernel(const nlam_mlp_b
 // ---------------------------------------------------------------------------
 // 16 zero bytes: the source of a load whose tensor is absent (a null row pointer becomes this address with stride 0, so the
 // load stays unconditional) and of LDS-DMA lanes past the end of a row
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 // column sums of the wave's staged 32-column block: lane -> (column, half of the rows)
 __device__ __forceinline__ float block_colsum_half(const float* stg, int lane) {
@@ -4405,6 +4436,7 @@ __global__ void pack_bf_table_kernel(const nlam_pack_rec_t* recs) {
 #if NLAM_IN_TU(1)
 int nlam_detail::wbf_min_supertiles = 192;
 int nlam_detail::wbf_half = 1;              // bit 0: forward, bit 1: backward on 4-wave workgroups, two per CU (NLAM_TUNE_WBF_HALF)
+int nlam_detail::wbf_v4 = 1;                // split-bf16 wide kernels: the V4 instantiations where every width is a multiple of 4 (NLAM_TUNE_WBF_V4; 0 for A/B)
 int nlam_detail::lin_resident_wgs = 256;    // NLAM_LIN_WGS (experiments): one per CU
 int nlam_detail::lin_gemm = 1;              // nlam_linear: LDS-tiled GEMM for n % 128 == 0 where it wins (0: the strip kernel of rounds 2-4; 2: wherever it applies)
 long nlam_detail::lin_gemm_big_rows = 32768;   // 128-row tiles from here (63 784 grid nodes), 64-row tiles below (6 561 mesh nodes)
@@ -4463,6 +4495,11 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_WGRAD_CHUNKS) {
         if (value < 1) return NLAM_EINVAL;
         nlam_detail::wgrad_chunks_per_wg = value;
+        return 0;
+    }
+    if (key == NLAM_TUNE_WBF_V4) {
+        if (value < 0 || value > 1) return NLAM_EINVAL;
+        nlam_detail::wbf_v4 = value;
         return 0;
     }
     if (key == NLAM_TUNE_LIN_GEMM) {
@@ -4749,17 +4786,23 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
             // weight-gradient kernels of the side streams, measured 20 % slower in the captured cfg3 step: 59.8 vs 49.4 ms)
             const long wcap = pl.nw == 4 ? 2 * kNumCUs : kNumCUs;
             const int wblocks = (int)(nsuper < wcap ? (nsuper < 1 ? 1 : nsuper) : wcap);
-#define NLAM_LAUNCH_FWD_WBF(NS_, NW_, FG_, FB_, RT_, RTP_)                                                                    \
+            bool v4 = nlam_detail::wbf_v4 != 0 && p->hid % 4 == 0 && p->dout % 4 == 0;   // every chunk a whole 16-byte piece: the branch-free chunk accessors
+            for (int s_ = 0; s_ < p->nsrc; ++s_) v4 = v4 && p->src[s_].width % 4 == 0;
+#define NLAM_LAUNCH_FWD_WBF1(NS_, NW_, FG_, FB_, RT_, RTP_, SBF_, V4_)                                                         \
     do {                                                                                                                      \
-        int rc = set_lds(mlp_fwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_, RTP_>, lds);                                             \
+        int rc = set_lds(mlp_fwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_, RTP_, SBF_, V4_>, lds);                                  \
         if (rc != 0) return rc;                                                                                               \
-        hipLaunchKernelGGL((mlp_fwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_, RTP_>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p); \
+        hipLaunchKernelGGL((mlp_fwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_, RTP_, SBF_, V4_>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p); \
     } while (0)
-#define NLAM_LAUNCH_FWD_WBF_S(NW_, FG_, FB_, RT_, RTP_)                                                                          \
-    do {                                                                                                                      \
-        int rc = set_lds(mlp_fwd_wbf_kernel<1, NW_, FG_, FB_, RT_, RTP_, true>, lds);                                          \
-        if (rc != 0) return rc;                                                                                               \
-        hipLaunchKernelGGL((mlp_fwd_wbf_kernel<1, NW_, FG_, FB_, RT_, RTP_, true>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p); \
+#define NLAM_LAUNCH_FWD_WBF(NS_, NW_, FG_, FB_, RT_, RTP_)                              \
+    do {                                                                                \
+        if (v4) NLAM_LAUNCH_FWD_WBF1(NS_, NW_, FG_, FB_, RT_, RTP_, false, true);       \
+        else NLAM_LAUNCH_FWD_WBF1(NS_, NW_, FG_, FB_, RT_, RTP_, false, false);         \
+    } while (0)
+#define NLAM_LAUNCH_FWD_WBF_S(NW_, FG_, FB_, RT_, RTP_)                                 \
+    do {                                                                                \
+        if (v4) NLAM_LAUNCH_FWD_WBF1(1, NW_, FG_, FB_, RT_, RTP_, true, true);          \
+        else NLAM_LAUNCH_FWD_WBF1(1, NW_, FG_, FB_, RT_, RTP_, true, false);            \
     } while (0)
             if (p->flags & NLAM_F_STORE_BF16) {   // z1 / xhat as bf16 rows: one term, whole blocks, the shapes of store_bf16_ok()
                 if (!store_bf16_ok(p)) return NLAM_EUNSUP;
@@ -4989,17 +5032,23 @@ int32_t nlam_detail::bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream) {
             }
             const size_t lds = bwd_wbf_lds(p, wns, pl);
             const int wblocks = nlam_mlp_bwd_blocks(p) / pl.rg;
-#define NLAM_LAUNCH_BWD_WBF(NS_, NW_, FG_, FB_, RT_)                                                                          \
+            bool v4 = nlam_detail::wbf_v4 != 0 && p->hid % 4 == 0 && p->dout % 4 == 0 && p->dz2_ld == 0;
+            for (int s_ = 0; s_ < p->nsrc; ++s_) v4 = v4 && p->src[s_].width % 4 == 0;
+#define NLAM_LAUNCH_BWD_WBF1(NS_, NW_, FG_, FB_, RT_, SBF_, V4_)                                                               \
     do {                                                                                                                      \
-        int rc = set_lds(mlp_bwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_>, lds);                                                   \
+        int rc = set_lds(mlp_bwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_, SBF_, V4_>, lds);                                        \
         if (rc != 0) return rc;                                                                                               \
-        hipLaunchKernelGGL((mlp_bwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p);    \
+        hipLaunchKernelGGL((mlp_bwd_wbf_kernel<NS_, NW_, FG_, FB_, RT_, SBF_, V4_>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p); \
     } while (0)
-#define NLAM_LAUNCH_BWD_WBF_S(NW_, FG_, FB_, RT_)                                                                                \
-    do {                                                                                                                      \
-        int rc = set_lds(mlp_bwd_wbf_kernel<1, NW_, FG_, FB_, RT_, true>, lds);                                                \
-        if (rc != 0) return rc;                                                                                               \
-        hipLaunchKernelGGL((mlp_bwd_wbf_kernel<1, NW_, FG_, FB_, RT_, true>), dim3(wblocks), dim3(NW_ * 64), lds, stream, *p);  \
+#define NLAM_LAUNCH_BWD_WBF(NS_, NW_, FG_, FB_, RT_)                               \
+    do {                                                                           \
+        if (v4) NLAM_LAUNCH_BWD_WBF1(NS_, NW_, FG_, FB_, RT_, false, true);        \
+        else NLAM_LAUNCH_BWD_WBF1(NS_, NW_, FG_, FB_, RT_, false, false);          \
+    } while (0)
+#define NLAM_LAUNCH_BWD_WBF_S(NW_, FG_, FB_, RT_)                                  \
+    do {                                                                           \
+        if (v4) NLAM_LAUNCH_BWD_WBF1(1, NW_, FG_, FB_, RT_, true, true);           \
+        else NLAM_LAUNCH_BWD_WBF1(1, NW_, FG_, FB_, RT_, true, false);             \
     } while (0)
             if (p->flags & NLAM_F_STORE_BF16) {
                 if (wns != 1 || p->hid % 32 != 0 || p->dout % 32 != 0 || p->dz2_ld != 0 || pl.cfg == 1) return NLAM_EUNSUP;
