@@ -441,3 +441,87 @@ def test_pack_and_layout_queries_are_host_logic():
     assert lib.nlam_mlp_fwd_pack_records(C.byref(f), recs, 4, C.byref(kind)) == 0                       # a narrow launch has no wide scratch
     assert lib.nlam_set_tuning(L.TUNE_WGRAD_MIN_PARTS, 0) == -1 and lib.nlam_set_tuning(L.TUNE_WGRAD_MIN_PARTS, 128) == 0
     assert lib.nlam_set_tuning(L.TUNE_WGRAD_BIG_MIN_ROWS, -1) == -1 and lib.nlam_set_tuning(L.TUNE_WGRAD_BIG_MIN_ROWS, 0) == 0
+
+
+def test_padded_input_cache_is_keyed_by_tensor_identity():
+    """Advisor finding (round 4, high): FusedMLP._padded_input cached the zero-padded input under (address, shape, version); a
+    fresh activation that the caching allocator placed where an earlier one lived hit the cache with other contents (16 stale
+    returns out of 20 tensors in a CPU check).  The key is now the tensor OBJECT (weak reference) plus its version counter."""
+    mlp = hl.make_mlp([3, 8, 8])
+    stale = 0
+    for k in range(20):
+        x = torch.full((5, 3), float(k))   # same size every time: the allocator hands out the same block again and again
+        p = mlp._padded_input(x)
+        stale += int(not torch.equal(p[:, :3], x))
+        assert p.shape == (5, 4) and float(p[:, 3].abs().max()) == 0.0
+        del x, p
+    assert stale == 0
+    x = torch.randn(7, 3)
+    p1 = mlp._padded_input(x)
+    assert mlp._padded_input(x) is p1            # the same, unmodified tensor: served from the cache (the static feature buffers)
+    x.add_(1.0)                                   # modified in place: the version counter moves, the copy is refreshed
+    p2 = mlp._padded_input(x)
+    assert p2 is not p1 and torch.equal(p2[:, :3], x)
+    y = x.clone()
+    assert mlp._padded_input(y) is not p2         # equal contents, another object: padded again
+
+
+def test_suffix_geometry_with_residual_sources_never_registers_a_weight_image():
+    """Advisor finding (round 4, medium): with hidden_layers >= 2 the last launch of a GNN-layer MLP gets a per-call
+    ``torch.cat([zeros, W1])`` as its first weight; the trainer's weight packer keys on, and re-reads at the start of every later
+    step, the ADDRESS of what it registers -- so that launch's geometry must carry no_pack."""
+    from neural_lam_amd.ops import MlpGeometry
+
+    geom = MlpGeometry(nsrc=3, flags=L.F_ADD_SRC0)
+    srcs = (torch.zeros(4, 8), torch.zeros(4, 8), torch.zeros(4, 8))
+    last, res = hl._suffix_geometry(geom, srcs)
+    assert len(res) == 1 and last.no_pack and last.nsrc == 2
+    plain, res0 = hl._suffix_geometry(MlpGeometry(nsrc=1), (torch.zeros(4, 8),))
+    assert res0 == () and not plain.no_pack
+
+
+def test_trainer_picks_its_executor_and_plans_bucket_launches_on_the_host():
+    """trainer.Trainer(executor="auto") and Trainer._plan_buckets are host logic: the segmented executor for modules with a fused
+    width above 64 and no chunked stage, the one-graph executor otherwise; a gradient bucket is launched behind the LAST chain
+    segment whose side work reported one of its parameters, never before a bucket of lower index."""
+    from neural_lam_amd.trainer import Trainer
+
+    class Narrow(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(192, 64)
+
+    class Wide(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(64, 256)
+
+    class SplitMLPs(torch.nn.Module):   # (the name is what marks a chunked stage)
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(64, 256)
+
+    class Chunked(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.s = SplitMLPs()
+
+    assert Trainer._pick_executor(Narrow()) == "forks"
+    assert Trainer._pick_executor(Wide()) == "segments"
+    assert Trainer._pick_executor(Chunked()) == "forks"
+
+    net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 8))
+    tr = Trainer(net, optimizer_factory=lambda p, g: type("O", (), {"step": lambda self, s=1.0: None})(), bucket_bytes=1)
+    assert len(tr.buckets.bounds) == 6                      # one parameter per bucket, in backward order: 2.bias, 2.weight, 1.bias ...
+    P = tr.fp.params                                        # registration order: 0.weight, 0.bias, 1.weight, 1.bias, 2.weight, 2.bias
+
+    class Seg:
+        chain = [0, 1, 2, 3]
+        # segment 0 completes the last layer's parameters, segment 1 layer 1's weight, segment 2 layer 1's bias AND again 2.weight
+        # (a rollout reports a parameter once per AR step: the last report counts); layer 0 is reported by nobody (last segment)
+        seg_params = [{id(P[5]), id(P[4])}, {id(P[2])}, {id(P[3]), id(P[4])}, set()]
+
+    plan = tr._plan_buckets(Seg())
+    # buckets: 0 = 2.bias (ready at 0), 1 = 2.weight (ready at 2), 2 = 1.bias (ready at 2), 3 = 1.weight (ready at 1, held back by
+    # bucket 1), 4 = 0.bias, 5 = 0.weight (ready with the last segment)
+    assert plan == [[0], [], [1, 2, 3], [4, 5]]
