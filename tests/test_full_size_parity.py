@@ -334,9 +334,7 @@ def test_cfg5_full_rollout_under_bf16_autocast_against_the_oracle_on_the_gpu(dev
 
     import bench
     from neural_lam_amd import graph as G
-    from neural_lam_amd.trainer import Trainer
     from oracle import gnn_layers as og
-    from oracle import models as om
 
     # ---- the oracle's own error: fp32 against fp64 on one mesh layer of this width
     raw = G.create_regular_grid_graph(G.regular_grid_xy(238, 268))
