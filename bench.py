@@ -196,7 +196,7 @@ def cpu_baseline(cfg, budget_s=30.0):
     }
 
 
-def gpu_reference_equivalent(cfg, device, steps=20, autocast=False):
+def gpu_reference_equivalent(cfg, device, steps=20, autocast=False, budget_s=4.0):
     """BASELINE.md section 4 / north_star ">= 5x the reference PyG-CUDA-equivalent step time": the reference's
     formulation -- gather (index_select) -> cat -> Linear -> SiLU -> Linear -> LayerNorm -> index_add_, un-fused,
     autograd, torch.optim.AdamW -- through stock PyTorch-ROCm ops on THIS GPU, same weights and batch, eager (the
@@ -241,7 +241,7 @@ def gpu_reference_equivalent(cfg, device, steps=20, autocast=False):
             t0 = time.perf_counter()
             one()
             torch.cuda.synchronize()
-            nsteps = max(2, min(steps, int(4.0 / max(time.perf_counter() - t0, 1e-4))))   # ~4 s of timed steps per mode
+            nsteps = max(2, min(steps, int(budget_s / max(time.perf_counter() - t0, 1e-4))))   # ~budget_s of timed steps per mode
             one()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -336,7 +336,9 @@ def kernel_rooflines(recs, meta, step_ms, traffic):
     instruction actually issued, and
         mfma_frac = executed MFMA FLOPs / (avg time * dense peak of THAT instruction type)
                     (bf16x3 = 6 bf16 MFMAs per product block against 2.5 PFLOP/s; fp32 MFMA against 157.3 TFLOP/s),
-        hbm_frac  = algorithmic bytes / (avg time * 8 TB/s),
+        hbm_frac  = MINIMUM algorithmic bytes (`algorithmic_bytes_min`: inputs once, outputs once) / (avg time * 8 TB/s);
+                    `algorithmic_bytes` / `hbm_frac_incl_saved_and_partials` = the same plus what this implementation moves on top
+                    (tensors saved for backward, dz1 / dz2 handed to the weight-gradient launch, partial sums),
         frac      = max(mfma_frac, hbm_frac), bound = whichever is larger.
     """
     rows = []
@@ -352,19 +354,69 @@ def kernel_rooflines(recs, meta, step_ms, traffic):
         else:
             exe, peak, inst = m["flops"], PEAK_FP32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32"
         mfma_frac = exe / t / 1e12 / peak
-        hbm_frac = m["bytes"] / t / 1e9 / PEAK_HBM_GBS
+        bmin = m.get("bytes_min", m["bytes"])   # inputs once, outputs once (no partial sums, no dz1 / dz2, no saved tensors)
+        hbm_frac = bmin / t / 1e9 / PEAK_HBM_GBS
+        hbm_frac_incl = m["bytes"] / t / 1e9 / PEAK_HBM_GBS
         rows.append({
             "launch": "%s rows=%d %s" % (key[0], key[1], "x".join(str(k) for k in key[2:5] if not isinstance(k, bool))),
             "what": m["what"], "matmul_mode": m["mm"], "mfma_instruction": inst,
             "launches": per_step, "avg_launch_ms": avg_ms, "total_ms": avg_ms * per_step,
             "algorithmic_flops": m["flops"], "executed_mfma_flops": exe,
             "algorithmic_tflops": m["flops"] / t / 1e12, "executed_tflops": exe / t / 1e12, "mfma_peak_tflops": peak,
-            "mfma_frac": mfma_frac, "algorithmic_bytes": m["bytes"], "hbm_GBps": m["bytes"] / t / 1e9, "hbm_frac": hbm_frac,
+            "mfma_frac": mfma_frac, "algorithmic_bytes_min": bmin, "hbm_GBps": bmin / t / 1e9, "hbm_frac": hbm_frac,
+            "algorithmic_bytes": m["bytes"], "hbm_GBps_incl_saved_and_partials": m["bytes"] / t / 1e9, "hbm_frac_incl_saved_and_partials": hbm_frac_incl,
             "bound": "mfma" if mfma_frac >= hbm_frac else "hbm", "frac": max(mfma_frac, hbm_frac),
             "traffic": traffic.get(":".join(str(k) for k in key[:4])) if traffic else None,
         })
     rows.sort(key=lambda r: -r["total_ms"])
     return rows
+
+
+def also_leg(name, precision, device, rank, world, args, timed_regions, reference=True):
+    """One more BASELINE configuration on the same clock as `value`: build it, 2 warm-up steps, a region
+    of <= 10 steps under the same barrier + synchronize contract (median of up to five regions below 0.5 s, as for `value`),
+    then -- at world 1 -- the same-GPU reference-equivalent (stock PyTorch-ROCm ops, eager / deterministic) on its weights and
+    batch, a few steps each.  Reported under "also"; `value` stays cfg2."""
+    import gc
+
+    from neural_lam_amd.trainer import Trainer
+
+    cfg = CONFIGS[name]
+    t_leg = time.perf_counter()
+    _, _, raw, _, step, batch = build(cfg, device, seed_offset=rank)
+    amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16")
+    amp.__enter__()
+    try:
+        tr = Trainer(step, lr=1e-3, use_graph=not args.eager)
+        k = max(2, min(args.steps, 10))
+        for _ in range(2):
+            tr.step(*batch)
+        regions, loss = timed_regions(tr, batch, k)
+    finally:
+        amp.__exit__(None, None, None)
+    el = sorted(regions)[len(regions) // 2]
+    from neural_lam_amd import ops
+
+    out = {"value": world * cfg["B"] * cfg["T"] * k / el, "unit": "sample-steps/s", "ms_per_step": el / k * 1e3,
+           "steps": k, "warmup": 2, "n_gpus": world, "scaling": "weak", "dtype": "f32" if precision == "fp32" else "bf16",
+           "matmul_mode": ops.matmul_mode_name() if precision == "fp32" else "bf16 (autocast)",
+           "executor": tr.executor, "regions_ms": [x * 1e3 for x in regions], "final_loss": float(loss),
+           "config": {"workload": f"{name}: {cfg['model']}, grid {cfg['nx']}x{cfg['ny']}, hidden_dim {cfg['d']}, {cfg['L']} processor layers, "
+                                  f"ar_steps {cfg['T']}, batch {cfg['B']}/GPU", "global_batch": world * cfg["B"], "parallelism": f"dp{world}"}}
+    del tr, step, batch, loss
+    gc.collect()
+    torch.cuda.empty_cache()
+    if reference and world == 1:
+        g = gpu_reference_equivalent(cfg, device, steps=4, autocast=precision == "bf16", budget_s=1.5)
+        for kk in ("nondeterministic", "deterministic"):
+            v = g.get(f"ms_per_step_{kk}")
+            g[f"speedup_vs_{kk}"] = (v / out["ms_per_step"]) if v else None
+        g.pop("what", None)
+        out["gpu_reference_equivalent"] = g
+        gc.collect()
+        torch.cuda.empty_cache()
+    out["leg_wall_s"] = time.perf_counter() - t_leg
+    return out
 
 
 def main():
@@ -378,6 +430,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-data-path", action="store_true", help="skip the leg that trains from the HBM-resident dataset")
     ap.add_argument("--no-lightning-leg", action="store_true", help="skip the Lightning-shaped (eager / graphed + torch AdamW) leg")
+    ap.add_argument("--no-also", action="store_true", help="skip the cfg3 / cfg5 legs reported under 'also'")
     ap.add_argument("--eager", action="store_true", help="issue every launch from Python instead of replaying a HIP graph")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = run the step inside torch.autocast(bfloat16), as Lightning --precision bf16-mixed does (cfg5)")
@@ -469,24 +522,11 @@ def main():
     value = world * cfg["B"] * cfg["T"] * args.steps / elapsed
 
     # N > 1: BASELINE configs[2] (GraphLAM d = 256, 8 layers, ar_steps 4, one sample per GPU) is the configuration the
-    # 0.9-efficiency target is written for; it is timed as well (same contract, fewer steps) and reported under "also"
+    # 0.9-efficiency target is written for; it is timed as well (same contract, fewer steps) and reported under "also".
+    # (N = 1: the wide configurations are timed further down, after the cfg2 legs have released their trainer: `also_wide`.)
     also = None
     if world > 1 and args.config == "cfg2" and os.environ.get("NLAM_BENCH_ALSO", "1") == "1":
-        cfg3 = CONFIGS["cfg3"]
-        _, _, raw3, _, step3, batch3 = build(cfg3, device, seed_offset=rank)
-        tr3 = Trainer(step3, lr=1e-3, use_graph=not args.eager)
-        k3 = max(2, min(args.steps, 10))
-        for _ in range(2):
-            tr3.step(*batch3)
-        r3, loss3 = timed_regions(tr3, batch3, k3)
-        e3 = sorted(r3)[len(r3) // 2]
-        also = {"cfg3": {"value": world * cfg3["B"] * cfg3["T"] * k3 / e3, "unit": "sample-steps/s", "ms_per_step": e3 / k3 * 1e3,
-                         "steps": k3, "warmup": 2, "n_gpus": world, "scaling": "weak", "dtype": "f32", "regions_ms": [x * 1e3 for x in r3],
-                         "final_loss": float(loss3),
-                         "config": {"workload": f"cfg3: graph_lam, grid {cfg3['nx']}x{cfg3['ny']}, hidden_dim {cfg3['d']}, {cfg3['L']} processor layers, "
-                                                f"ar_steps {cfg3['T']}, batch {cfg3['B']}/GPU", "global_batch": world * cfg3["B"], "parallelism": f"dp{world}"}}}
-        del tr3, step3, batch3
-        torch.cuda.empty_cache()
+        also = {"cfg3": also_leg("cfg3", "fp32", device, rank, world, args, timed_regions, reference=False)}
 
     # forecast throughput (inference rollout, no grad), reported alongside; same launch mode as training
     fsteps = min(args.steps, 200)
@@ -609,6 +649,7 @@ def main():
             tot_flops = sum(r["algorithmic_flops"] * r["launches"] for r in rows)
             tot_exec = sum(r["executed_mfma_flops"] * r["launches"] for r in rows)
             tot_bytes = sum(r["algorithmic_bytes"] * r["launches"] for r in rows)
+            tot_bytes_min = sum(r["algorithmic_bytes_min"] * r["launches"] for r in rows)
             t = ms_per_step * 1e-3
             roofline = {
                 # the contract's fields describe the DOMINANT launch = largest share of the step's kernel time
@@ -620,14 +661,17 @@ def main():
                 "traffic": top["traffic"],
                 "traffic_source": traffic_src,
                 "kernel": top["launch"] + ": " + top["what"],
-                "note": "frac = max(executed MFMA FLOPs / dense peak of the instruction issued, algorithmic HBM bytes / 8 TB/s); "
+                "algorithmic_bytes_min": top["algorithmic_bytes_min"], "algorithmic_bytes": top["algorithmic_bytes"],
+                "note": "frac = max(executed MFMA FLOPs / dense peak of the instruction issued, MINIMUM algorithmic HBM bytes (inputs once, outputs once) / 8 TB/s); "
                         "times = HIP events on the launch stream, eager instrumented pass of %d steps with every launch on one stream (uncontended kernel durations)" % psteps,
                 "kernels": rows[:6],
                 "step": {
                     "ms": ms_per_step,
                     "algorithmic_gflop": tot_flops / 1e9, "executed_mfma_gflop": tot_exec / 1e9, "algorithmic_MB": tot_bytes / 1e6,
                     "algorithmic_tflops": tot_flops / t / 1e12, "frac_of_fp32_mfma_peak": tot_flops / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                    "hbm_GBps_algorithmic": tot_bytes / t / 1e9, "hbm_frac": tot_bytes / t / 1e9 / PEAK_HBM_GBS,
+                    "algorithmic_MB_min": tot_bytes_min / 1e6,
+                    "hbm_GBps_algorithmic": tot_bytes / t / 1e9, "hbm_frac": tot_bytes_min / t / 1e9 / PEAK_HBM_GBS,
+                    "hbm_frac_incl_saved_and_partials": tot_bytes / t / 1e9 / PEAK_HBM_GBS,
                     "sum_of_kernel_ms_in_fused_mlp_launches": sum(r["total_ms"] for r in rows),
                 },
             }
@@ -655,6 +699,12 @@ def main():
         drop_in = lightning_shaped(cfg, device, args.steps, args.precision)
         for k in ("eager", "graphed", "graphed_fused_adamw"):
             drop_in[f"{k}_vs_value_step"] = drop_in[f"ms_per_step_{k}_torch_adamw"] / ms_per_step
+    if world == 1 and args.config == "cfg2" and args.precision == "fp32" and not args.no_also and os.environ.get("NLAM_BENCH_ALSO", "1") == "1":
+        # N = 1: the wide BASELINE configurations on the driver's clock too -- configs[2] (d = 256, 8 layers, ar_steps 4, fp32 class)
+        # and configs[4] (d = 512, 8 layers, ar_steps 8, bf16 autocast), one sample per GPU, each with its same-GPU
+        # reference-equivalent; `value` stays cfg2
+        also = {"cfg3": also_leg("cfg3", "fp32", device, rank, world, args, timed_regions),
+                "cfg5_bf16": also_leg("cfg5", "bf16", device, rank, world, args, timed_regions)}
     if rank == 0:
         out = {
             "metric": "training sample-steps/s (on_after_batch_transfer+fwd+wmse+bwd+allreduce+AdamW), GraphCast-LAM, MEPS-shaped grid",

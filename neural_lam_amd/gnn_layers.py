@@ -630,7 +630,9 @@ class InteractionNet(nn.Module):
         if need_edges is None:
             need_edges = self.update_edges
         with ops.mail_scope() as tok:
-            alias = tok is not None and rec_rep.is_cuda and rec_rep.requires_grad
+            # fp32 tables only: the fused functions widen other dtypes INSIDE the Function, autograd then casts the fp32 gradient they
+            # return into a new tensor and a posted buffer would be orphaned (the product's data gradient silently lost)
+            alias = tok is not None and rec_rep.is_cuda and rec_rep.requires_grad and rec_rep.dtype == torch.float32
             if alias:
                 # a private alias of the receiver table for THIS layer's two consumers of it (node-level product, node MLP):
                 # their gradients meet in the alias' own autograd node, where the second can be accumulated onto the first

@@ -683,12 +683,13 @@ class FusedMLPFunction(torch.autograd.Function):
                 nbytes += out.numel() * 4
             if aggr is not None:
                 nbytes += aggr.numel() * 4
+            nmin = nbytes   # inputs once, outputs once -- nothing saved for a backward that could recompute it
             for t_ in (z1, xhat, rstd):
                 if t_ is not None:
                     nbytes += t_.numel() * t_.element_size()
             name, mf = _mm_executed(mm_flags, hid, dout, widths, ragged_out_ok=ln_w is None and not geom.aggregate)
             k1 = widths[0] if pre else kin
-            return {"flops": 2.0 * rows * B * (k1 * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
+            return {"flops": 2.0 * rows * B * (k1 * hid + hid * dout), "bytes": float(nbytes), "bytes_min": float(nmin), "mm": name, "mfmas_per_block": mf,
                     "what": ("gather + " if geom.nsrc == 3 else "") + ("factorised " if pre else "") + "Linear-SiLU-Linear" + ("-LayerNorm" if ln_w is not None else "")
                             + (" + segment aggregate" if geom.aggregate else "") + (" (saves z1/xhat/rstd)" if need_grad else "")}
 
@@ -842,10 +843,16 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     def bwd_meta():
         nbytes = sum(t_.numel() * t_.element_size() for t_ in (g_out, g_aggr, z1, xhat, rstd, dz1, dz2) if t_ is not None)
         nbytes += sum(t_.numel() * 4 for t_ in (*dsrc, *tmp2) if t_ is not None)
+        # the minimum the math needs: incoming gradients once, data gradients once, and the cheaper of {the saved
+        # tensors, the input rows a recomputing backward would gather instead}; dz1 / dz2 (they exist only because the weight
+        # gradient is another launch) and the tile-row-order scratch of the sender gradient are not algorithmic
+        saved = sum(t_.numel() * t_.element_size() for t_ in (z1, xhat, rstd) if t_ is not None)
+        nmin = sum(t_.numel() * t_.element_size() for t_ in (g_out, g_aggr) if t_ is not None)
+        nmin += sum(t_.numel() * 4 for t_ in dsrc if t_ is not None) + min(saved, rows * B * kin * 4)
         kin_live = sum(w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0 and not (pre and k_ > 0))
         name, mf = _mm_executed(ctx.mm_flags, hid, dout, [w_ for k_, w_ in enumerate(widths) if p.dmode[k_] != 0] or [hid],
                                 ragged_out_ok=dpad != dout)
-        return {"flops": 2.0 * rows * B * (kin_live * hid + hid * dout), "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
+        return {"flops": 2.0 * rows * B * (kin_live * hid + hid * dout), "bytes": float(nbytes), "bytes_min": float(nmin), "mm": name, "mfmas_per_block": mf,
                 "what": "LayerNorm/SiLU backward + dh = dz2 W2 + dx = dz1 W1 (data gradients; writes dz1, dz2 for the weight gradients)"}
 
     def launch_data():
@@ -903,11 +910,12 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
         key = ("wgrad", rows * B, m, n)
 
         def wg_meta():
-            nbytes = A.numel() * A.element_size() + partials.numel() * 4
-            nbytes += sum(t.shape[-2] * w * t.element_size() * (B if bstride != 0 or B == 1 else 1) for (t, bstride, w, idx) in src_list)
+            nsrc_b = sum(t.shape[-2] * w * t.element_size() * (B if bstride != 0 or B == 1 else 1) for (t, bstride, w, idx) in src_list)
+            nbytes = A.numel() * A.element_size() + partials.numel() * 4 + nsrc_b
+            nmin = A.numel() * A.element_size() + nsrc_b + m * n * 4   # operands once, dW once: partial sums are not algorithmic
             narrow = m <= 64 and all(w <= 64 for (_, _, w, _) in src_list)
             name, mf = ("f32", 0) if narrow else _mm_executed(ctx.mm_flags, m, m, [w for (_, _, w, _) in src_list])
-            return {"flops": 2.0 * rows * B * m * n, "bytes": float(nbytes), "mm": name, "mfmas_per_block": mf,
+            return {"flops": 2.0 * rows * B * m * n, "bytes": float(nbytes), "bytes_min": float(nmin), "mm": name, "mfmas_per_block": mf,
                     "what": "weight gradient dW = A^T [gathered B], rows = MFMA K"}
 
         L.check(PROFILE.launch(key, lambda: lib.nlam_wgrad(C.byref(q), _stream()), wg_meta), "nlam_wgrad")
@@ -1479,6 +1487,9 @@ class GroupedMLPFunction(torch.autograd.Function):
         lw = (n > 1 and FUSED_LEAF_WGRAD and (mm_flags >> 8) & 3 != 0
               and all(pr[0].shape[1] <= 3 and pr[0].shape[0] in (32, 64) and pr[2].shape[0] == pr[0].shape[0] for pr in params)
               and len({(pr[0].shape[0], pr[4] is None) for pr in params}) == 1 and all(x.dim() == 2 for x in xs))
+        # ONE set of backward matrix-mode bits for the whole group (the kernel flags of the grouped backward launch and every
+        # member's backward weight image must agree on the term count): narrow rules only when every member is narrow
+        grp_bflags = _bwd_flags(mm_flags, all(max(*q[0].shape, q[2].shape[0]) <= 64 for q in params))
         for k in range(n):
             W1, b1, W2, b2, ln_w, ln_b = params[k]
             x = xs[k]
@@ -1499,7 +1510,7 @@ class GroupedMLPFunction(torch.autograd.Function):
                 pack = PACKER.get(W1c, W2c, [kin], hid, dout, False, 0, mm_flags)
                 if pack is not None:
                     p.wpack, p.wpack_floats = pack.fwd.data_ptr(), pack.fwd.numel()
-                pack = _bwd_pack(pack, mm_flags, _bwd_flags(mm_flags, True), W1c, W2c, [kin], hid, dout, False, 0)
+                pack = _bwd_pack(pack, mm_flags, grp_bflags, W1c, W2c, [kin], hid, dout, False, 0)
             packs.append(pack)
             out = torch.empty((B, rows, dout), device=dev, dtype=torch.float32)
             p.out, p.out_bstride = _ptr(out), rows * dout
@@ -1551,7 +1562,7 @@ class GroupedMLPFunction(torch.autograd.Function):
         if need_grad:
             ctx.lw = lw
             ctx.packs = packs
-            ctx.n, ctx.params, ctx.saved, ctx.mm_flags = n, params, saved, _bwd_flags(mm_flags, all(max(*q[0].shape, q[2].shape[0]) <= 64 for q in params))
+            ctx.n, ctx.params, ctx.saved, ctx.mm_flags = n, params, saved, grp_bflags
             ctx.set_materialize_grads(False)
             if GRAD_LISTENER is not None:
                 GRAD_LISTENER.note_use([q for pr in params for q in pr if q is not None and q.requires_grad])
@@ -1838,6 +1849,8 @@ class NodeLinearFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if g is None:
+            if ctx.mail is not None:
+                _MAILBOX.pop(ctx.mail, None)   # nothing to add: the posted buffer already is the whole gradient autograd holds
             return None, None, None, None
         lib = L.load()
         x2d, W1 = ctx.saved_tensors
@@ -1889,7 +1902,7 @@ def _node_linear_wgrad(prm, g_cols, x2d, mm):
             keep.append(partials)
             key = ("wgrad", rows, hid, k)
             L.check(PROFILE.launch(key, lambda: lib.nlam_wgrad(C.byref(q), _stream()),
-                                   lambda: {"flops": 2.0 * rows * hid * k, "bytes": 4.0 * (rows * (hid + k) + nparts * hid * k),
+                                   lambda: {"flops": 2.0 * rows * hid * k, "bytes": 4.0 * (rows * (hid + k) + nparts * hid * k), "bytes_min": 4.0 * (rows * (hid + k) + hid * k),
                                             "mm": "f32" if max(hid, k) <= 64 else _MM_NAMES[(mm >> 8) & 3],
                                             "mfmas_per_block": 0 if max(hid, k) <= 64 else ((mm >> 8) & 3) * (((mm >> 8) & 3) + 1) // 2,
                                             "what": "node-level weight gradient of the factorised edge MLP"}), "nlam_wgrad")
@@ -1945,6 +1958,8 @@ class NodeLinearPairFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gj, gi):
         if gj is None and gi is None:
+            if ctx.mail is not None:
+                _MAILBOX.pop(ctx.mail, None)
             return None, None, None, None, None
         x2d, W1 = ctx.saved_tensors
         cj, ci, xshape, B, N, shared, mm = ctx.meta

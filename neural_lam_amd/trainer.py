@@ -174,7 +174,11 @@ class GradBuckets:
             if i is not None:
                 self.uses[i] = self.uses.get(i, 0) + 1
 
+    chain_recorder = None   # a set while a _SegmentedStep records its chain: ids of parameters whose .grad a CHAIN launch wrote
+
     def note_done(self, params):
+        if self.chain_recorder is not None:
+            self.chain_recorder.update(id(p) for p in params)
         if not self.enabled or self.world == 1:
             return
         for p in params:
@@ -249,6 +253,7 @@ class _SegmentedStep:
         self.pool = torch.cuda.graph_pool_handle()
         self.side_pool = torch.cuda.graph_pool_handle()
         self.seg_params = []       # per segment: ids of the parameters whose gradients its side work completed
+        self.chain_params = set()  # ids of parameters a launch of the CHAIN itself accumulated into (complete with the last segment only)
         self.mode = "relaxed"      # capture error mode: segments are closed / opened from inside autograd's backward
 
     # ---- recording ----
@@ -360,6 +365,20 @@ class _SegmentedStep:
                 self.tail.replay()
             self.tr._exit_event.record(cs)
         torch.cuda.current_stream().wait_event(self.tr._exit_event)
+
+
+class _TouchRecorder:
+    """ops.GRAD_LISTENER stand-in inside graphed_training_step's captured backward: the parameters a fused function accumulated
+    into its staging view itself (direct mode), so that an untouched parameter reports None, as the eager module does."""
+
+    def __init__(self):
+        self.ids = set()
+
+    def note_use(self, params):
+        pass
+
+    def note_done(self, params):
+        self.ids.update(id(p) for p in params)
 
 
 class _DoneRecorder:
@@ -610,6 +629,9 @@ class Trainer:
             with torch.cuda.stream(cs):
                 self._recording = seg
                 seg._begin_segment()
+                # (the side closures run under their own listener inside seg.finish(): what reaches self.buckets here are the
+                # reductions a chain launch did itself)
+                self.buckets.chain_recorder = seg.chain_params
                 try:
                     self.fp.grad.zero_()
                     self._static_loss = self._fwd_bwd()   # ops.OVERLAP.end() -> seg.finish(): every graph but the optimizer's
@@ -618,6 +640,7 @@ class Trainer:
                     raise
                 finally:
                     self._recording = None
+                    self.buckets.chain_recorder = None
                 if self._opt_in_graph:
                     seg.tail = torch.cuda.CUDAGraph()
                     seg.tail.capture_begin(pool=seg.pool, capture_error_mode=seg.mode)
@@ -644,6 +667,8 @@ class Trainer:
         for i, ids in enumerate(seg.seg_params):
             for pid in ids:
                 last_seg[pid] = i
+        for pid in seg.chain_params:   # also written by a chain launch (a later segment may add to it): ready with the last segment
+            last_seg[pid] = nseg - 1
         out, cur = [[] for _ in range(nseg)], 0
         for b, (_s0, _e0, members) in enumerate(self.buckets.bounds):
             ready = max((last_seg.get(id(self.fp.params[i]), nseg - 1) for i in members), default=nseg - 1)
@@ -678,24 +703,36 @@ class Trainer:
             self._tail_graph = None
             self._opt_sig = None
             return
-        if seg is None:
-            if self._tail_graph is not None:   # the optimizer's own graph: only that is recorded again
-                self._capture_tail()
-                self._opt_sig = self._opt_signature()
-            else:
-                self._graph = None
-            return
-        t_before = getattr(self.opt, "t", None)
-        with torch.cuda.stream(self._chain_stream):
-            seg.tail = torch.cuda.CUDAGraph()
-            seg.tail.capture_begin(pool=seg.pool, capture_error_mode=seg.mode)
+        # re-recording is a stream capture: no cyclic garbage collection inside it (see _capture)
+        import gc
+
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            if seg is None:
+                if self._tail_graph is not None:   # the optimizer's own graph: only that is recorded again
+                    self._capture_tail()
+                    self._opt_sig = self._opt_signature()
+                else:
+                    self._graph = None
+                return
+            t_before = getattr(self.opt, "t", None)
             try:
-                self.opt.step(1.0 / self.world)
+                with torch.cuda.stream(self._chain_stream):
+                    seg.tail = torch.cuda.CUDAGraph()
+                    seg.tail.capture_begin(pool=seg.pool, capture_error_mode=seg.mode)
+                    try:
+                        self.opt.step(1.0 / self.world)
+                    finally:
+                        seg.tail.capture_end()
             finally:
-                seg.tail.capture_end()
-        if t_before is not None:
-            self.opt.t = t_before
-        self._opt_sig = self._opt_signature()
+                if t_before is not None:
+                    self.opt.t = t_before   # the capture recorded the launches without running them (also when it failed)
+            self._opt_sig = self._opt_signature()
+        finally:
+            if was_enabled:
+                gc.enable()
 
     def _graph_step(self, *batch):
         if self._graph is not None and (self._opt_in_graph or self._tail_graph is not None) and self._opt_signature() != self._opt_sig:
@@ -893,7 +930,8 @@ class _GraphedStep:
                 for p, v, ok in zip(self.params, self.gviews, fp32):
                     if ok:
                         p.grad = v
-                ops.DIRECT_PARAM_GRADS, ops.GRAD_LISTENER, ops.EARLY_LEAF_BACKWARD = True, None, False
+                rec = _TouchRecorder()
+                ops.DIRECT_PARAM_GRADS, ops.GRAD_LISTENER, ops.EARLY_LEAF_BACKWARD = True, rec, False
                 ops.OVERLAP.begin()
                 try:
                     got = torch.autograd.grad(tuple(o for o, _ in live), surface, grad_outputs=tuple(g for _, g in live),
@@ -904,9 +942,12 @@ class _GraphedStep:
                     for p, g in zip(self.params, held):
                         p.grad = g
                 got = list(got)
-                for i, (v, ok) in enumerate(zip(self.gviews, fp32)):
+                touched = rec.ids
+                for i, (p, v, ok) in enumerate(zip(self.params, self.gviews, fp32)):
                     k = self.n_in_grads + i
-                    if ok:   # what the fused MLPs accumulated themselves (+ whatever came back through autograd for this parameter)
+                    # what the fused MLPs accumulated themselves (+ whatever came back through autograd for this parameter); a
+                    # parameter neither of them produced keeps None, as under the eager module (torch AdamW / DDP skip it)
+                    if ok and id(p) in touched:
                         got[k] = v if got[k] is None else v + got[k]
                 return tuple(got)
             finally:
