@@ -667,7 +667,7 @@ class Trainer:
         for i, ids in enumerate(seg.seg_params):
             for pid in ids:
                 last_seg[pid] = i
-        for pid in seg.chain_params:   # also written by a chain launch (a later segment may add to it): ready with the last segment
+        for pid in getattr(seg, "chain_params", ()):   # also written by a chain launch (a later segment may add to it): ready with the last segment
             last_seg[pid] = nseg - 1
         out, cur = [[] for _ in range(nseg)], 0
         for b, (_s0, _e0, members) in enumerate(self.buckets.bounds):

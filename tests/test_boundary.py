@@ -525,3 +525,10 @@ def test_trainer_picks_its_executor_and_plans_bucket_launches_on_the_host():
     # buckets: 0 = 2.bias (ready at 0), 1 = 2.weight (ready at 2), 2 = 1.bias (ready at 2), 3 = 1.weight (ready at 1, held back by
     # bucket 1), 4 = 0.bias, 5 = 0.weight (ready with the last segment)
     assert plan == [[0], [], [1, 2, 3], [4, 5]]
+
+    class SegChain(Seg):
+        # 2.bias is reported by segment 0's side work AND written by a launch of the chain itself (a later segment may add to it):
+        # complete with the last segment only, and every bucket behind it is held back with it (advisor finding, round 5)
+        chain_params = {id(P[5])}
+
+    assert tr._plan_buckets(SegChain()) == [[], [], [], [0, 1, 2, 3, 4, 5]]
