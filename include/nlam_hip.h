@@ -265,7 +265,8 @@ int32_t nlam_max_width(void);
 #define NLAM_TUNE_WGRAD_BIG_MIN_ROWS 5
 /*   NLAM_TUNE_WBF_HALF: split-bf16 wide kernels on 4-wave workgroups of half the rows, TWO co-resident per CU, so that one
  *   workgroup's load / store phases overlap the other's matrix phases (bit 0: forward, bit 1: backward; shapes without a
- *   half-size instantiation keep the 8-wave kernels). */
+ *   half-size instantiation keep the 8-wave kernels).  Bit 2 (round 6): the one-term forward above d = 256 on 4-wave workgroups
+ *   of 64 rows (two MFMAs per weight fragment fetched from L2 instead of one). */
 #define NLAM_TUNE_WBF_HALF 6
 /*   NLAM_TUNE_LIN_GEMM: nlam_linear with n % 128 == 0 on the LDS-tiled GEMM: 1 (default) = where it beats the strip kernel of
  *   rounds 2-4 (one term: everywhere; two / three terms: 6 561-row class up to K = 256, 63 784-row class from K = 512), 0 = never,
@@ -274,6 +275,12 @@ int32_t nlam_max_width(void);
 /*   NLAM_TUNE_WBF_V4: the split-bf16 wide kernels' instantiations with branch-free 16-byte chunk accesses for launches whose
  *   widths are all multiples of 4 (default 1; 0 = the generic lane-predicated accessors everywhere, for A/B runs). */
 #define NLAM_TUNE_WBF_V4 8
+/*   NLAM_TUNE_WGRAD_LDMA (round 6): one-term weight gradients with 256 x 256 windows on wgrad_ldma_kernel (both operands streamed
+ *   by LDS-DMA into a 3-stage ring, bf16 operands read with the LDS transpose read): bit 0 = launches with bf16 operands
+ *   (NLAM_F_A_BF16), bit 1 = fp32-operand launches; default 3, 0 = the column-per-thread kernel of rounds 1-5 (A/B runs). */
+#define NLAM_TUNE_WGRAD_LDMA 9
+/*   NLAM_TUNE_WGRAD_LDMA_VAR: (rows per stage, ring depth) variant of wgrad_ldma_kernel, 0 = default (A/B runs). */
+#define NLAM_TUNE_WGRAD_LDMA_VAR 10
 int32_t nlam_set_tuning(int32_t key, int32_t value);
 /* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this
  * call; 0 when the call runs on the narrow (weights-in-LDS) kernels. */

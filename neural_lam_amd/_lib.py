@@ -28,6 +28,8 @@ TUNE_WGRAD_BIG_MIN_ROWS = 5
 TUNE_WBF_HALF = 6
 TUNE_LIN_GEMM = 7
 TUNE_WBF_V4 = 8
+TUNE_WGRAD_LDMA = 9
+TUNE_WGRAD_LDMA_VAR = 10
 TILE_SPLIT = 1 << 30
 
 EXPORTS = [
@@ -418,11 +420,15 @@ def load():
     if os.environ.get("NLAM_WGRAD_MIN_PARTS"):
         lib.nlam_set_tuning(TUNE_WGRAD_MIN_PARTS, int(os.environ["NLAM_WGRAD_MIN_PARTS"]))
     if os.environ.get("NLAM_WBF_HALF"):
-        lib.nlam_set_tuning(TUNE_WBF_HALF, int(os.environ["NLAM_WBF_HALF"]))
+        check(lib.nlam_set_tuning(TUNE_WBF_HALF, int(os.environ["NLAM_WBF_HALF"])), "nlam_set_tuning(NLAM_WBF_HALF)")
     if os.environ.get("NLAM_WBF_V4"):
         lib.nlam_set_tuning(TUNE_WBF_V4, int(os.environ["NLAM_WBF_V4"]))
     if os.environ.get("NLAM_LIN_GEMM"):
         lib.nlam_set_tuning(TUNE_LIN_GEMM, int(os.environ["NLAM_LIN_GEMM"]))
+    if os.environ.get("NLAM_WGRAD_LDMA"):
+        check(lib.nlam_set_tuning(TUNE_WGRAD_LDMA, int(os.environ["NLAM_WGRAD_LDMA"])), "nlam_set_tuning(NLAM_WGRAD_LDMA)")
+    if os.environ.get("NLAM_WGRAD_LDMA_VAR"):
+        check(lib.nlam_set_tuning(TUNE_WGRAD_LDMA_VAR, int(os.environ["NLAM_WGRAD_LDMA_VAR"])), "nlam_set_tuning(NLAM_WGRAD_LDMA_VAR)")
     if os.environ.get("NLAM_WGRAD_CHUNKS"):
         lib.nlam_set_tuning(TUNE_WGRAD_CHUNKS, int(os.environ["NLAM_WGRAD_CHUNKS"]))
     _lib = lib

@@ -98,6 +98,8 @@ extern int wbf_min_supertiles;                                     // nlam_set_t
 extern int wbf_half;                                               // nlam_set_tuning (defined in slice 1)
 extern int wbf_v4;                                                 // branch-free chunk accessors in the split-bf16 wide kernels (NLAM_TUNE_WBF_V4)
 extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
+extern int wgrad_ldma;                                             // one-term weight gradients on wgrad_ldma_kernel (NLAM_TUNE_WGRAD_LDMA)
+extern int wgrad_ldma_var;                                         // its (rows per stage, ring depth) variant (NLAM_TUNE_WGRAD_LDMA_VAR)
 extern int wgrad_min_parts;                                        // nlam_set_tuning (defined in slice 1)
 extern int wgrad_min_parts_wide;                                   // the same for weight matrices of more than 128 rows
 extern int wgrad_big_min_rows;                                     // nlam_set_tuning (defined in slice 1)
@@ -4443,6 +4445,8 @@ long nlam_detail::lin_gemm_big_rows = 32768;   // 128-row tiles from here (63 78
 int nlam_detail::wgrad_big_min_rows = 0;    // rows from which a wide weight gradient uses 256 x 256 windows (0 = always, the round-2 behaviour)
 int nlam_detail::wgrad_min_parts = 128;     // row slices a weight gradient of more than that many 32-row chunks is cut into at least
 int nlam_detail::wgrad_min_parts_wide = 64; // ... when the weight matrix has more than 128 rows (nlam_set_tuning sets both)
+int nlam_detail::wgrad_ldma_var = 0;
+int nlam_detail::wgrad_ldma = 1;           // bit 0: bf16-operand launches, bit 1: fp32-operand one-term launches with 256 x 256 windows (NLAM_TUNE_WGRAD_LDMA)
 int nlam_detail::wgrad_chunks_per_wg = 8;   // A/B at cfg2 (tools/ab_bench.sh): 2.13 -> 2.06 ms per step against one chunk per workgroup
 #endif
 
@@ -4472,7 +4476,7 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
         return 0;
     }
     if (key == NLAM_TUNE_WBF_HALF) {
-        if (value < 0 || value > 3) return NLAM_EINVAL;
+        if (value < 0 || value > 7) return NLAM_EINVAL;
         nlam_detail::wbf_half = value;
         return 0;
     }
@@ -4495,6 +4499,16 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_WGRAD_CHUNKS) {
         if (value < 1) return NLAM_EINVAL;
         nlam_detail::wgrad_chunks_per_wg = value;
+        return 0;
+    }
+    if (key == NLAM_TUNE_WGRAD_LDMA_VAR) {
+        if (value < 0 || value > 3) return NLAM_EINVAL;
+        nlam_detail::wgrad_ldma_var = value;
+        return 0;
+    }
+    if (key == NLAM_TUNE_WGRAD_LDMA) {
+        if (value < 0 || value > 3) return NLAM_EINVAL;
+        nlam_detail::wgrad_ldma = value;
         return 0;
     }
     if (key == NLAM_TUNE_WBF_V4) {
@@ -4809,6 +4823,7 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
                 if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF_S(8, 8, 1, 4, 2);
                 else if (pl.cfg == 5) NLAM_LAUNCH_FWD_WBF_S(4, 4, 2, 2, 1);
                 else if (pl.cfg == 6) NLAM_LAUNCH_FWD_WBF_S(4, 4, 4, 1, 1);
+                else if (pl.cfg == 7) NLAM_LAUNCH_FWD_WBF_S(4, 4, 4, 2, 1);
                 else if (pl.cfg == 3) NLAM_LAUNCH_FWD_WBF_S(8, 8, 2, 2, 1);
                 else return NLAM_EUNSUP;
                 return (int32_t)hipGetLastError();
@@ -4819,6 +4834,7 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
                 else if (pl.cfg == 4) NLAM_LAUNCH_FWD_WBF(1, 8, 8, 1, 2, 2);
                 else if (pl.cfg == 5) NLAM_LAUNCH_FWD_WBF(1, 4, 4, 2, 2, 1);
                 else if (pl.cfg == 6) NLAM_LAUNCH_FWD_WBF(1, 4, 4, 4, 1, 1);
+                else if (pl.cfg == 7) NLAM_LAUNCH_FWD_WBF(1, 4, 4, 4, 2, 1);
                 else NLAM_LAUNCH_FWD_WBF(1, 8, 8, 2, 2, 1);
             } else {
                 if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(3, 8, 4, 1, 4, 2);
@@ -5457,12 +5473,42 @@ int32_t nlam_detail::wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream) {
         if (rc != 0) return rc;                                                                                                   \
         hipLaunchKernelGGL((wgrad_wbf_kernel<1, S_, 1, WM_, WN_, NBW_, true, SB_>), grid, dim3(WM_ * WN_ * 64), lds, stream, *p);  \
     } while (0)
+#define NLAM_LAUNCH_WG_LDMA(ABF_, SBF_, SILU_, R_, NB_)                                                                   \
+    do {                                                                                                                  \
+        const size_t lds2 = WgLdma<ABF_, SBF_, SILU_, R_, NB_>::LDS;                                                       \
+        int rc = set_lds(wgrad_ldma_kernel<ABF_, SBF_, SILU_, R_, NB_>, lds2);                                             \
+        if (rc != 0) return rc;                                                                                           \
+        hipLaunchKernelGGL((wgrad_ldma_kernel<ABF_, SBF_, SILU_, R_, NB_>), grid, dim3(512), lds2, stream, *p);            \
+    } while (0)
+            const int var = nlam_detail::wgrad_ldma_var;   // (rows per stage, ring depth) variants for A/B runs (NLAM_TUNE_WGRAD_LDMA_VAR)
             if (sb) {
-                if (big) NLAM_LAUNCH_WG_WBF_B(true, 4, 2, 4, true);
+                if (big && (nlam_detail::wgrad_ldma & 1)) {
+                    if (var == 1) NLAM_LAUNCH_WG_LDMA(true, true, true, 32, 5);
+                    else if (var == 2) NLAM_LAUNCH_WG_LDMA(true, true, true, 16, 6);
+                    else if (var == 3) NLAM_LAUNCH_WG_LDMA(true, true, true, 16, 8);
+                    else NLAM_LAUNCH_WG_LDMA(true, true, true, 32, 4);
+                } else if (big) NLAM_LAUNCH_WG_WBF_B(true, 4, 2, 4, true);
                 else NLAM_LAUNCH_WG_WBF_B(true, 2, 2, 2, true);
             } else {
-                if (big) NLAM_LAUNCH_WG_WBF_B(false, 4, 2, 4, false);
+                if (big && (nlam_detail::wgrad_ldma & 1)) {
+                    if (var == 1) NLAM_LAUNCH_WG_LDMA(true, false, false, 16, 4);
+                    else if (var == 2) NLAM_LAUNCH_WG_LDMA(true, false, false, 16, 5);
+                    else if (var == 3) NLAM_LAUNCH_WG_LDMA(true, false, false, 16, 6);
+                    else NLAM_LAUNCH_WG_LDMA(true, false, false, 32, 3);
+                } else if (big) NLAM_LAUNCH_WG_WBF_B(false, 4, 2, 4, false);
                 else NLAM_LAUNCH_WG_WBF_B(false, 2, 2, 2, false);
+            }
+            return (int32_t)hipGetLastError();
+        }
+        if (wns == 1 && big && (nlam_detail::wgrad_ldma & 2)) {   // fp32 operands, one term (autocast launches without bf16 storage)
+            const int var = nlam_detail::wgrad_ldma_var;
+            if (silu) {
+                if (var >= 1) NLAM_LAUNCH_WG_LDMA(false, false, true, 16, 5);
+                else NLAM_LAUNCH_WG_LDMA(false, false, true, 16, 4);
+            } else {
+                if (var == 1) NLAM_LAUNCH_WG_LDMA(false, false, false, 16, 4);
+                else if (var >= 2) NLAM_LAUNCH_WG_LDMA(false, false, false, 16, 5);
+                else NLAM_LAUNCH_WG_LDMA(false, false, false, 16, 3);
             }
             return (int32_t)hipGetLastError();
         }

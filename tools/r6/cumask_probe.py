@@ -55,7 +55,16 @@ masks = {
     "every 4th bit": list(range(0, 256, 4)),
     "bits 0-191": list(range(192)),
     "all 256": list(range(256)),
+    "bits 0-31": list(range(32)),
+    "bits 0-127": list(range(128)),
+    "bits 64-255": list(range(64, 256)),
+    "bits i % 8 == 0": list(range(0, 256, 8)),
+    "bits i % 8 < 2": [i for i in range(256) if i % 8 < 2],
+    "bits i % 32 < 8": [i for i in range(256) if i % 32 < 8],
+    "bits i % 32 < 24": [i for i in range(256) if i % 32 < 24],
 }
+mm = torch.randn(4096, 4096, device=dev)
+copy = lambda: torch.mm(mm, mm)   # noqa: E731  (compute-bound: its time scales with the CUs it may use)
 print("plain stream: copy %.1f us, silu %.1f us" % (timeit(copy, plain), timeit(sil, plain)))
 for name, bits in masks.items():
     st = masked_stream(bits)
