@@ -4823,7 +4823,7 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
                 if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF_S(8, 8, 1, 4, 2);
                 else if (pl.cfg == 5) NLAM_LAUNCH_FWD_WBF_S(4, 4, 2, 2, 1);
                 else if (pl.cfg == 6) NLAM_LAUNCH_FWD_WBF_S(4, 4, 4, 1, 1);
-                else if (pl.cfg == 7) NLAM_LAUNCH_FWD_WBF_S(4, 4, 4, 2, 1);
+                else if (pl.cfg == 7) NLAM_LAUNCH_FWD_WBF_S(4, 4, 4, 2, 2);
                 else if (pl.cfg == 3) NLAM_LAUNCH_FWD_WBF_S(8, 8, 2, 2, 1);
                 else return NLAM_EUNSUP;
                 return (int32_t)hipGetLastError();
@@ -4834,7 +4834,7 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
                 else if (pl.cfg == 4) NLAM_LAUNCH_FWD_WBF(1, 8, 8, 1, 2, 2);
                 else if (pl.cfg == 5) NLAM_LAUNCH_FWD_WBF(1, 4, 4, 2, 2, 1);
                 else if (pl.cfg == 6) NLAM_LAUNCH_FWD_WBF(1, 4, 4, 4, 1, 1);
-                else if (pl.cfg == 7) NLAM_LAUNCH_FWD_WBF(1, 4, 4, 4, 2, 1);
+                else if (pl.cfg == 7) NLAM_LAUNCH_FWD_WBF(1, 4, 4, 4, 2, 2);
                 else NLAM_LAUNCH_FWD_WBF(1, 8, 8, 2, 2, 1);
             } else {
                 if (pl.cfg == 1) NLAM_LAUNCH_FWD_WBF(3, 8, 4, 1, 4, 2);

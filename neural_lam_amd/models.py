@@ -53,6 +53,9 @@ FUSED_STATE_UPDATE = True
 import os as _os
 
 FOLD_INPUT_CAT = _os.environ.get("NLAM_FOLD_CAT", "1") == "1"
+# static-feature embedders (keys of static_embedding_specs: "mesh", "g2m", "m2g", "m2m", ..; "all") whose backward runs as soon as
+# the gradient of their output is complete instead of in the grouped launch at the very end of backward (NLAM_EARLY_EMB; default none)
+EARLY_EMBEDDER_BACKWARD = frozenset(k for k in _os.environ.get("NLAM_EARLY_EMB", "").split(",") if k)
 
 class BufferList(nn.Module):
     """utils/buffer_list.py:11: list of non-persistent buffers."""
@@ -259,7 +262,17 @@ class BaseGraphModel(StepPredictor):
             else:
                 pairs.append((mlps, feats))
                 slots.append((key, None))
+        from . import ops
+
         outs = grouped_mlp_forward(pairs)
+        # embedders whose output gradient is complete long before the end of backward run their backward right then, on a side
+        # stream (ops.early_backward_leaf).  Measured (round 6, profiles/round6/ab_early_emb.log): the mesh -> grid edge embedder
+        # (64 % of the grouped backward's rows at MEPS size; its gradient is final behind the decoder's backward) leaves the tail of
+        # the cfg2 step -- and the step does not move (1.7564 vs 1.7565 ms; cfg3 / cfg4 within noise): the chip is time-shared
+        # either way.  Off by default (NLAM_EARLY_EMB=m2g, or "all", switches it on)
+        early = EARLY_EMBEDDER_BACKWARD
+        outs = [ops.early_backward_leaf(o, force=True) if (key in early or "all" in early) and o.requires_grad else o
+                for (key, _i), o in zip(slots, outs)]
         st = {}
         for (key, i), o in zip(slots, outs):
             if i is None:

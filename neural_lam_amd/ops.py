@@ -170,7 +170,7 @@ def direct_param_grads(listener=None, early_leaf=True, packer=None):
         DIRECT_PARAM_GRADS, GRAD_LISTENER, EARLY_LEAF_BACKWARD, PACKER = prev
 
 
-def early_backward_leaf(out):
+def early_backward_leaf(out, force: bool = False):
     """Cut the autograd graph behind an MLP whose inputs need no gradient (the embedders of the static grid / mesh /
     edge features, the grid embedder of the first AR step) and run its backward as soon as the gradient of its output
     is complete, instead of when the autograd engine gets to it.
@@ -182,7 +182,10 @@ def early_backward_leaf(out):
     post-accumulate hook (AccumulateGrad nodes have top priority in the engine) runs the MLP's own backward right
     there; FusedMLPFunction.backward puts all of it (data-gradient kernel included) on a weight-gradient side stream.
     """
-    if not (EARLY_LEAF_BACKWARD and torch.is_grad_enabled() and out.requires_grad):
+    # ``force``: the caller knows the early launch pays (round 6: the m2g edge embedder inside the grouped launch, whose backward
+    # then leaves the tail of the step) -- still only inside a trainer's own step (DIRECT_PARAM_GRADS), where the embedder's
+    # whole backward goes to a side stream
+    if not ((EARLY_LEAF_BACKWARD or (force and DIRECT_PARAM_GRADS)) and torch.is_grad_enabled() and out.requires_grad):
         return out
     leaf = out.detach().requires_grad_()
 
@@ -1755,14 +1758,34 @@ def _grouped_backward_fused(ctx, g_outs, live, grads):
 
     if lib.nlam_mlp_bwd_family(arr) != 0:   # the fused-weight-gradient kernel is a narrow one
         return False
-    rc = PROFILE.launch(("mlp_bwd_group_lw", rows_all, m, int(arr[0].hid), int(arr[0].dout)), lambda: lib.nlam_mlp_bwd_group(arr, m, _stream()), meta)
-    if rc == -2:
-        return False
-    L.check(rc, "nlam_mlp_bwd_group (fused weight gradients)")
 
     def is_direct(param, shape):
         return (DIRECT_PARAM_GRADS and param is not None and param.grad is not None and param.grad.is_contiguous()
                 and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32)
+
+    # A dead end of backward (nothing upstream of a static-feature embedder needs a gradient): under a trainer that owns the
+    # parameter gradients the launch and its reduction go to a weight-gradient side stream.  At the end of backward that changes
+    # nothing; for an embedder whose output gradient is complete EARLY (early_backward_leaf: the m2g edge embedding right behind
+    # the decoder's backward) it takes 64 % of this kernel's rows out of the tail of the step (round 6).
+    all_direct = all(q is None or not ctx.needs_input_grad[1 + 6 * k + i_] or is_direct(q, q.shape)
+                     for (k, *_r) in work for i_, q in enumerate(params[k]))
+    if OVERLAP.active and all_direct:
+        hold = [t_ for (k, g, dw2p, vecp, nblk, vs, b1c) in work for t_ in (g, dw2p, vecp, b1c, *[x_ for x_ in ctx.saved[k] if isinstance(x_, torch.Tensor)])]
+        hold += [pk_.bwd for pk_ in ctx.packs if pk_ is not None and getattr(pk_, "bwd", None) is not None]
+        OVERLAP.run(params[work[0][0]][0], hold, lambda: _grouped_backward_fused_launch(ctx, arr, m, work, rows_all, meta, grads, is_direct), dead_end=True)
+    else:
+        _grouped_backward_fused_launch(ctx, arr, m, work, rows_all, meta, grads, is_direct)
+    return True
+
+
+def _grouped_backward_fused_launch(ctx, arr, m, work, rows_all, meta, grads, is_direct):
+    lib = L.load()
+    params = ctx.params
+    dev = params[0][0].device
+    rc = PROFILE.launch(("mlp_bwd_group_lw", rows_all, m, int(arr[0].hid), int(arr[0].dout)), lambda: lib.nlam_mlp_bwd_group(arr, m, _stream()), meta)
+    if rc == -2:
+        raise RuntimeError("nlam_mlp_bwd_group has no fused-weight-gradient kernel for a shape the forward planned it for")
+    L.check(rc, "nlam_mlp_bwd_group (fused weight gradients)")
 
     keep = []
     jobs = L.ReduceJobs()   # ONE reduction launch for all members (<= 9 jobs each): they were four serial launches at the very end of the step
@@ -1819,7 +1842,8 @@ def _grouped_backward_fused(ctx, g_outs, live, grads):
         for (k, *_rest) in work:
             needs = [ctx.needs_input_grad[1 + 6 * k + q] for q in range(6)]
             GRAD_LISTENER.note_done([q for q, nd in zip(params[k], needs) if nd and q is not None and is_direct(q, q.shape)])
-    return True
+    if OVERLAP.active and not OVERLAP.capturing and OVERLAP.deferred is None:
+        OVERLAP.hold(torch.cuda.current_stream(), *keep)
 
 
 def _linear_launch(x2d, W, ldn, ldk, k, n, out=None, accumulate=False, mm_flags=None, W2=None, out2=None):
