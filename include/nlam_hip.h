@@ -99,6 +99,12 @@ extern "C" {
  * nlam_wgrad: NLAM_F_A_BF16 = `A` (dz1 / dz2) is bf16, NLAM_F_S_BF16 = src[0] (z1; nsrc must be 1, no gather index) is bf16. */
 #define NLAM_F_STORE_BF16 (1u << 10)
 #define NLAM_F_A_BF16     (1u << 10)
+/* NLAM_F_ACC_DSRC0 (nlam_mlp_bwd, round 6): the data gradient of source 0 (dmode 1: rows scattered through the unique gather
+ * index) is ADDED to what dsrc[0] holds instead of overwriting it -- a tensor every autoregressive step of a rollout consumes (the
+ * static edge embeddings, models/forecasters/autoregressive.py:63-149) then collects its gradient in ONE buffer, in the order the
+ * steps are back-propagated, instead of T buffers and T - 1 add launches over 0.1-0.5 GB each.  Split-bf16 super-tile family
+ * only (nlam_mlp_bwd_family == 2): NLAM_EUNSUP elsewhere. */
+#define NLAM_F_ACC_DSRC0  (1u << 12)
 #define NLAM_F_S_BF16     (1u << 11)
 /* matrix path of the GEMMs (bits 8-9): 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains);
  * n = 1..3: operands split into n bf16 terms on the bf16 matrix cores, fp32 accumulate
@@ -277,7 +283,9 @@ int32_t nlam_max_width(void);
 #define NLAM_TUNE_WBF_V4 8
 /*   NLAM_TUNE_WGRAD_LDMA (round 6): one-term weight gradients with 256 x 256 windows on wgrad_ldma_kernel (both operands streamed
  *   by LDS-DMA into a 3-stage ring, bf16 operands read with the LDS transpose read): bit 0 = launches with bf16 operands
- *   (NLAM_F_A_BF16), bit 1 = fp32-operand launches; default 3, 0 = the column-per-thread kernel of rounds 1-5 (A/B runs). */
+ *   (NLAM_F_A_BF16), bit 1 = fp32-operand one-term launches, bit 2 = fp32-class (three-term) launches; default 1: with fp32 operands
+ *   the kernel measured no faster than the column-per-thread kernel of rounds 1-5 (profiles/round6/wgrad_check.log: three terms
+ *   67.9 vs 64.8 us at 57 616 x 256 x 256, bit-identical results), 0 = that kernel everywhere. */
 #define NLAM_TUNE_WGRAD_LDMA 9
 /*   NLAM_TUNE_WGRAD_LDMA_VAR: (rows per stage, ring depth) variant of wgrad_ldma_kernel, 0 = default (A/B runs). */
 #define NLAM_TUNE_WGRAD_LDMA_VAR 10

@@ -4507,7 +4507,7 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
         return 0;
     }
     if (key == NLAM_TUNE_WGRAD_LDMA) {
-        if (value < 0 || value > 3) return NLAM_EINVAL;
+        if (value < 0 || value > 7) return NLAM_EINVAL;
         nlam_detail::wgrad_ldma = value;
         return 0;
     }
@@ -5025,8 +5025,10 @@ int32_t nlam_mlp_bwd(const nlam_mlp_bwd_t* p, void* hip_stream) {
     hipStream_t stream = (hipStream_t)hip_stream;
     if (bwd_is_wide(p)) {
         if (bwd_wbf_ns(p) > 0) return nlam_detail::bwd_wbf(p, stream);   // split-bf16 matrix path (nlam_wbf.inc)
+        if (p->flags & NLAM_F_ACC_DSRC0) return NLAM_EUNSUP;
         return nlam_detail::bwd_wide(p, stream);
     }
+    if (p->flags & NLAM_F_ACC_DSRC0) return NLAM_EUNSUP;
     return nlam_detail::bwd_narrow(p, stream);
 }
 
@@ -5476,9 +5478,9 @@ int32_t nlam_detail::wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream) {
 #define NLAM_LAUNCH_WG_LDMA(ABF_, SBF_, SILU_, R_, NB_)                                                                   \
     do {                                                                                                                  \
         const size_t lds2 = WgLdma<ABF_, SBF_, SILU_, R_, NB_>::LDS;                                                       \
-        int rc = set_lds(wgrad_ldma_kernel<ABF_, SBF_, SILU_, R_, NB_>, lds2);                                             \
+        int rc = set_lds(wgrad_ldma_kernel<1, ABF_, SBF_, SILU_, R_, NB_>, lds2);                                          \
         if (rc != 0) return rc;                                                                                           \
-        hipLaunchKernelGGL((wgrad_ldma_kernel<ABF_, SBF_, SILU_, R_, NB_>), grid, dim3(512), lds2, stream, *p);            \
+        hipLaunchKernelGGL((wgrad_ldma_kernel<1, ABF_, SBF_, SILU_, R_, NB_>), grid, dim3(512), lds2, stream, *p);         \
     } while (0)
             const int var = nlam_detail::wgrad_ldma_var;   // (rows per stage, ring depth) variants for A/B runs (NLAM_TUNE_WGRAD_LDMA_VAR)
             if (sb) {
@@ -5510,6 +5512,18 @@ int32_t nlam_detail::wgrad_wbf(const nlam_wgrad_t* p, hipStream_t stream) {
                 else if (var >= 2) NLAM_LAUNCH_WG_LDMA(false, false, false, 16, 5);
                 else NLAM_LAUNCH_WG_LDMA(false, false, false, 16, 3);
             }
+            return (int32_t)hipGetLastError();
+        }
+        if (wns == 3 && big && (nlam_detail::wgrad_ldma & 4)) {   // fp32 class: three terms on the LDS-DMA kernel
+#define NLAM_LAUNCH_WG_LDMA3(SILU_, NB_)                                                                                  \
+    do {                                                                                                                  \
+        const size_t lds2 = WgLdma<false, false, SILU_, 16, NB_>::LDS;                                                     \
+        int rc = set_lds(wgrad_ldma_kernel<3, false, false, SILU_, 16, NB_>, lds2);                                        \
+        if (rc != 0) return rc;                                                                                           \
+        hipLaunchKernelGGL((wgrad_ldma_kernel<3, false, false, SILU_, 16, NB_>), grid, dim3(512), lds2, stream, *p);       \
+    } while (0)
+            if (silu) NLAM_LAUNCH_WG_LDMA3(true, 4);
+            else NLAM_LAUNCH_WG_LDMA3(false, 4);
             return (int32_t)hipGetLastError();
         }
         if (wns == 1 && silu) NLAM_LAUNCH_WG_WBF2(1, true);

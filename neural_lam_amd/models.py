@@ -279,6 +279,8 @@ class BaseGraphModel(StepPredictor):
                 st[key] = o
             else:
                 st.setdefault(key, []).append(o)
+        # the embeddings live for a whole rollout: their consumers' backward passes hand the gradient over in one buffer
+        ops.rollout_shared_reset(outs)
         for key, mlps, _ in specs:   # empty lists (a one-level hierarchy has no up / down embedders)
             if isinstance(mlps, (list, tuple, nn.ModuleList)) and key not in st:
                 st[key] = []

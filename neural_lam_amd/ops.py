@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import math
 import os
 from dataclasses import dataclass, field
 
@@ -138,6 +139,32 @@ def mail_scope():
         MAIL_TOKEN = prev
         if len(_MAILBOX) > 256:   # posts whose consumer never ran (a backward that stopped half way): drop them
             _MAILBOX.clear()
+
+
+# Tensors every autoregressive step of a rollout consumes as source 0 of a fused edge launch (the static edge embeddings, registered
+# by models.compute_static_embeddings): addresses, and -- during backward -- the gradient buffer the first back-propagated step
+# reported for each (see _fused_mlp_backward).  NLAM_ROLLOUT_ACC=0 switches the hand-over off.
+ROLLOUT_ACC_ON = os.environ.get("NLAM_ROLLOUT_ACC", "1") == "1"
+ROLLOUT_SHARED = set()
+_ROLLOUT_USES = {}        # address -> fused launches of this forward pass that take the tensor as source 0 and have not been back-propagated
+_ROLLOUT_ACC = {}         # address -> the gradient buffer their backward passes are collecting (held back until the last one)
+ROLLOUT_ACC_STATS = {"accumulated": 0}   # tests read it
+
+
+def rollout_shared_reset(tensors=()):
+    """New rollout: register the tensors every AR step will consume.  A gradient buffer still held back from the previous pass
+    means a consumer's backward never ran and the others' contributions were not reported: fail loudly."""
+    if _ROLLOUT_ACC and any(v > 0 for v in _ROLLOUT_USES.values()):
+        _ROLLOUT_ACC.clear()
+        _ROLLOUT_USES.clear()
+        raise RuntimeError("gradient hand-over across a rollout: a consumer of a shared embedding was never back-propagated, the gradient "
+                           "held back for it was not reported (set NLAM_ROLLOUT_ACC=0)")
+    ROLLOUT_SHARED.clear()
+    _ROLLOUT_ACC.clear()
+    _ROLLOUT_USES.clear()
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            ROLLOUT_SHARED.add(t.data_ptr())
 
 
 _MAIL_POST = False         # True only around the ONE launch that is a layer's node MLP (gnn_layers._node_update, single-launch depth)
@@ -745,6 +772,13 @@ class FusedMLPFunction(torch.autograd.Function):
                             and ctx.needs_input_grad[7 + k] and ctx.needs_input_grad[7 + t]):
                         ctx.twin_of[k] = t
             ctx.has_ln = ln_w is not None
+            # a tensor registered as shared by the AR steps of a rollout, taken as source 0 with a row-wise gradient: this launch is one of
+            # the consumers whose backward passes collect its gradient in one buffer (see _fused_mlp_backward)
+            ctx.acc_key = None
+            if (ROLLOUT_ACC_ON and geom.dmode[0] == 1 and ctx.needs_input_grad[7] and srcs[0].data_ptr() in ROLLOUT_SHARED
+                    and (binfo[0][1] == B or B == 1)):
+                ctx.acc_key = srcs[0].data_ptr()
+                _ROLLOUT_USES[ctx.acc_key] = _ROLLOUT_USES.get(ctx.acc_key, 0) + 1
             ctx.param_refs = (W1, b1, W2, b2, ln_w, ln_b)   # for .grad views only (DIRECT_PARAM_GRADS)
             # the node MLP of a factorised layer: its dense source-0 gradient is posted for the node-level product's backward
             ctx.mail_post = (MAIL_TOKEN if (_MAIL_POST and MAIL_TOKEN in _MAIL_CONSUMERS and geom.nsrc == 2 and geom.dmode[0] == 1 and geom.src_idx[0] is None
@@ -778,6 +812,15 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     widths = [s[-1] for s in ctx.src_shapes]
     n_fixed = 7
     if g_out is None and g_aggr is None:
+        key_ = getattr(ctx, "acc_key", None)
+        held = None
+        if key_ is not None:   # nothing to add, but this consumer counts: the last one reports what the others collected
+            _ROLLOUT_USES[key_] = _ROLLOUT_USES.get(key_, 1) - 1
+            if _ROLLOUT_USES[key_] <= 0:
+                held = _ROLLOUT_ACC.pop(key_, None)
+        if held is not None:
+            shape0 = ctx.src_shapes[0]
+            return (None,) * n_fixed + (held.reshape(shape0) if held.numel() == math.prod(shape0) else held.sum(0).reshape(shape0),) + (None,) * (nsrc - 1)
         return (None,) * (n_fixed + nsrc)
     if g_out is not None:
         g_out = g_out.reshape(B, -1, dout).contiguous()
@@ -835,12 +878,42 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
         p.dz2, p.dz2_ld = _ptr(dz2), 0
     else:
         dz2, dpad = _alloc_dz2(lib, p, B * rows, dout, dev)   # (rows, dout); 32-padded columns for a ragged output width (output_map)
+    # Gradient hand-over across the autoregressive steps of a rollout (round 6): a static edge embedding is computed once per
+    # rollout and is source 0 of one edge launch per AR step; every step's backward used to report its own (E, d) gradient and
+    # autograd added them (0.1 - 0.5 GB per add at d = 512: 3.7 ms of the cfg5 step).  The first back-propagated step's buffer
+    # is what autograd holds; the later ones add into it inside the kernel (NLAM_F_ACC_DSRC0) and report nothing.
+    # Gradients are HELD BACK until the last of the tensor's consumers (counted in forward) is back-propagated, which reports the
+    # sum: autograd sees one contribution from the fused launches, whatever else contributes to the tensor.
+    acc_report = None   # set on the last consumer: what it reports for source 0
+    acc_key = getattr(ctx, "acc_key", None)
+    if acc_key is not None:
+        remaining = _ROLLOUT_USES.get(acc_key, 1) - 1
+        _ROLLOUT_USES[acc_key] = remaining
+        prev = _ROLLOUT_ACC.get(acc_key)
+        fam2 = (dsrc[0] is not None and int(p.dmode[0]) == 1 and lib.nlam_mlp_bwd_family(C.byref(p)) == 2
+                and (prev is None or prev.shape == dsrc[0].shape))
+        if prev is None:
+            if remaining > 0 and fam2:
+                _ROLLOUT_ACC[acc_key] = dsrc[0]   # first of several: written by this launch, reported by the last
+                acc_report, dsrc[0] = "held", None
+        elif fam2:
+            p.flags = int(p.flags) | L.F_ACC_DSRC0
+            p.dsrc[0] = _ptr(prev)
+            dsrc[0] = None
+            ROLLOUT_ACC_STATS["accumulated"] += 1
+            acc_report = prev if remaining <= 0 else "held"
+        elif remaining <= 0 and dsrc[0] is not None:   # a launch of another kernel family closes the sequence: add what was held back
+            acc_report = "flush"
+        if remaining <= 0:
+            _ROLLOUT_ACC.pop(acc_key, None)
+            if acc_report == "flush":
+                acc_report = prev
     nwp = lib.nlam_mlp_bwd_wpack_floats(C.byref(p))
     wpack = None
     if nwp > 0:
         wbuf = None
         if PACKER is not None and not geom.no_pack:
-            wbuf = PACKER.get_wide("b", p, nwp, ("b", W1.data_ptr(), W2.data_ptr(), tuple(widths), hid, dout, int(p.flags) & ~L.F_STORE_BF16, int(p.ldw1),
+            wbuf = PACKER.get_wide("b", p, nwp, ("b", W1.data_ptr(), W2.data_ptr(), tuple(widths), hid, dout, int(p.flags) & ~(L.F_STORE_BF16 | L.F_ACC_DSRC0), int(p.ldw1),
                                                   rows, ntiles, B, tuple(int(p.dmode[k]) for k in range(nsrc)), int(p.dz2_ld)))
         if wbuf is not None:
             p.wpack, p.wpack_floats, p.flags = wbuf.data_ptr(), nwp, int(p.flags) | L.F_WPACK_READY
@@ -1016,6 +1089,9 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
         launch_weights()
     dW1, db1, dW2, db2, dg, dbt = results
 
+    if isinstance(acc_report, torch.Tensor):
+        # the held-back sum: reported as it is when this launch accumulated into it, added to this launch's own gradient when it could not
+        dsrc[0] = acc_report if dsrc[0] is None else dsrc[0].add_(acc_report)
     grads_src = []
     for k in range(nsrc):
         g = dsrc[k]

@@ -1065,6 +1065,55 @@ def test_rollout_gradients_identical_with_and_without_wgrad_side_streams(dev, tm
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
+def test_rollout_gradient_handover_equals_autograd_accumulation(dev, tmp_path, use_graph):
+    """The static edge embeddings are computed once per rollout and consumed by one edge launch per AR step
+    (models/forecasters/autoregressive.py:63-149).  With ops.ROLLOUT_ACC_ON the first back-propagated step's gradient buffer is
+    what autograd holds and the later steps add into it inside the backward kernel (NLAM_F_ACC_DSRC0, split-bf16 super-tile
+    family) instead of reporting T gradients for autograd to add.  Same sums up to the association of one addition: the
+    step with the hand-over equals the step without it to fp32 rounding, and the hand-over really happens."""
+    from neural_lam_amd import _lib as L
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import models as hm
+    from neural_lam_amd import ops
+    from neural_lam_amd.datastore import SyntheticDatastore
+    from neural_lam_amd.trainer import Trainer
+
+    lib = L.load()
+    assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 0) == 0   # the super-tile family at test sizes
+    T = 3
+    try:
+        def make(on):
+            ops.ROLLOUT_ACC_ON = on
+            ds = SyntheticDatastore(60, 54, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+            ext = ds.get_xy_extent("state")
+            raw = G.create_regular_grid_graph(ds.get_xy("state"))
+            graph = G.normalise_graph(raw, max(ext[1] - ext[0], ext[3] - ext[2]))
+            torch.manual_seed(1)
+            fc = hm.ARForecaster(hm.GraphLAM(ds, graph=graph, hidden_dim=128, processor_layers=2), ds)
+            return ds, Trainer(hm.ForecasterStep(fc, ds).to(dev), lr=1e-3, use_graph=use_graph)
+
+        ds, t_on = make(True)
+        N = ds.num_grid_points
+        g = torch.Generator().manual_seed(0)
+        batch = [torch.randn(1, 2, N, 5, generator=g).to(dev), torch.randn(1, T, N, 5, generator=g).to(dev),
+                 torch.randn(1, T, N, 6, generator=g).to(dev)]
+        ops.ROLLOUT_ACC_STATS["accumulated"] = 0
+        l_on = float(t_on.step(*batch))
+        assert ops.ROLLOUT_ACC_STATS["accumulated"] >= 2 * (T - 1)   # at least the g2m and m2g edge embeddings, once per earlier step
+        g_on = t_on.fp.grad.clone()
+        _, t_off = make(False)
+        ops.ROLLOUT_ACC_STATS["accumulated"] = 0
+        l_off = float(t_off.step(*batch))
+        assert ops.ROLLOUT_ACC_STATS["accumulated"] == 0
+        assert l_on == l_off
+        err = float((g_on - t_off.fp.grad).abs().max()) / float(t_off.fp.grad.abs().max())
+        assert err < 2e-5, err   # (one addition per shared tensor and AR step associates differently: fp32 rounding, amplified by the embedders' LayerNorm backward)
+    finally:
+        ops.ROLLOUT_ACC_ON = True
+        assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("family", ["graph_lam", "hi_lam"])
 def test_early_leaf_backward_gives_the_same_step(dev, tmp_path, family, use_graph):
     """``Trainer(early_leaf_backward=True)`` (NLAM_EARLY_LEAF=1, off by default) cuts the autograd graph behind the

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round 6, call 8: forward with the next super tile's metadata + first chunk prefetched (LDS-carried): parity + kernel timings
+mkdir -p gpurun_out/r6
+LOG=gpurun_out/r6
+timeout 1500 python -m pytest tests/test_hip_parity.py tests/test_full_size_parity.py -x -q -m gpu -k "wide or d128 or d256 or d512 or golden or cfg3 or cfg5 or autocast or bf16_storage or chunk or hilam or split" 2>&1 | tail -4
+for h in 0 1; do
+  echo "== NLAM_WBF_HALF=$h"
+  NLAM_WBF_HALF=$h NLAM_KB_AUTOCAST=1 python tools/kernel_bench.py m2m 12 512 edge 2>&1 | grep -v amdgpu.ids | grep "mlp_fwd"
+  NLAM_WBF_HALF=$h NLAM_KB_AUTOCAST=1 python tools/kernel_bench.py m2g 8 512 edge 2>&1 | grep -v amdgpu.ids | grep "mlp_fwd"
+  NLAM_WBF_HALF=$h python tools/kernel_bench.py m2m 12 256 edge 2>&1 | grep -v amdgpu.ids | grep "mlp_fwd"
+  NLAM_WBF_HALF=$h python tools/kernel_bench.py m2g 8 256 edge 2>&1 | grep -v amdgpu.ids | grep "mlp_fwd"
+done 2>&1 | tee $LOG/ab_fwd_prefetch_kernels.log
+python tools/kernel_bench.py m2m 12 128 edge 2>&1 | grep -v amdgpu.ids | grep "mlp_fwd" | tee -a $LOG/ab_fwd_prefetch_kernels.log
+run() { echo "[$1 $2 $4] $(env $1 python bench.py --config $2 $4 --steps $3 --warmup 2 --no-cpu-baseline --no-gpu-baseline --no-roofline --no-data-path --no-lightning-leg --no-also 2>$LOG/last_err.log | tail -1 | python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4),'ms/step', 'forecast', round(d['forecast_steps_per_s'],1), 'final', d['final_loss'])
+except Exception as e: print('ERR', e)
+")"; }
+for h in 0 1; do run "NLAM_WBF_HALF=$h" cfg5 4 "--precision bf16"; done 2>&1 | tee $LOG/ab_fwd_prefetch_steps.log
+for h in 0 1; do run "NLAM_WBF_HALF=$h" cfg3 8; done 2>&1 | tee -a $LOG/ab_fwd_prefetch_steps.log
+run "X=1" cfg4 30 2>&1 | tee -a $LOG/ab_fwd_prefetch_steps.log
