@@ -289,6 +289,9 @@ int32_t nlam_max_width(void);
 #define NLAM_TUNE_WGRAD_LDMA 9
 /*   NLAM_TUNE_WGRAD_LDMA_VAR: (rows per stage, ring depth) variant of wgrad_ldma_kernel, 0 = default (A/B runs). */
 #define NLAM_TUNE_WGRAD_LDMA_VAR 10
+/*   NLAM_TUNE_WBF_EDGE (round 6): the factorised InteractionNet edge layers of width 512 in the one-term matrix mode on
+ *   mlp_fwd_edge_kernel (shapes as template constants, software-pipelined across super tiles); default 1, 0 = mlp_fwd_wbf_kernel. */
+#define NLAM_TUNE_WBF_EDGE 11
 int32_t nlam_set_tuning(int32_t key, int32_t value);
 /* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this
  * call; 0 when the call runs on the narrow (weights-in-LDS) kernels. */

@@ -31,6 +31,7 @@ TUNE_LIN_GEMM = 7
 TUNE_WBF_V4 = 8
 TUNE_WGRAD_LDMA = 9
 TUNE_WGRAD_LDMA_VAR = 10
+TUNE_WBF_EDGE = 11
 TILE_SPLIT = 1 << 30
 
 EXPORTS = [
@@ -428,6 +429,8 @@ def load():
         lib.nlam_set_tuning(TUNE_LIN_GEMM, int(os.environ["NLAM_LIN_GEMM"]))
     if os.environ.get("NLAM_WGRAD_LDMA"):
         check(lib.nlam_set_tuning(TUNE_WGRAD_LDMA, int(os.environ["NLAM_WGRAD_LDMA"])), "nlam_set_tuning(NLAM_WGRAD_LDMA)")
+    if os.environ.get("NLAM_WBF_EDGE"):
+        check(lib.nlam_set_tuning(TUNE_WBF_EDGE, int(os.environ["NLAM_WBF_EDGE"])), "nlam_set_tuning(NLAM_WBF_EDGE)")
     if os.environ.get("NLAM_WGRAD_LDMA_VAR"):
         check(lib.nlam_set_tuning(TUNE_WGRAD_LDMA_VAR, int(os.environ["NLAM_WGRAD_LDMA_VAR"])), "nlam_set_tuning(NLAM_WGRAD_LDMA_VAR)")
     if os.environ.get("NLAM_WGRAD_CHUNKS"):

@@ -99,6 +99,7 @@ extern int wbf_half;                                               // nlam_set_t
 extern int wbf_v4;                                                 // branch-free chunk accessors in the split-bf16 wide kernels (NLAM_TUNE_WBF_V4)
 extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
 extern int wgrad_ldma;                                             // one-term weight gradients on wgrad_ldma_kernel (NLAM_TUNE_WGRAD_LDMA)
+extern int wbf_edge;                                               // mlp_fwd_edge_kernel for the factorised one-term edge layers (NLAM_TUNE_WBF_EDGE)
 extern int wgrad_ldma_var;                                         // its (rows per stage, ring depth) variant (NLAM_TUNE_WGRAD_LDMA_VAR)
 extern int wgrad_min_parts;                                        // nlam_set_tuning (defined in slice 1)
 extern int wgrad_min_parts_wide;                                   // the same for weight matrices of more than 128 rows
@@ -4445,6 +4446,7 @@ long nlam_detail::lin_gemm_big_rows = 32768;   // 128-row tiles from here (63 78
 int nlam_detail::wgrad_big_min_rows = 0;    // rows from which a wide weight gradient uses 256 x 256 windows (0 = always, the round-2 behaviour)
 int nlam_detail::wgrad_min_parts = 128;     // row slices a weight gradient of more than that many 32-row chunks is cut into at least
 int nlam_detail::wgrad_min_parts_wide = 64; // ... when the weight matrix has more than 128 rows (nlam_set_tuning sets both)
+int nlam_detail::wbf_edge = 1;
 int nlam_detail::wgrad_ldma_var = 0;
 int nlam_detail::wgrad_ldma = 1;           // bit 0: bf16-operand launches, bit 1: fp32-operand one-term launches with 256 x 256 windows (NLAM_TUNE_WGRAD_LDMA)
 int nlam_detail::wgrad_chunks_per_wg = 8;   // A/B at cfg2 (tools/ab_bench.sh): 2.13 -> 2.06 ms per step against one chunk per workgroup
@@ -4499,6 +4501,11 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_WGRAD_CHUNKS) {
         if (value < 1) return NLAM_EINVAL;
         nlam_detail::wgrad_chunks_per_wg = value;
+        return 0;
+    }
+    if (key == NLAM_TUNE_WBF_EDGE) {
+        if (value < 0 || value > 1) return NLAM_EINVAL;
+        nlam_detail::wbf_edge = value;
         return 0;
     }
     if (key == NLAM_TUNE_WGRAD_LDMA_VAR) {
@@ -4818,6 +4825,27 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
         if (v4) NLAM_LAUNCH_FWD_WBF1(1, NW_, FG_, FB_, RT_, RTP_, true, true);          \
         else NLAM_LAUNCH_FWD_WBF1(1, NW_, FG_, FB_, RT_, RTP_, true, false);            \
     } while (0)
+            // the factorised InteractionNet edge layer of one width in the one-term mode: its own software-pipelined kernel (round 6)
+            if (nlam_detail::wbf_edge != 0 && wns == 1 && v4 && (p->flags & NLAM_F_PRE_ADD) && !(p->flags & (NLAM_F_ADD_SRC1 | NLAM_F_NO_ACT)) &&
+                p->nsrc == NLAM_MAX_SRC && p->hid == p->dout && p->hid == 512 && p->src[0].width == p->hid &&
+                p->src[1].width == p->hid && p->src[2].width == p->hid && p->ln_w != nullptr && p->ln_b != nullptr && p->b1 != nullptr &&
+                p->b2 != nullptr && p->aggr != nullptr && p->rowptr != nullptr && p->ncat == 0 && (long)p->ntiles * p->batch >= 2 * 64) {
+                if ((p->flags & NLAM_F_STORE_BF16) && !store_bf16_ok(p)) return NLAM_EUNSUP;
+                const long ns2 = (long)((p->ntiles + 1) / 2) * p->batch;
+                const int eblocks = (int)(ns2 < kNumCUs ? ns2 : kNumCUs);
+#define NLAM_LAUNCH_FWD_EDGE(D_, SBF_)                                                                                    \
+    do {                                                                                                                  \
+        const size_t elds = fwd_edge_lds<D_>();                                                                            \
+        int rc = set_lds(mlp_fwd_edge_kernel<D_, SBF_>, elds);                                                             \
+        if (rc != 0) return rc;                                                                                           \
+        hipLaunchKernelGGL((mlp_fwd_edge_kernel<D_, SBF_>), dim3(eblocks), dim3(512), elds, stream, *p);                   \
+    } while (0)
+                const bool esb = (p->flags & NLAM_F_STORE_BF16) != 0;
+                // (d = 256 in this mode -- cfg3 under autocast, not a BASELINE configuration -- measured no faster than the template's
+                // 4-wave shape, 103.3 vs 102.5 us on the m2m edges: not instantiated)
+                if (esb) NLAM_LAUNCH_FWD_EDGE(512, true); else NLAM_LAUNCH_FWD_EDGE(512, false);
+                return (int32_t)hipGetLastError();
+            }
             if (p->flags & NLAM_F_STORE_BF16) {   // z1 / xhat as bf16 rows: one term, whole blocks, the shapes of store_bf16_ok()
                 if (!store_bf16_ok(p)) return NLAM_EUNSUP;
                 if (pl.cfg == 2) NLAM_LAUNCH_FWD_WBF_S(8, 8, 1, 4, 2);

@@ -145,7 +145,7 @@ def mail_scope():
 # by models.compute_static_embeddings): addresses, and -- during backward -- the gradient buffer the first back-propagated step
 # reported for each (see _fused_mlp_backward).  NLAM_ROLLOUT_ACC=0 switches the hand-over off.
 ROLLOUT_ACC_ON = os.environ.get("NLAM_ROLLOUT_ACC", "1") == "1"
-ROLLOUT_SHARED = set()
+ROLLOUT_SHARED = {}       # address -> weak reference to the registered tensor (a dead tensor's address may be anybody's by now)
 _ROLLOUT_USES = {}        # address -> fused launches of this forward pass that take the tensor as source 0 and have not been back-propagated
 _ROLLOUT_ACC = {}         # address -> the gradient buffer their backward passes are collecting (held back until the last one)
 ROLLOUT_ACC_STATS = {"accumulated": 0}   # tests read it
@@ -154,7 +154,7 @@ ROLLOUT_ACC_STATS = {"accumulated": 0}   # tests read it
 def rollout_shared_reset(tensors=()):
     """New rollout: register the tensors every AR step will consume.  A gradient buffer still held back from the previous pass
     means a consumer's backward never ran and the others' contributions were not reported: fail loudly."""
-    if _ROLLOUT_ACC and any(v > 0 for v in _ROLLOUT_USES.values()):
+    if _ROLLOUT_ACC:
         _ROLLOUT_ACC.clear()
         _ROLLOUT_USES.clear()
         raise RuntimeError("gradient hand-over across a rollout: a consumer of a shared embedding was never back-propagated, the gradient "
@@ -162,9 +162,23 @@ def rollout_shared_reset(tensors=()):
     ROLLOUT_SHARED.clear()
     _ROLLOUT_ACC.clear()
     _ROLLOUT_USES.clear()
+    import weakref
+
     for t in tensors:
         if isinstance(t, torch.Tensor) and t.is_cuda:
-            ROLLOUT_SHARED.add(t.data_ptr())
+            ROLLOUT_SHARED[t.data_ptr()] = weakref.ref(t)
+
+
+def _rollout_shared(t) -> bool:
+    """``t`` (or a view of it starting at the same address) is a registered tensor that is still alive."""
+    ref = ROLLOUT_SHARED.get(t.data_ptr())
+    if ref is None:
+        return False
+    reg = ref()
+    if reg is None:
+        del ROLLOUT_SHARED[t.data_ptr()]
+        return False
+    return reg.untyped_storage().data_ptr() == t.untyped_storage().data_ptr()
 
 
 _MAIL_POST = False         # True only around the ONE launch that is a layer's node MLP (gnn_layers._node_update, single-launch depth)
@@ -775,7 +789,7 @@ class FusedMLPFunction(torch.autograd.Function):
             # a tensor registered as shared by the AR steps of a rollout, taken as source 0 with a row-wise gradient: this launch is one of
             # the consumers whose backward passes collect its gradient in one buffer (see _fused_mlp_backward)
             ctx.acc_key = None
-            if (ROLLOUT_ACC_ON and geom.dmode[0] == 1 and ctx.needs_input_grad[7] and srcs[0].data_ptr() in ROLLOUT_SHARED
+            if (ROLLOUT_ACC_ON and geom.dmode[0] == 1 and ctx.needs_input_grad[7] and ROLLOUT_SHARED and _rollout_shared(srcs[0])
                     and (binfo[0][1] == B or B == 1)):
                 ctx.acc_key = srcs[0].data_ptr()
                 _ROLLOUT_USES[ctx.acc_key] = _ROLLOUT_USES.get(ctx.acc_key, 0) + 1

@@ -410,6 +410,8 @@ class Trainer:
 
         self.module = module
         self.use_graph = use_graph
+        if os.environ.get("NLAM_OVERLAP_WGRAD") in ("0", "1"):   # A/B runs: the whole step on one stream (0)
+            overlap_wgrad = os.environ["NLAM_OVERLAP_WGRAD"] == "1"
         self.overlap_wgrad = overlap_wgrad
         # how a captured step is replayed: "segments" = a chain of linear graphs on one stream + weight-gradient
         # graphs on side streams (_SegmentedStep); "forks" = ONE graph whose weight-gradient branches the executor places
