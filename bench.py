@@ -622,7 +622,7 @@ def main():
         from neural_lam_amd import _lib as _L
 
         traffic, traffic_src = None, "no profiles/round*/pmc_traffic.json"
-        if args.config == "cfg2" and args.precision == "fp32":
+        if True:   # (round 6: the file carries launch keys of the wide configurations too; a key that is absent reads None)
             def round_no(f):
                 digits = "".join(ch for ch in f.parent.name if ch.isdigit())
                 return int(digits) if digits else -1

@@ -33,10 +33,31 @@ STEP = {
     ("mlp_bwd_fast_kernel<2, 2, ", 206 * 512): f"mlp_bwd:6561:{2 * d}:{d}",        # node MLP backward, 6 561 mesh nodes
     ("mlp_fwd_bf_kernel<2, 2, 3, false, true, false", 206 * 512): f"mlp_fwd:6561:{2 * d}:{d}",
 }
+# round 6: the wide edge stages (`path:rows:d` with d = 256: fp32 class, three terms; d = 512: one term, bf16 storage) -- kernel name
+# prefix -> (kind, k, n); the two weight gradients of an edge MLP share one launch key (m = n = d): their mean
+WIDE = {
+    512: {"mlp_fwd_edge_kernel<512": ("mlp_fwd", 1536, 512), "mlp_fwd_wbf_kernel<1,": ("mlp_fwd", 1536, 512),
+          "mlp_bwd_wbf_kernel<1,": ("mlp_bwd", 1536, 512), "wgrad_ldma_kernel<1, true": ("wgrad", 512, 512),
+          "wgrad_wbf_kernel<1,": ("wgrad", 512, 512)},
+    256: {"mlp_fwd_wbf_kernel<3,": ("mlp_fwd", 768, 256), "mlp_bwd_wbf_kernel<3,": ("mlp_bwd", 768, 256),
+          "wgrad_wbf_kernel<3,": ("wgrad", 256, 256), "wgrad_ldma_kernel<3,": ("wgrad", 256, 256)},
+}
 for arg in sys.argv[1:]:
-    path, rows = arg.split(":")
+    parts = arg.split(":")
+    path, rows = parts[0], parts[1]
     js = json.load(open(path))
     out["commands"].append(js["command"])
+    if len(parts) == 3:
+        acc = {}
+        for name, c in js["kernels"].items():
+            for prefix, (kind, k, n) in WIDE[int(parts[2])].items():
+                if name.startswith(prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c and c.get("grid", "").split()[0] not in ("",):
+                    key = f"{kind}:{rows}:{k}:{n}"
+                    acc.setdefault(key, []).append((int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), name, c))
+        for key, lst in acc.items():
+            out["bytes_per_launch"][key] = int(sum(b for b, _, _ in lst) / len(lst))
+            out["counters"][key] = {"kernels": [nm for _, nm, _ in lst], **{kk: vv for kk, vv in lst[0][2].items() if kk != "grid"}}
+        continue
     if rows == "step":
         for kg, c in js.get("by_grid", {}).items():
             name, grid = kg.rsplit("|", 1)
