@@ -4825,25 +4825,28 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
         if (v4) NLAM_LAUNCH_FWD_WBF1(1, NW_, FG_, FB_, RT_, RTP_, true, true);          \
         else NLAM_LAUNCH_FWD_WBF1(1, NW_, FG_, FB_, RT_, RTP_, true, false);            \
     } while (0)
-            // the factorised InteractionNet edge layer of one width in the one-term mode: its own software-pipelined kernel (round 6)
-            if (nlam_detail::wbf_edge != 0 && wns == 1 && v4 && (p->flags & NLAM_F_PRE_ADD) && !(p->flags & (NLAM_F_ADD_SRC1 | NLAM_F_NO_ACT)) &&
-                p->nsrc == NLAM_MAX_SRC && p->hid == p->dout && p->hid == 512 && p->src[0].width == p->hid &&
-                p->src[1].width == p->hid && p->src[2].width == p->hid && p->ln_w != nullptr && p->ln_b != nullptr && p->b1 != nullptr &&
-                p->b2 != nullptr && p->aggr != nullptr && p->rowptr != nullptr && p->ncat == 0 && (long)p->ntiles * p->batch >= 2 * 64) {
+            // the factorised InteractionNet edge layer of one width -- d = 512 in the one-term mode (cfg5), d = 256 in the fp32-class
+            // mode (cfg3): its own software-pipelined kernel (round 6)
+            if (nlam_detail::wbf_edge != 0 && v4 && (p->flags & NLAM_F_PRE_ADD) && !(p->flags & (NLAM_F_ADD_SRC1 | NLAM_F_NO_ACT)) &&
+                p->nsrc == NLAM_MAX_SRC && p->hid == p->dout && ((wns == 1 && p->hid == 512) || (wns == 3 && p->hid == 256 && !(p->flags & NLAM_F_STORE_BF16))) &&
+                p->src[0].width == p->hid && p->src[1].width == p->hid && p->src[2].width == p->hid && p->ln_w != nullptr && p->ln_b != nullptr &&
+                p->b1 != nullptr && p->b2 != nullptr && p->aggr != nullptr && p->rowptr != nullptr && p->ncat == 0 &&
+                (long)p->ntiles * p->batch >= 2 * 64) {
                 if ((p->flags & NLAM_F_STORE_BF16) && !store_bf16_ok(p)) return NLAM_EUNSUP;
                 const long ns2 = (long)((p->ntiles + 1) / 2) * p->batch;
                 const int eblocks = (int)(ns2 < kNumCUs ? ns2 : kNumCUs);
-#define NLAM_LAUNCH_FWD_EDGE(D_, SBF_)                                                                                    \
+#define NLAM_LAUNCH_FWD_EDGE(NS_, D_, SBF_)                                                                               \
     do {                                                                                                                  \
-        const size_t elds = fwd_edge_lds<D_>();                                                                            \
-        int rc = set_lds(mlp_fwd_edge_kernel<D_, SBF_>, elds);                                                             \
+        const size_t elds = fwd_edge_lds<NS_, D_>();                                                                       \
+        int rc = set_lds(mlp_fwd_edge_kernel<NS_, D_, SBF_>, elds);                                                        \
         if (rc != 0) return rc;                                                                                           \
-        hipLaunchKernelGGL((mlp_fwd_edge_kernel<D_, SBF_>), dim3(eblocks), dim3(512), elds, stream, *p);                   \
+        hipLaunchKernelGGL((mlp_fwd_edge_kernel<NS_, D_, SBF_>), dim3(eblocks), dim3(512), elds, stream, *p);              \
     } while (0)
-                const bool esb = (p->flags & NLAM_F_STORE_BF16) != 0;
-                // (d = 256 in this mode -- cfg3 under autocast, not a BASELINE configuration -- measured no faster than the template's
-                // 4-wave shape, 103.3 vs 102.5 us on the m2m edges: not instantiated)
-                if (esb) NLAM_LAUNCH_FWD_EDGE(512, true); else NLAM_LAUNCH_FWD_EDGE(512, false);
+                // (d = 256 in the one-term mode -- cfg3 under autocast, not a BASELINE configuration -- measured no faster than the
+                // template's 4-wave shape, 103.3 vs 102.5 us on the m2m edges: not instantiated)
+                if (wns == 3) NLAM_LAUNCH_FWD_EDGE(3, 256, false);
+                else if (p->flags & NLAM_F_STORE_BF16) NLAM_LAUNCH_FWD_EDGE(1, 512, true);
+                else NLAM_LAUNCH_FWD_EDGE(1, 512, false);
                 return (int32_t)hipGetLastError();
             }
             if (p->flags & NLAM_F_STORE_BF16) {   // z1 / xhat as bf16 rows: one term, whole blocks, the shapes of store_bf16_ok()
