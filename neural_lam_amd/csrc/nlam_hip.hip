@@ -4431,6 +4431,21 @@ __global__ void pack_bf_table_kernel(const nlam_pack_rec_t* recs) {
     }
 }
 
+// mlp_bwd_edge_kernel takes the launch: the data gradients of the factorised InteractionNet edge layer of width 512 in the one-term
+// mode (the backward of what mlp_fwd_edge_kernel<1, 512, .> computes)
+bool bwd_edge_ok(const nlam_mlp_bwd_t* p) {
+    if (nlam_detail::wbf_edge == 0 || !bwd_is_wide(p) || bwd_wbf_ns(p) != 1) return false;
+    if (!(p->flags & NLAM_F_PRE_ADD) || (p->flags & (NLAM_F_ADD_SRC1 | NLAM_F_NO_ACT))) return false;
+    if (p->nsrc != NLAM_MAX_SRC || p->hid != 512 || p->dout != 512) return false;
+    for (int s = 0; s < NLAM_MAX_SRC; ++s)
+        if (p->src[s].width != 512) return false;
+    if (p->ln_w == nullptr || p->g_aggr == nullptr || p->seg_of_row == nullptr || p->rowptr == nullptr || p->dz2_ld != 0) return false;
+    if (p->z1 == nullptr || p->xhat == nullptr || p->rstd == nullptr) return false;
+    if ((p->dmode[0] != 0 && p->dmode[0] != 1) || p->dmode[1] != 0 || (p->dmode[2] != 0 && p->dmode[2] != 3)) return false;
+    if ((p->flags & NLAM_F_MEAN) && p->inv_deg == nullptr) return false;
+    return (long)p->ntiles * p->batch >= 2 * 64;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -4656,6 +4671,10 @@ int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p) {
     if (p == nullptr) return 0;
     const long total = (long)p->ntiles * p->batch;
     if (!bwd_is_wide(p)) return grid_blocks(total);
+    if (bwd_edge_ok(p)) {
+        const long ns2 = (long)((p->ntiles + 1) / 2) * p->batch;
+        return (int32_t)(ns2 < kNumCUs ? ns2 : kNumCUs);
+    }
     if (bwd_wbf_ns(p) > 0) {   // partial-sum rows: one per (workgroup, row group)
         const WbfBwdPlan pl = wbf_bwd_choose(bwd_wide_maxw(p));
         const long nsuper = (long)((p->ntiles + pl.nrt - 1) / pl.nrt) * p->batch;
@@ -5078,6 +5097,20 @@ int32_t nlam_detail::bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream) {
                 if (pblocks > 1024) pblocks = 1024;
                 if (wns == 1) hipLaunchKernelGGL(pack_bf_kernel<1>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
                 else hipLaunchKernelGGL(pack_bf_kernel<3>, dim3((int)pblocks, jobs.njobs), dim3(256), 0, stream, jobs);
+            }
+            if (bwd_edge_ok(p)) {
+                const int eblocks = nlam_mlp_bwd_blocks(p);
+                const size_t elds = bwd_edge_lds<512>();
+                if (p->flags & NLAM_F_STORE_BF16) {
+                    int rc = set_lds(mlp_bwd_edge_kernel<512, true>, elds);
+                    if (rc != 0) return rc;
+                    hipLaunchKernelGGL((mlp_bwd_edge_kernel<512, true>), dim3(eblocks), dim3(512), elds, stream, *p);
+                } else {
+                    int rc = set_lds(mlp_bwd_edge_kernel<512, false>, elds);
+                    if (rc != 0) return rc;
+                    hipLaunchKernelGGL((mlp_bwd_edge_kernel<512, false>), dim3(eblocks), dim3(512), elds, stream, *p);
+                }
+                return (int32_t)hipGetLastError();
             }
             const size_t lds = bwd_wbf_lds(p, wns, pl);
             const int wblocks = nlam_mlp_bwd_blocks(p) / pl.rg;
