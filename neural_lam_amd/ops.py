@@ -238,32 +238,6 @@ def early_backward_leaf(out, force: bool = False):
     return leaf
 
 
-def cu_masked_stream(lo: int, hi: int):
-    """A HIP stream whose kernels may only run on the compute units with mask bits ``lo .. hi - 1`` (hipExtStreamCreateWithCUMask;
-    round 6).  Measured on MI355X / ROCm 7.2 (profiles/round6/cumask_probe.log): contiguous bit ranges are
-    honoured -- by eager launches AND by a HIP graph replayed on the stream (the stream a graph is replayed on decides, not the one
-    it was captured on) -- a 64-bit range gives a compute-bound kernel 1/3.6 of the chip and isolates it from work on the
-    complementary mask; strided masks (every 4th bit) are silently ignored."""
-    import ctypes
-    import glob
-
-    cands = sorted(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so*")))
-    hip = ctypes.CDLL(cands[0]) if cands else ctypes.CDLL("libamdhip64.so")
-    words = (ctypes.c_uint32 * 8)(*[0] * 8)
-    for b in range(max(0, lo), min(256, hi)):
-        words[b // 32] |= 1 << (b % 32)
-    st = ctypes.c_void_p()
-    hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
-    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
-    if rc != 0:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: hipError_t {rc}")
-    return torch.cuda.ExternalStream(st.value)
-
-
-SIDE_CUS = int(os.environ.get("NLAM_SIDE_CUS", "0"))   # > 0: the weight-gradient side streams own mask bits 0 .. SIDE_CUS - 1, a segmented
-                                                        # executor's chain stream the rest (experiment, off by default)
-
-
 class _WgradOverlap:
     """Weight-gradient kernels on a second HIP stream.
 
@@ -287,10 +261,8 @@ class _WgradOverlap:
         work is not launched here at all: every fork is handed over as (side-stream index, closure) and the trainer records
         it into graphs of its own, replayed beside the chain's (DESIGN.md finding 39)."""
         if not self.streams:
-            if SIDE_CUS > 0:
-                self.streams = [cu_masked_stream(0, SIDE_CUS) for _ in range(max(1, self.NSTREAMS))]
-            else:
-                self.streams = [torch.cuda.Stream() for _ in range(max(1, self.NSTREAMS))]
+            # (CU-masked side streams -- hipExtStreamCreateWithCUMask -- were measured in round 6 and lose: DESIGN.md finding 47)
+            self.streams = [torch.cuda.Stream() for _ in range(max(1, self.NSTREAMS))]
         self.active = True
         self.assigned = {}
         self.keep = []

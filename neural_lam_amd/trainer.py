@@ -619,11 +619,7 @@ class Trainer:
         if self._chain_stream is None:
             # normal priority: a HIGH-priority chain stream does get a hardware queue of its own, but the queue priority starves
             # and context-switches the side queues instead of sharing the chip with them: 4.0-4.9 ms per cfg2 step against 1.94
-            ops_ = self._ops()
-            if ops_ is not None and ops_.SIDE_CUS > 0 and os.environ.get("NLAM_CHAIN_MASKED", "1") == "1":
-                self._chain_stream = ops_.cu_masked_stream(ops_.SIDE_CUS, 256)   # experiment: the chain owns the CUs the side streams do not
-            else:
-                self._chain_stream = torch.cuda.Stream(priority=int(os.environ.get("NLAM_CHAIN_PRIO", "0")))
+            self._chain_stream = torch.cuda.Stream(priority=int(os.environ.get("NLAM_CHAIN_PRIO", "0")))
             self._entry_event, self._exit_event = torch.cuda.Event(), torch.cuda.Event()
         cs = self._chain_stream
         seg = _SegmentedStep(self, self.forks_per_segment)
