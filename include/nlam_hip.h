@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define NLAM_ABI_VERSION 7
+#define NLAM_ABI_VERSION 8
 #define NLAM_MAX_SRC 3
 #define NLAM_MAX_CAT 6
 
@@ -384,6 +384,11 @@ int32_t nlam_segment_sum(const float* in, int64_t in_bstride, const int32_t* ptr
 int32_t nlam_segment_sum_acc(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order,
                          const float* scale, float* out, int32_t nseg, int32_t width, int32_t batch,
                          void* hip_stream);
+/* out[b, s] += extra[b, s] + scale[s] * sum_{q in ptr[s]:ptr[s+1]} in[b, order[q]]   (round 6: a layer's sender-side gradient, its
+ * receiver-side gradient `extra` and the node MLP's gradient already in `out` meet in ONE pass -- the torch add launch behind
+ * every mesh <-> mesh layer's backward (gnn_layers.py:110-157: send_rep is rec_rep) is gone). */
+int32_t nlam_segment_sum_add(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
+                             const float* extra, float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream);
 
 /* nlam_segment_sum over input rows stored as bfloat16 (width % 8 == 0; out is float): the dz1 rows of a backward launch that ran with
  * NLAM_F_STORE_BF16 */

@@ -56,6 +56,7 @@ EXPORTS = [
     "nlam_wgrad",
     "nlam_segment_sum",
     "nlam_segment_sum_acc",
+    "nlam_segment_sum_add",
     "nlam_split_combine",
     "nlam_segment_sum_bf16",
     "nlam_store_bf16_supported",
@@ -300,7 +301,7 @@ class PackRec(C.Structure):
     _fields_ = [("bytes", C.c_ubyte * 64)]
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 
@@ -365,6 +366,8 @@ def load():
     lib.nlam_segment_sum.restype = i32
     lib.nlam_segment_sum_acc.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.nlam_segment_sum_acc.restype = i32
+    lib.nlam_segment_sum_add.argtypes = [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.nlam_segment_sum_add.restype = i32
     lib.nlam_segment_sum_bf16.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.nlam_segment_sum_bf16.restype = i32
     lib.nlam_store_bf16_supported.argtypes = [C.POINTER(MlpFwd)]

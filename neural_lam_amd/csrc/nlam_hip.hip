@@ -2971,7 +2971,7 @@ __global__ void split_combine_kernel(float* buf, long bstride, const int32_t* pt
 }
 
 __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32_t* ptr, const int32_t* order,
-                                   const float* scale, float* out, int nseg, int width, int batch, int accumulate) {
+                                   const float* scale, float* out, int nseg, int width, int batch, int accumulate, const float* extra) {
     const int w4 = (width + 3) >> 2;
     const long total = (long)batch * nseg * w4;
     for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
@@ -3001,8 +3001,9 @@ __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32
                 const long row = order != nullptr ? order[q] : q;
                 acc += *reinterpret_cast<const f32x4*>(base + row * width + 4 * c4);
             }
-            if (accumulate) acc = acc * sc + *reinterpret_cast<const f32x4*>(o);   // every output row has exactly one writer
-            else acc = acc * sc;
+            acc = acc * sc;
+            if (extra != nullptr) acc += *reinterpret_cast<const f32x4*>(extra + ((size_t)b * nseg + sgm) * width + 4 * c4);
+            if (accumulate) acc += *reinterpret_cast<const f32x4*>(o);   // every output row has exactly one writer
             *reinterpret_cast<f32x4*>(o) = acc;
         } else {
             for (int c = 0; c < 4 && 4 * c4 + c < width; ++c) {
@@ -3011,7 +3012,9 @@ __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32
                     const long row = order != nullptr ? order[q] : q;
                     acc += base[row * width + 4 * c4 + c];
                 }
-                o[c] = accumulate ? o[c] + acc * sc : acc * sc;
+                float v = acc * sc;
+                if (extra != nullptr) v += extra[((size_t)b * nseg + sgm) * width + 4 * c4 + c];
+                o[c] = accumulate ? o[c] + v : v;
             }
         }
     }
@@ -3024,7 +3027,7 @@ __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32
 template <int S>
 __global__ __launch_bounds__(256) void segment_sum_split_kernel(const float* in, long in_bstride, const int32_t* ptr, const int32_t* order,
                                                                 const float* scale, float* out, int nseg, int width, int batch,
-                                                                int accumulate) {
+                                                                int accumulate, const float* extra) {
     const int w4 = width >> 2;            // lanes per group; S * w4 divides 64
     const long total = (long)batch * nseg * S * w4;
     const long nthr = (long)gridDim.x * blockDim.x;
@@ -3063,6 +3066,7 @@ __global__ __launch_bounds__(256) void segment_sum_split_kernel(const float* in,
             const float sc = scale != nullptr ? scale[sgm] : 1.f;
             float* o = out + ((size_t)b * nseg + sgm) * width + 4 * c4;
             acc = acc * sc;
+            if (extra != nullptr) acc += *reinterpret_cast<const f32x4*>(extra + ((size_t)b * nseg + sgm) * width + 4 * c4);
             if (accumulate) acc += *reinterpret_cast<const f32x4*>(o);
             *reinterpret_cast<f32x4*>(o) = acc;
         }
@@ -5912,7 +5916,8 @@ __global__ void segment_sum_bf16_kernel(const unsigned short* in, long in_bstrid
 }
 
 static int32_t segment_sum_launch(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
-                                  float* out, int32_t nseg, int32_t width, int32_t batch, int accumulate, void* hip_stream) {
+                                  float* out, int32_t nseg, int32_t width, int32_t batch, int accumulate, void* hip_stream,
+                                  const float* extra = nullptr) {
     if (in == nullptr || ptr == nullptr || out == nullptr || nseg < 0 || width < 1 || batch < 1) return NLAM_EINVAL;
     if (nseg == 0) return 0;
     // segments of 16+ rows on average (known when the input has its own batch stride): several lane groups per segment
@@ -5925,17 +5930,17 @@ static int32_t segment_sum_launch(const float* in, int64_t in_bstride, const int
         if (blk > 256 * 16) blk = 256 * 16;
         if (S == 4)
             hipLaunchKernelGGL(segment_sum_split_kernel<4>, dim3((int)blk), dim3(256), 0, (hipStream_t)hip_stream, in, (long)in_bstride, ptr,
-                               order, scale, out, nseg, width, batch, accumulate);
+                               order, scale, out, nseg, width, batch, accumulate, extra);
         else
             hipLaunchKernelGGL(segment_sum_split_kernel<2>, dim3((int)blk), dim3(256), 0, (hipStream_t)hip_stream, in, (long)in_bstride, ptr,
-                               order, scale, out, nseg, width, batch, accumulate);
+                               order, scale, out, nseg, width, batch, accumulate, extra);
         return (int32_t)hipGetLastError();
     }
     const long total = (long)batch * nseg * ((width + 3) / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(segment_sum_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)hip_stream, in, (long)in_bstride,
-                       ptr, order, scale, out, nseg, width, batch, accumulate);
+                       ptr, order, scale, out, nseg, width, batch, accumulate, extra);
     return (int32_t)hipGetLastError();
 }
 
@@ -5963,6 +5968,13 @@ int32_t nlam_segment_sum_acc(const float* in, int64_t in_bstride, const int32_t*
                              float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream) {
     NLAM_RANGE("nlam_segment_sum_acc");
     return segment_sum_launch(in, in_bstride, ptr, order, scale, out, nseg, width, batch, 1, hip_stream);
+}
+
+int32_t nlam_segment_sum_add(const float* in, int64_t in_bstride, const int32_t* ptr, const int32_t* order, const float* scale,
+                             const float* extra, float* out, int32_t nseg, int32_t width, int32_t batch, void* hip_stream) {
+    NLAM_RANGE("nlam_segment_sum_add");
+    if (extra == nullptr) return NLAM_EINVAL;
+    return segment_sum_launch(in, in_bstride, ptr, order, scale, out, nseg, width, batch, 1, hip_stream, extra);
 }
 
 int32_t nlam_split_combine(float* buf, int64_t bstride, const int32_t* ptr, const int32_t* src, const int32_t* dst, int32_t n,

@@ -640,6 +640,7 @@ class InteractionNet(nn.Module):
                 rec_rep = rec_rep.view_as(rec_rep)
                 if same:
                     send_rep = rec_rep
+                ops.MAIL_ALIASED = tok
             aggr, edge_out = self._messages_and_aggregate(send_rep, rec_rep, edge_rep, need_edges, True, rec_alias=alias)
             rec_out = self._node_update(rec_rep, aggr)
         if self.update_edges:

@@ -119,7 +119,8 @@ GRAD_LISTENER = None
 # accumulate) and returns nothing.  Same two-operand fp32 additions, one launch fewer.  NLAM_GRAD_MAILBOX=0 switches it off.
 GRAD_MAILBOX_ON = os.environ.get("NLAM_GRAD_MAILBOX", "1") == "1"
 MAIL_TOKEN = None          # set by gnn_layers.InteractionNet.forward around its calls (mail_scope)
-_MAIL_CONSUMERS = set()    # tokens for which a consumer (a node-level product) was recorded in this forward
+MAIL_ALIASED = None        # the token of a layer whose receiver table IS a private alias (set by InteractionNet.forward, read by consumers)
+_MAIL_CONSUMERS = set()    # tokens for which a consumer (a node-level product, a twin edge launch) was recorded in this forward
 _MAILBOX = {}              # token -> posted gradient buffer (B, N, w), between the two backward calls of one layer
 MAIL_STATS = {"posted": 0, "consumed": 0}   # tests read it
 
@@ -131,12 +132,14 @@ def mail_scope():
     if not GRAD_MAILBOX_ON or not torch.is_grad_enabled():
         yield None
         return
+    global MAIL_ALIASED
     prev, MAIL_TOKEN = MAIL_TOKEN, object()
     try:
         yield MAIL_TOKEN
     finally:
         _MAIL_CONSUMERS.discard(MAIL_TOKEN)
         MAIL_TOKEN = prev
+        MAIL_ALIASED = None
         if len(_MAILBOX) > 256:   # posts whose consumer never ran (a backward that stopped half way): drop them
             _MAILBOX.clear()
 
@@ -757,6 +760,14 @@ class FusedMLPFunction(torch.autograd.Function):
                             and srcs[k].shape == srcs[t].shape and srcs[k].stride() == srcs[t].stride()
                             and ctx.needs_input_grad[7 + k] and ctx.needs_input_grad[7 + t]):
                         ctx.twin_of[k] = t
+            # mesh <-> mesh layer run unfactorised (narrow widths): this launch's gradient of the node table (receiver side + sender
+            # side) is accumulated onto the one the layer's node MLP posts (one nlam_segment_sum_add pass), nothing reported
+            ctx.mail = None
+            if ctx.twin_of and MAIL_TOKEN is not None and MAIL_ALIASED is MAIL_TOKEN:
+                tw = next(iter(ctx.twin_of.values()))
+                if len(ctx.twin_of) == 1 and (binfo[tw][1] == B or B == 1):
+                    ctx.mail = MAIL_TOKEN
+                    _MAIL_CONSUMERS.add(MAIL_TOKEN)
             ctx.has_ln = ln_w is not None
             # a tensor registered as shared by the AR steps of a rollout, taken as source 0 with a row-wise gradient: this launch is one of
             # the consumers whose backward passes collect its gradient in one buffer (see _fused_mlp_backward)
@@ -797,6 +808,8 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     nsrc = geom.nsrc
     widths = [s[-1] for s in ctx.src_shapes]
     n_fixed = 7
+    # (a twin edge launch registered as mailbox consumer: whatever happens below, the post is taken out of the box)
+    posted = _MAILBOX.pop(ctx.mail, None) if getattr(ctx, "mail", None) is not None else None
     if g_out is None and g_aggr is None:
         key_ = getattr(ctx, "acc_key", None)
         held = None
@@ -974,8 +987,16 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
             if tw is not None and dsrc[tw] is not None and dsrc[tw].shape == (B, geom.num_send, widths[k]) and dsrc[tw].is_contiguous():
                 # senders and receivers are the same tensor (mesh <-> mesh layers): add onto the receiver-side
                 # gradient and report nothing for this slot -- one autograd add launch less per layer
-                segment_sum(tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B,
-                            out=dsrc[tw], accumulate=True)
+                if posted is not None and posted.shape == dsrc[tw].shape and posted.is_contiguous():
+                    # ... and both onto the gradient the layer's node MLP has already handed to autograd: nothing to report at all
+                    L.check(lib.nlam_segment_sum_add(_ptr(tmp2[k]), rows * widths[k], _ptr(geom.colptr), _ptr(geom.cperm), None, _ptr(dsrc[tw]),
+                                                     _ptr(posted), geom.num_send, widths[k], B, _stream()), "nlam_segment_sum_add")
+                    MAIL_STATS["consumed"] += 1
+                    dsrc[tw] = None
+                    posted = None
+                else:
+                    segment_sum(tmp2[k], rows * widths[k], geom.colptr, geom.cperm, None, geom.num_send, widths[k], B,
+                                out=dsrc[tw], accumulate=True)
                 dsrc[k] = None
             else:
                 dsrc[k] = segment_sum(

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()  # raises if the .so is missing
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nlam_abi_version() == L.ABI_VERSION == 7
+    assert lib.nlam_abi_version() == L.ABI_VERSION == 8
     assert lib.nlam_max_width() >= 64
     assert lib.nlam_num_blocks(1) == 1 and lib.nlam_num_blocks(10**6) == 256
     # tuning knob: known key accepted (and restored), unknown key / negative value rejected

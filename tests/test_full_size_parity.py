@@ -489,6 +489,41 @@ def test_cfg2_hip_graph_trainer_step_matches_oracle_adamw(dev):
             assert float((v.cpu() - o_sd[k]).abs().max()) < 2e-4, k
 
 
+def test_cfg3_segmented_trainer_trajectory_matches_oracle_adamw(dev):
+    """The wide kernels under the executor the trainer picks for them (segmented chain graphs + weight-gradient side graphs),
+    with the optimizer ON: BASELINE configs[2] (GraphLAM d = 256, 8 processor layers, full MEPS size) with two of its four AR
+    steps (the oracle's memory and minutes), three optimizer steps against the oracle + torch.optim.AdamW -- every step's loss and
+    the final weights.  The lr = 0 test above proves one gradient; this one proves that replay, gradient zeroing, the weight
+    re-pack at the start of each step and the rollout's gradient hand-over stay right while the weights move."""
+    import bench
+    from neural_lam_amd.trainer import Trainer
+    from oracle import models as om
+
+    cfg = bench.CONFIGS["cfg3"]
+    T = 2
+    ds, _, _, o_fc, _, batch_cpu = bench.build(cfg, torch.device("cpu"), oracle=True)
+    _, _, _, h_fc, step, batch = bench.build(cfg, dev)
+    batch_cpu = (batch_cpu[0], batch_cpu[1][:, :T].contiguous(), batch_cpu[2][:, :T].contiguous())
+    batch = (batch[0], batch[1][:, :T].contiguous(), batch[2][:, :T].contiguous())
+    pvs, mask = om.per_var_std_uniform(ds), om.interior_mask_bool(ds)
+    opt = torch.optim.AdamW(o_fc.parameters(), lr=1e-3, betas=(0.9, 0.95))
+    tr = Trainer(step, lr=1e-3, use_graph=True)
+    assert tr.executor == "segments", tr.executor
+    with _Threads():
+        for it in range(3):
+            opt.zero_grad(set_to_none=True)
+            _, o_loss = om.training_loss(o_fc, om.standardize_batch(ds, *batch_cpu), pvs, mask)
+            o_loss.backward()
+            opt.step()
+            h_loss = tr.step(*batch)
+            assert abs(float(h_loss) - float(o_loss)) < TOL * abs(float(o_loss)), it
+    assert tr._graph is not None
+    o_sd = o_fc.state_dict()
+    for k, v in h_fc.state_dict().items():
+        if v.numel():
+            assert float((v.cpu() - o_sd[k]).abs().max()) < 2e-4, k
+
+
 def test_standardize_matches_reference_formula(dev, tmp_path):
     """ForecasterStep.standardize == ForecasterModule.on_after_batch_transfer (models/module.py:326-367): per-variable
     state statistics, forcing statistics tiled feature-major over the window (repeat_interleave, :352-358)."""

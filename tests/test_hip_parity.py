@@ -1657,13 +1657,16 @@ def test_graphed_training_step_equals_eager(dev, tmp_path, model, kw, autocast, 
     assert float(l_e) == float(l_g)
 
 
-@pytest.mark.parametrize("d,same", [(64, True), (64, False), (128, True), (256, False)])
-def test_gradient_mailbox_equals_autograd_accumulation(dev, d, same):
+@pytest.mark.parametrize("d,same,factorised", [(64, True, True), (64, False, True), (128, True, True), (256, False, True),
+                                               (64, True, False), (32, True, False)])
+def test_gradient_mailbox_equals_autograd_accumulation(dev, d, same, factorised):
     """A factorised layer hands the data gradient of its receiver table from the node MLP's backward to the node-level
     product's backward (ops.mail_scope: accumulated in place by nlam_linear, one autograd `add` launch less per layer and AR
     step) instead of returning two tensors for autograd to add.  Two stacked layers (the second one's table is a non-leaf with a
     residual consumer outside the layer): same gradients with the hand-over on and off, and against the oracle; the hand-over
-    really happened (one post + one consume per layer and backward)."""
+    really happened (one post + one consume per layer and backward).  factorised=False: a mesh <-> mesh layer on the plain gather
+    kernels (narrow widths, the cfg2 processor) -- there the EDGE launch is the consumer: its receiver-side and sender-side gradients
+    of the node table meet the node MLP's in one nlam_segment_sum_add pass."""
     from neural_lam_amd import _lib as L
     from neural_lam_amd import ops
     from oracle import gnn_layers as og
@@ -1692,7 +1695,7 @@ def test_gradient_mailbox_equals_autograd_accumulation(dev, d, same):
     s0, r0, e0 = (t.clone().requires_grad_() for t in (send, rec, edge))
     run(refs, s0, r0, e0).backward()
     old = (hl.FACTORISE_MIN_EDGES, hl.FACTORISE_MIN_WORK_WIDE, hl.FACTORISE_MIN_WIDTH_WIDE, hl.FACTORISE_MIN_EDGES_WIDE, ops.GRAD_MAILBOX_ON)
-    hl.FACTORISE_MIN_EDGES = hl.FACTORISE_MIN_WORK_WIDE = hl.FACTORISE_MIN_WIDTH_WIDE = hl.FACTORISE_MIN_EDGES_WIDE = 0
+    hl.FACTORISE_MIN_EDGES = hl.FACTORISE_MIN_WORK_WIDE = hl.FACTORISE_MIN_WIDTH_WIDE = hl.FACTORISE_MIN_EDGES_WIDE = 0 if factorised else 1 << 30
     lib = L.load()
     res = {}
     try:

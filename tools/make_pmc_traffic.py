@@ -36,11 +36,11 @@ STEP = {
 # round 6: the wide edge stages (`path:rows:d` with d = 256: fp32 class, three terms; d = 512: one term, bf16 storage) -- kernel name
 # prefix -> (kind, k, n); the two weight gradients of an edge MLP share one launch key (m = n = d): their mean
 WIDE = {
-    512: {"mlp_fwd_edge_kernel<512": ("mlp_fwd", 1536, 512), "mlp_fwd_wbf_kernel<1,": ("mlp_fwd", 1536, 512),
-          "mlp_bwd_wbf_kernel<1,": ("mlp_bwd", 1536, 512), "wgrad_ldma_kernel<1, true": ("wgrad", 512, 512),
-          "wgrad_wbf_kernel<1,": ("wgrad", 512, 512)},
-    256: {"mlp_fwd_wbf_kernel<3,": ("mlp_fwd", 768, 256), "mlp_bwd_wbf_kernel<3,": ("mlp_bwd", 768, 256),
-          "wgrad_wbf_kernel<3,": ("wgrad", 256, 256), "wgrad_ldma_kernel<3,": ("wgrad", 256, 256)},
+    512: {"mlp_fwd_edge_kernel<1, 512": ("mlp_fwd", 1536, 512), "mlp_fwd_wbf_kernel<1,": ("mlp_fwd", 1536, 512),
+          "mlp_bwd_edge_kernel<512": ("mlp_bwd", 1536, 512), "mlp_bwd_wbf_kernel<1,": ("mlp_bwd", 1536, 512),
+          "wgrad_ldma_kernel<1, true": ("wgrad", 512, 512)},
+    256: {"mlp_fwd_edge_kernel<3, 256": ("mlp_fwd", 768, 256), "mlp_fwd_wbf_kernel<3,": ("mlp_fwd", 768, 256),
+          "mlp_bwd_wbf_kernel<3,": ("mlp_bwd", 768, 256), "wgrad_wbf_kernel<3,": ("wgrad", 256, 256), "wgrad_ldma_kernel<3,": ("wgrad", 256, 256)},
 }
 for arg in sys.argv[1:]:
     parts = arg.split(":")
@@ -48,15 +48,20 @@ for arg in sys.argv[1:]:
     js = json.load(open(path))
     out["commands"].append(js["command"])
     if len(parts) == 3:
+        # per (kernel, grid): the node-level weight gradients of the same stage run the same kernels on a smaller grid -- the edge
+        # launches are the ones on the LARGEST grid of each key
         acc = {}
-        for name, c in js["kernels"].items():
+        for kg, c in js.get("by_grid", {}).items():
+            name, grid = kg.rsplit("|", 1)
             for prefix, (kind, k, n) in WIDE[int(parts[2])].items():
-                if name.startswith(prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c and c.get("grid", "").split()[0] not in ("",):
+                if name.startswith(prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c and grid.isdigit():
                     key = f"{kind}:{rows}:{k}:{n}"
-                    acc.setdefault(key, []).append((int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), name, c))
+                    acc.setdefault(key, []).append((int(grid), int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), name, c))
         for key, lst in acc.items():
-            out["bytes_per_launch"][key] = int(sum(b for b, _, _ in lst) / len(lst))
-            out["counters"][key] = {"kernels": [nm for _, nm, _ in lst], **{kk: vv for kk, vv in lst[0][2].items() if kk != "grid"}}
+            gmax = max(g for g, _, _, _ in lst)
+            lst = [e for e in lst if e[0] == gmax]
+            out["bytes_per_launch"][key] = int(sum(b for _, b, _, _ in lst) / len(lst))
+            out["counters"][key] = {"kernels": [nm for _, _, nm, _ in lst], "grid": gmax, **lst[0][3]}
         continue
     if rows == "step":
         for kg, c in js.get("by_grid", {}).items():
