@@ -263,8 +263,9 @@ int32_t nlam_max_width(void);
  *   LDS for the whole launch (default 256 = one per CU; 0 = stream the strip through two LDS buffers as for k > 256). */
 #define NLAM_TUNE_LIN_WGS 3
 /*   NLAM_TUNE_WGRAD_MIN_PARTS: least number of row slices (= partial sums per element) a weight gradient over more than that
- *   many 32-row chunks is cut into (default 128, and 64 for weight matrices of more than 128 rows: launch width for the mid-size
- *   problems; smaller = less partial-sum traffic; setting it sets both). */
+ *   many 32-row chunks is cut into (default 128; for weight matrices of more than 128 rows as many as give 64 workgroups:
+ *   64 / number of 256 x 256 windows -- launch width for the mid-size problems; smaller = less partial-sum traffic; setting it
+ *   sets both to the given slice count). */
 #define NLAM_TUNE_WGRAD_MIN_PARTS 4
 /*   NLAM_TUNE_WGRAD_BIG_MIN_ROWS: rows (x batch) from which a split-bf16 weight gradient with more than 128 output rows uses
  *   256 x 256 windows; below it 128 x 128 windows (same launch width, a quarter of the row slices and partial sums). */

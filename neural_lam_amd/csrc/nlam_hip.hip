@@ -4464,7 +4464,7 @@ int nlam_detail::lin_gemm = 1;              // nlam_linear: LDS-tiled GEMM for n
 long nlam_detail::lin_gemm_big_rows = 32768;   // 128-row tiles from here (63 784 grid nodes), 64-row tiles below (6 561 mesh nodes)
 int nlam_detail::wgrad_big_min_rows = 0;    // rows from which a wide weight gradient uses 256 x 256 windows (0 = always, the round-2 behaviour)
 int nlam_detail::wgrad_min_parts = 128;     // row slices a weight gradient of more than that many 32-row chunks is cut into at least
-int nlam_detail::wgrad_min_parts_wide = 64; // ... when the weight matrix has more than 128 rows (nlam_set_tuning sets both)
+int nlam_detail::wgrad_min_parts_wide = -1; // ... when the weight matrix has more than 128 rows: -1 = as many as give 64 WORKGROUPS (nlam_set_tuning sets both to a slice count)
 int nlam_detail::wbf_edge = 1;
 int nlam_detail::wgrad_ldma_var = 0;
 int nlam_detail::wgrad_ldma = 1;           // bit 0: bf16-operand launches, bit 1: fp32-operand one-term launches with 256 x 256 windows (NLAM_TUNE_WGRAD_LDMA)
@@ -4739,7 +4739,15 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     // nlam_set_tuning; defaults 128, and 64 for weight matrices of more than 128 rows (d >= 256): re-measured under the segmented
     // executor (profiles/round5/ab_wgrad_knobs_segmented.log: cfg3 44.1 -> 43.3 / 43.2 -> 42.5 ms, under autocast 29.4 -> 28.7;
     // cfg5 unchanged; at d <= 128 the value 64 LOSES 1-2 %: cfg2 1.732 -> 1.745, cfg4 10.67 -> 10.86)
-    const int minp_cfg = p->m > 128 ? nlam_detail::wgrad_min_parts_wide : nlam_detail::wgrad_min_parts;
+    // round 6 (profiles/round6/ab_wgrad_min_parts.log): what the wide floor buys is launch width, and a 512 x 512 gradient has four
+    // 256 x 256 windows per slice -- 64 slices of a 6 561-row problem are 64 MB of partial sums for 27 MB of operands.  The floor is
+    // 64 workgroups, not 64 slices: cfg5 112.2 -> 109.7 ms (its isolated launch 25.6 -> 34.8 us: the step gains what the partial
+    // traffic cost its neighbours), cfg3 (one window: 64 slices as before) unchanged
+    int minp_cfg = p->m > 128 ? nlam_detail::wgrad_min_parts_wide : nlam_detail::wgrad_min_parts;
+    if (minp_cfg < 0) {
+        const int win = wgrad_is_wide(p) ? wgrad_windows_of(p, 256, 256) : 1;
+        minp_cfg = (64 + win - 1) / (win < 1 ? 1 : win);
+    }
     const long minp = minp_cfg < 1 ? 1 : minp_cfg;
     if (np < minp && total_chunks > minp) np = minp;
     long cap = 512;
