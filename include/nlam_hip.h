@@ -293,6 +293,10 @@ int32_t nlam_max_width(void);
 /*   NLAM_TUNE_WBF_EDGE (round 6): the factorised InteractionNet edge layers of width 512 in the one-term matrix mode on
  *   mlp_fwd_edge_kernel (shapes as template constants, software-pipelined across super tiles); default 1, 0 = mlp_fwd_wbf_kernel. */
 #define NLAM_TUNE_WBF_EDGE 11
+/*   NLAM_TUNE_WGRAD_MAX_WGS (round 6): most workgroups (row slices x 256 x 256 windows) of a split-bf16 weight gradient with more
+ *   than 128 output rows (default 128: half the CUs -- the launch runs beside the data-gradient chain; 256 = one per CU, rounds 2-5;
+ *   4 .. 1024). */
+#define NLAM_TUNE_WGRAD_MAX_WGS 12
 int32_t nlam_set_tuning(int32_t key, int32_t value);
 /* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this
  * call; 0 when the call runs on the narrow (weights-in-LDS) kernels. */

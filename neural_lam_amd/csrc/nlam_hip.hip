@@ -99,6 +99,7 @@ extern int wbf_half;                                               // nlam_set_t
 extern int wbf_v4;                                                 // branch-free chunk accessors in the split-bf16 wide kernels (NLAM_TUNE_WBF_V4)
 extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
 extern int wgrad_ldma;                                             // one-term weight gradients on wgrad_ldma_kernel (NLAM_TUNE_WGRAD_LDMA)
+extern int wgrad_max_wgs;                                          // workgroups of a big split-bf16 weight gradient (NLAM_TUNE_WGRAD_MAX_WGS)
 extern int wbf_edge;                                               // mlp_fwd_edge_kernel for the factorised one-term edge layers (NLAM_TUNE_WBF_EDGE)
 extern int wgrad_ldma_var;                                         // its (rows per stage, ring depth) variant (NLAM_TUNE_WGRAD_LDMA_VAR)
 extern int wgrad_min_parts;                                        // nlam_set_tuning (defined in slice 1)
@@ -4466,6 +4467,7 @@ int nlam_detail::wgrad_big_min_rows = 0;    // rows from which a wide weight gra
 int nlam_detail::wgrad_min_parts = 128;     // row slices a weight gradient of more than that many 32-row chunks is cut into at least
 int nlam_detail::wgrad_min_parts_wide = -1; // ... when the weight matrix has more than 128 rows: -1 = as many as give 64 WORKGROUPS (nlam_set_tuning sets both to a slice count)
 int nlam_detail::wbf_edge = 1;
+int nlam_detail::wgrad_max_wgs = 128;   // round 6: 256 (one per CU) until then -- see nlam_wgrad_nparts
 int nlam_detail::wgrad_ldma_var = 0;
 int nlam_detail::wgrad_ldma = 1;           // bit 0: bf16-operand launches, bit 1: fp32-operand one-term launches with 256 x 256 windows (NLAM_TUNE_WGRAD_LDMA)
 int nlam_detail::wgrad_chunks_per_wg = 8;   // A/B at cfg2 (tools/ab_bench.sh): 2.13 -> 2.06 ms per step against one chunk per workgroup
@@ -4520,6 +4522,11 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_WGRAD_CHUNKS) {
         if (value < 1) return NLAM_EINVAL;
         nlam_detail::wgrad_chunks_per_wg = value;
+        return 0;
+    }
+    if (key == NLAM_TUNE_WGRAD_MAX_WGS) {
+        if (value < 4 || value > 1024) return NLAM_EINVAL;
+        nlam_detail::wgrad_max_wgs = value;
         return 0;
     }
     if (key == NLAM_TUNE_WBF_EDGE) {
@@ -4754,7 +4761,11 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     if (p->nsrc == 1 && p->src[0].width <= kSmallN && p->m % 4 == 0) np = (total_chunks + 3) / 4;   // streaming kernel: >= 128 rows per workgroup
     if (wgrad_is_wide(p)) {
         cap = 1024 / wgrad_windows(p);
-        if (wgrad_wbf_ns(p) > 0 && wgrad_wbf_big(p)) cap = 256 / wgrad_windows_of(p, 256, 256);   // one 8-wave workgroup per CU
+        // 8-wave workgroups on 256 x 256 windows: at most NLAM_TUNE_WGRAD_MAX_WGS of them.  One per CU (256) until round 6; measured
+        // then (profiles/round6/ab_wgrad_chunks.log, ab_wgrad_max_wgs.log): a 512 x 512 gradient over 57 616 rows in 29 slices x 4
+        // windows instead of 64 x 4 -- half the partial sums, half the CUs taken from the chain -- cfg5 109.9 -> 108.1 ms; a
+        // 256 x 256 one (one window) is indifferent between 113 and 226 slices and loses 3-5 % below 60
+        if (wgrad_wbf_ns(p) > 0 && wgrad_wbf_big(p)) cap = nlam_detail::wgrad_max_wgs / wgrad_windows_of(p, 256, 256);
         if (cap < 4) cap = 4;
     }
     if (np > cap) np = cap;

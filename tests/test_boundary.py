@@ -42,6 +42,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.nlam_set_tuning(L.TUNE_WGRAD_LDMA, 8) == -1 and lib.nlam_set_tuning(L.TUNE_WGRAD_LDMA, 1) == 0
     assert lib.nlam_set_tuning(L.TUNE_WGRAD_LDMA_VAR, 4) == -1 and lib.nlam_set_tuning(L.TUNE_WGRAD_LDMA_VAR, 0) == 0
     assert lib.nlam_set_tuning(L.TUNE_WBF_EDGE, 2) == -1 and lib.nlam_set_tuning(L.TUNE_WBF_EDGE, 1) == 0
+    assert lib.nlam_set_tuning(L.TUNE_WGRAD_MAX_WGS, 3) == -1 and lib.nlam_set_tuning(L.TUNE_WGRAD_MAX_WGS, 128) == 0
 
 
 def test_ctypes_structs_match_c_layout(tmp_path):
@@ -249,7 +250,7 @@ def test_launch_shape_queries():
     q.m, q.n, q.rows, q.flags = 256, 768, 255136, 3 << 8
     for k in range(3):
         q.src[k].width = 256
-    assert lib.nlam_wgrad_nparts(C.byref(q)) == 256 // 3      # split-bf16: three 256 x 256 windows, one workgroup per CU
+    assert lib.nlam_wgrad_nparts(C.byref(q)) == 128 // 3      # split-bf16: three 256 x 256 windows, at most 128 workgroups (NLAM_TUNE_WGRAD_MAX_WGS)
     q.flags = 0
     assert lib.nlam_wgrad_nparts(C.byref(q)) == 1024 // 12    # fp32: twelve 128 x 128 windows
 
