@@ -297,6 +297,10 @@ int32_t nlam_max_width(void);
  *   than 128 output rows (default 128: half the CUs -- the launch runs beside the data-gradient chain; 256 = one per CU, rounds 2-5;
  *   4 .. 1024). */
 #define NLAM_TUNE_WGRAD_MAX_WGS 12
+/*   NLAM_TUNE_CHAIN_CUS (round 6): CUs a wide (> 64) fused-MLP launch sizes its persistent grid for (default 256 = all of them;
+ *   16 .. 1024: values above 256 oversubscribe the CUs; set before the first launch of a step is recorded -- nlam_mlp_bwd_blocks
+ *   follows it.  Measured (profiles/round6/ab_chain_cus.log): 192 .. 240 lose 1.5-5 %, 384 .. 1024 lose 0.5-5 %). */
+#define NLAM_TUNE_CHAIN_CUS 13
 int32_t nlam_set_tuning(int32_t key, int32_t value);
 /* Scratch the wide kernels need for the packed (MFMA A-operand order) weights of this
  * call; 0 when the call runs on the narrow (weights-in-LDS) kernels. */

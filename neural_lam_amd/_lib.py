@@ -33,6 +33,7 @@ TUNE_WGRAD_LDMA = 9
 TUNE_WGRAD_LDMA_VAR = 10
 TUNE_WBF_EDGE = 11
 TUNE_WGRAD_MAX_WGS = 12
+TUNE_CHAIN_CUS = 13
 TILE_SPLIT = 1 << 30
 
 EXPORTS = [
@@ -437,6 +438,8 @@ def load():
         check(lib.nlam_set_tuning(TUNE_WBF_EDGE, int(os.environ["NLAM_WBF_EDGE"])), "nlam_set_tuning(NLAM_WBF_EDGE)")
     if os.environ.get("NLAM_WGRAD_LDMA_VAR"):
         check(lib.nlam_set_tuning(TUNE_WGRAD_LDMA_VAR, int(os.environ["NLAM_WGRAD_LDMA_VAR"])), "nlam_set_tuning(NLAM_WGRAD_LDMA_VAR)")
+    if os.environ.get("NLAM_CHAIN_CUS"):
+        check(lib.nlam_set_tuning(TUNE_CHAIN_CUS, int(os.environ["NLAM_CHAIN_CUS"])), "nlam_set_tuning(NLAM_CHAIN_CUS)")
     if os.environ.get("NLAM_WGRAD_MAX_WGS"):
         check(lib.nlam_set_tuning(TUNE_WGRAD_MAX_WGS, int(os.environ["NLAM_WGRAD_MAX_WGS"])), "nlam_set_tuning(NLAM_WGRAD_MAX_WGS)")
     if os.environ.get("NLAM_WGRAD_CHUNKS"):

@@ -99,6 +99,7 @@ extern int wbf_half;                                               // nlam_set_t
 extern int wbf_v4;                                                 // branch-free chunk accessors in the split-bf16 wide kernels (NLAM_TUNE_WBF_V4)
 extern int wgrad_chunks_per_wg;                                    // nlam_set_tuning (defined in slice 1)
 extern int wgrad_ldma;                                             // one-term weight gradients on wgrad_ldma_kernel (NLAM_TUNE_WGRAD_LDMA)
+extern int chain_cus;                                              // persistent workgroups (x occupancy) of a wide fused-MLP launch (NLAM_TUNE_CHAIN_CUS)
 extern int wgrad_max_wgs;                                          // workgroups of a big split-bf16 weight gradient (NLAM_TUNE_WGRAD_MAX_WGS)
 extern int wbf_edge;                                               // mlp_fwd_edge_kernel for the factorised one-term edge layers (NLAM_TUNE_WBF_EDGE)
 extern int wgrad_ldma_var;                                         // its (rows per stage, ring depth) variant (NLAM_TUNE_WGRAD_LDMA_VAR)
@@ -4206,7 +4207,7 @@ int wide_grid(long total_tiles, size_t lds, int nwv) {
     const int wave_cap = 16 / nwv;          // at most 4 waves per SIMD
     if (occ > wave_cap) occ = wave_cap;
     if (occ < 1) occ = 1;
-    long g = (long)kNumCUs * occ;
+    long g = (long)nlam_detail::chain_cus * occ;
     if (total_tiles < g) g = total_tiles;
     return (int)(g < 1 ? 1 : g);
 }
@@ -4467,6 +4468,7 @@ int nlam_detail::wgrad_big_min_rows = 0;    // rows from which a wide weight gra
 int nlam_detail::wgrad_min_parts = 128;     // row slices a weight gradient of more than that many 32-row chunks is cut into at least
 int nlam_detail::wgrad_min_parts_wide = -1; // ... when the weight matrix has more than 128 rows: -1 = as many as give 64 WORKGROUPS (nlam_set_tuning sets both to a slice count)
 int nlam_detail::wbf_edge = 1;
+int nlam_detail::chain_cus = kNumCUs;
 int nlam_detail::wgrad_max_wgs = 128;   // round 6: 256 (one per CU) until then -- see nlam_wgrad_nparts
 int nlam_detail::wgrad_ldma_var = 0;
 int nlam_detail::wgrad_ldma = 1;           // bit 0: bf16-operand launches, bit 1: fp32-operand one-term launches with 256 x 256 windows (NLAM_TUNE_WGRAD_LDMA)
@@ -4522,6 +4524,11 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
     if (key == NLAM_TUNE_WGRAD_CHUNKS) {
         if (value < 1) return NLAM_EINVAL;
         nlam_detail::wgrad_chunks_per_wg = value;
+        return 0;
+    }
+    if (key == NLAM_TUNE_CHAIN_CUS) {
+        if (value < 16 || value > 4 * kNumCUs) return NLAM_EINVAL;
+        nlam_detail::chain_cus = value;
         return 0;
     }
     if (key == NLAM_TUNE_WGRAD_MAX_WGS) {
@@ -4684,12 +4691,12 @@ int32_t nlam_mlp_bwd_blocks(const nlam_mlp_bwd_t* p) {
     if (!bwd_is_wide(p)) return grid_blocks(total);
     if (bwd_edge_ok(p)) {
         const long ns2 = (long)((p->ntiles + 1) / 2) * p->batch;
-        return (int32_t)(ns2 < kNumCUs ? ns2 : kNumCUs);
+        return (int32_t)(ns2 < nlam_detail::chain_cus ? ns2 : nlam_detail::chain_cus);
     }
     if (bwd_wbf_ns(p) > 0) {   // partial-sum rows: one per (workgroup, row group)
         const WbfBwdPlan pl = wbf_bwd_choose(bwd_wide_maxw(p));
         const long nsuper = (long)((p->ntiles + pl.nrt - 1) / pl.nrt) * p->batch;
-        const long cap = pl.nw == 4 ? 2 * kNumCUs : kNumCUs;   // one 8-wave workgroup per CU, or two of 4 waves
+        const long cap = pl.nw == 4 ? 2 * nlam_detail::chain_cus : nlam_detail::chain_cus;   // one 8-wave workgroup per CU, or two of 4 waves
         return (int32_t)((nsuper < cap ? (nsuper < 1 ? 1 : nsuper) : cap) * pl.rg);
     }
     const WideCfg cfg = wide_cfg(bwd_wide_maxw(p));
@@ -4847,7 +4854,7 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
             const long nsuper = (long)((p->ntiles + pl.nrt - 1) / pl.nrt) * p->batch;
             // one 8-wave workgroup per CU, or two of 4 waves (ONE 4-wave workgroup per CU, leaving half of every CU to the
             // weight-gradient kernels of the side streams, measured 20 % slower in the captured cfg3 step: 59.8 vs 49.4 ms)
-            const long wcap = pl.nw == 4 ? 2 * kNumCUs : kNumCUs;
+            const long wcap = pl.nw == 4 ? 2 * nlam_detail::chain_cus : nlam_detail::chain_cus;
             const int wblocks = (int)(nsuper < wcap ? (nsuper < 1 ? 1 : nsuper) : wcap);
             bool v4 = nlam_detail::wbf_v4 != 0 && p->hid % 4 == 0 && p->dout % 4 == 0;   // every chunk a whole 16-byte piece: the branch-free chunk accessors
             for (int s_ = 0; s_ < p->nsrc; ++s_) v4 = v4 && p->src[s_].width % 4 == 0;
@@ -4876,7 +4883,7 @@ int32_t nlam_detail::fwd_wbf(const nlam_mlp_fwd_t* p, hipStream_t stream) {
                 (long)p->ntiles * p->batch >= 2 * 64) {
                 if ((p->flags & NLAM_F_STORE_BF16) && !store_bf16_ok(p)) return NLAM_EUNSUP;
                 const long ns2 = (long)((p->ntiles + 1) / 2) * p->batch;
-                const int eblocks = (int)(ns2 < kNumCUs ? ns2 : kNumCUs);
+                const int eblocks = (int)(ns2 < nlam_detail::chain_cus ? ns2 : nlam_detail::chain_cus);
 #define NLAM_LAUNCH_FWD_EDGE(NS_, D_, SBF_)                                                                               \
     do {                                                                                                                  \
         const size_t elds = fwd_edge_lds<NS_, D_>();                                                                       \
