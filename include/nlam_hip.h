@@ -290,8 +290,10 @@ int32_t nlam_max_width(void);
 #define NLAM_TUNE_WGRAD_LDMA 9
 /*   NLAM_TUNE_WGRAD_LDMA_VAR: (rows per stage, ring depth) variant of wgrad_ldma_kernel, 0 = default (A/B runs). */
 #define NLAM_TUNE_WGRAD_LDMA_VAR 10
-/*   NLAM_TUNE_WBF_EDGE (round 6): the factorised InteractionNet edge layers of width 512 in the one-term matrix mode on
- *   mlp_fwd_edge_kernel (shapes as template constants, software-pipelined across super tiles); default 1, 0 = mlp_fwd_wbf_kernel. */
+/*   NLAM_TUNE_WBF_EDGE (round 6): the factorised InteractionNet edge layers of width 512 in the one-term matrix mode and of width
+ *   256 in the three-term mode on mlp_fwd_edge_kernel / mlp_bwd_edge_kernel (shapes as template constants, software-pipelined across
+ *   super tiles); default 1; 0 = the template kernels (mlp_fwd_wbf_kernel / mlp_bwd_wbf_kernel); 3 = as 1 without the three-term
+ *   backward. */
 #define NLAM_TUNE_WBF_EDGE 11
 /*   NLAM_TUNE_WGRAD_MAX_WGS (round 6): most workgroups (row slices x 256 x 256 windows) of a split-bf16 weight gradient with more
  *   than 128 output rows (default 128: half the CUs -- the launch runs beside the data-gradient chain; 256 = one per CU, rounds 2-5;

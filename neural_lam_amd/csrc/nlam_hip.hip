@@ -4438,13 +4438,16 @@ __global__ void pack_bf_table_kernel(const nlam_pack_rec_t* recs) {
 }
 
 // mlp_bwd_edge_kernel takes the launch: the data gradients of the factorised InteractionNet edge layer of width 512 in the one-term
-// mode (the backward of what mlp_fwd_edge_kernel<1, 512, .> computes)
+// mode or of width 256 in the three-term mode (the backward of what mlp_fwd_edge_kernel<1, 512, .> / <3, 256, false> compute)
 bool bwd_edge_ok(const nlam_mlp_bwd_t* p) {
-    if (nlam_detail::wbf_edge == 0 || !bwd_is_wide(p) || bwd_wbf_ns(p) != 1) return false;
+    if (nlam_detail::wbf_edge == 0 || !bwd_is_wide(p)) return false;
+    const int wns = bwd_wbf_ns(p);
+    const int d = wns == 1 ? 512 : 256;
+    if (wns != 1 && !(wns == 3 && (nlam_detail::wbf_edge & 2) == 0 && !(p->flags & NLAM_F_STORE_BF16))) return false;
     if (!(p->flags & NLAM_F_PRE_ADD) || (p->flags & (NLAM_F_ADD_SRC1 | NLAM_F_NO_ACT))) return false;
-    if (p->nsrc != NLAM_MAX_SRC || p->hid != 512 || p->dout != 512) return false;
+    if (p->nsrc != NLAM_MAX_SRC || p->hid != d || p->dout != d) return false;
     for (int s = 0; s < NLAM_MAX_SRC; ++s)
-        if (p->src[s].width != 512) return false;
+        if (p->src[s].width != d) return false;
     if (p->ln_w == nullptr || p->g_aggr == nullptr || p->seg_of_row == nullptr || p->rowptr == nullptr || p->dz2_ld != 0) return false;
     if (p->z1 == nullptr || p->xhat == nullptr || p->rstd == nullptr) return false;
     if ((p->dmode[0] != 0 && p->dmode[0] != 1) || p->dmode[1] != 0 || (p->dmode[2] != 0 && p->dmode[2] != 3)) return false;
@@ -4537,7 +4540,7 @@ int32_t nlam_set_tuning(int32_t key, int32_t value) {
         return 0;
     }
     if (key == NLAM_TUNE_WBF_EDGE) {
-        if (value < 0 || value > 1) return NLAM_EINVAL;
+        if (value < 0 || value > 3) return NLAM_EINVAL;
         nlam_detail::wbf_edge = value;
         return 0;
     }
@@ -5130,15 +5133,21 @@ int32_t nlam_detail::bwd_wbf(const nlam_mlp_bwd_t* p, hipStream_t stream) {
             }
             if (bwd_edge_ok(p)) {
                 const int eblocks = nlam_mlp_bwd_blocks(p);
-                const size_t elds = bwd_edge_lds<512>();
-                if (p->flags & NLAM_F_STORE_BF16) {
-                    int rc = set_lds(mlp_bwd_edge_kernel<512, true>, elds);
+                if (wns == 3) {
+                    const size_t elds = bwd_edge_lds<3, 256>();
+                    int rc = set_lds(mlp_bwd_edge_kernel<3, 256, false>, elds);
                     if (rc != 0) return rc;
-                    hipLaunchKernelGGL((mlp_bwd_edge_kernel<512, true>), dim3(eblocks), dim3(512), elds, stream, *p);
+                    hipLaunchKernelGGL((mlp_bwd_edge_kernel<3, 256, false>), dim3(eblocks), dim3(512), elds, stream, *p);
+                } else if (p->flags & NLAM_F_STORE_BF16) {
+                    const size_t elds = bwd_edge_lds<1, 512>();
+                    int rc = set_lds(mlp_bwd_edge_kernel<1, 512, true>, elds);
+                    if (rc != 0) return rc;
+                    hipLaunchKernelGGL((mlp_bwd_edge_kernel<1, 512, true>), dim3(eblocks), dim3(512), elds, stream, *p);
                 } else {
-                    int rc = set_lds(mlp_bwd_edge_kernel<512, false>, elds);
+                    const size_t elds = bwd_edge_lds<1, 512>();
+                    int rc = set_lds(mlp_bwd_edge_kernel<1, 512, false>, elds);
                     if (rc != 0) return rc;
-                    hipLaunchKernelGGL((mlp_bwd_edge_kernel<512, false>), dim3(eblocks), dim3(512), elds, stream, *p);
+                    hipLaunchKernelGGL((mlp_bwd_edge_kernel<1, 512, false>), dim3(eblocks), dim3(512), elds, stream, *p);
                 }
                 return (int32_t)hipGetLastError();
             }

@@ -241,6 +241,91 @@ def early_backward_leaf(out, force: bool = False):
     return leaf
 
 
+# ---- streams by hardware queue (round 6, DESIGN.md finding 54) -------------------------------------------------------------------
+# ROCm runs all HIP streams of a process on a few in-order hardware queues (GPU_MAX_HW_QUEUES, default 4; a stream is bound to one
+# when it is first used, whichever has the fewest streams then).  Which streams end up TOGETHER therefore depends on everything the
+# process did before -- and a chain stream that shares its queue with weight-gradient side streams waits behind their launches: the
+# same cfg3 step took 41.9 ms in a fresh process and 47.7 ms after a cfg2 trainer had run in it (profiles/round6/queue_placement.log:
+# chain + two side streams on one queue, one queue idle).  The binding cannot be queried, but it can be OBSERVED: a tiny launch on
+# stream b behind a spinning kernel on stream a finishes late exactly when the two share a queue.  stream_layout() does that once per
+# process over a handful of pool streams and hands out a chain stream with a queue to itself and side streams spread over the others.
+_LAYOUT = None
+QUEUE_PROBE = os.environ.get("NLAM_QUEUE_PROBE", "1") == "1"
+# side streams per hardware queue the chain does not use, in the order of the groups found; "0" = do not place anything (round-5
+# behaviour: the next pool streams, wherever they land)
+QUEUE_SIDES = os.environ.get("NLAM_QUEUE_SIDES", "")
+
+
+def _streams_share_queue(a, b, tick, spin_cycles=4_000_000):
+    """True when a launch on ``b`` waits for an earlier, long launch on ``a``: the two are bound to one in-order hardware queue."""
+    torch.cuda.synchronize()
+    ea, eb = torch.cuda.Event(), torch.cuda.Event()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(spin_cycles)   # ~2 ms
+        ea.record()
+    with torch.cuda.stream(b):
+        tick.add_(1)
+        eb.record()
+    eb.synchronize()
+    shared = ea.query()   # the spin was over before the tiny launch finished
+    ea.synchronize()
+    return bool(shared)
+
+
+def stream_layout(nsides=None):
+    """-> {"chain": stream, "sides": [streams], "groups": [[streams of one hardware queue], ..]} -- process-wide, built once."""
+    global _LAYOUT
+    if _LAYOUT is not None:
+        return _LAYOUT
+    nsides = max(1, _WgradOverlap.NSTREAMS if nsides is None else nsides)
+    if not QUEUE_PROBE or torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing():   # never probe inside a capture; do not cache either
+            return {"chain": torch.cuda.Stream(), "sides": [torch.cuda.Stream() for _ in range(nsides)], "groups": []}
+        _LAYOUT = {"chain": torch.cuda.Stream(), "sides": [torch.cuda.Stream() for _ in range(nsides)], "groups": []}
+        return _LAYOUT
+    dev = torch.cuda.current_device()
+    tick = torch.zeros(1, device=f"cuda:{dev}")
+    main = torch.cuda.default_stream()   # where a step is launched from (the first call comes from inside a trainer's warm-up stream)
+    cands = [torch.cuda.Stream() for _ in range(12)]
+    groups = [[main]]   # group 0 = the queue of the device's default stream
+    for c in cands:
+        for g in groups:
+            if _streams_share_queue(g[0], c, tick):
+                g.append(c)
+                break
+        else:
+            groups.append([c])
+    torch.cuda.synchronize()
+    others = [g for g in groups[1:] if g]
+    if not others:   # one queue for everything (GPU_MAX_HW_QUEUES=1): nothing to choose
+        _LAYOUT = {"chain": cands[0], "sides": cands[1 : 1 + nsides], "groups": groups}
+        return _LAYOUT
+    chain = others[0][0]
+    # side queues: the ones neither the chain nor the caller uses.  Measured (profiles/round6/queue_placement.log): two side streams
+    # on each of the two remaining queues 42.5 ms (cfg3) / 108.7 (cfg5) whatever ran in the process before; one of the four on the
+    # caller's queue as well 45.9 / 115.7; three streams on three queues 43.6 / 110.1; unplaced 43.0 / 107.9 in a fresh process and
+    # 48.5 / 124.0 after a cfg2 trainer.  NLAM_QUEUE_SIDES="a,b,c": a, b streams on those queues, c on the caller's.
+    mine = [c for c in groups[0] if c is not main]
+    side_groups = [g for g in others[1:] if g]
+    if not side_groups:   # two queues in all: the side work shares the caller's
+        side_groups = [mine] if mine else [others[0][1:] or [cands[-1]]]
+    per_queue = [int(x) for x in QUEUE_SIDES.split(",")] if QUEUE_SIDES and QUEUE_SIDES != "0" else None
+    sides = []
+    if per_queue is not None:
+        for g, n in zip([*others[1:], mine], per_queue):
+            sides += g[:n]
+    else:
+        # neighbours in the list (= the side streams of MLPs whose backward passes follow each other) on the SAME queue: 42.0 against
+        # 42.9 ms at cfg3 for the interleaved order
+        per = -(-nsides // len(side_groups))
+        for g in side_groups:
+            sides += g[: min(per, nsides - len(sides))]
+    if not sides:
+        sides = [cands[-1]]
+    _LAYOUT = {"chain": chain, "sides": sides, "groups": groups}
+    return _LAYOUT
+
+
 class _WgradOverlap:
     """Weight-gradient kernels on a second HIP stream.
 
@@ -265,7 +350,7 @@ class _WgradOverlap:
         it into graphs of its own, replayed beside the chain's (DESIGN.md finding 39)."""
         if not self.streams:
             # (CU-masked side streams -- hipExtStreamCreateWithCUMask -- were measured in round 6 and lose: DESIGN.md finding 47)
-            self.streams = [torch.cuda.Stream() for _ in range(max(1, self.NSTREAMS))]
+            self.streams = list(stream_layout()["sides"]) if QUEUE_SIDES != "0" else [torch.cuda.Stream() for _ in range(max(1, self.NSTREAMS))]
         self.active = True
         self.assigned = {}
         self.keep = []
@@ -930,7 +1015,7 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
 
     def is_direct(param, shape):
         return (
-            DIRECT_PARAM_GRADS and param is not None and param.grad is not None and param.grad.is_contiguous()
+            DIRECT_PARAM_GRADS and param is not None and param.is_leaf and param.grad is not None and param.grad.is_contiguous()
             and tuple(param.grad.shape) == tuple(shape) and param.grad.dtype == torch.float32
         )
 

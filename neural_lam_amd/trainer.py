@@ -619,7 +619,11 @@ class Trainer:
         if self._chain_stream is None:
             # normal priority: a HIGH-priority chain stream does get a hardware queue of its own, but the queue priority starves
             # and context-switches the side queues instead of sharing the chip with them: 4.0-4.9 ms per cfg2 step against 1.94
-            self._chain_stream = torch.cuda.Stream(priority=int(os.environ.get("NLAM_CHAIN_PRIO", "0")))
+            # a stream bound to a hardware queue that no weight-gradient side stream uses (ops.stream_layout: observed, once per process)
+            from . import ops
+
+            prio = int(os.environ.get("NLAM_CHAIN_PRIO", "0"))
+            self._chain_stream = ops.stream_layout()["chain"] if (prio == 0 and ops.QUEUE_SIDES != "0") else torch.cuda.Stream(priority=prio)
             self._entry_event, self._exit_event = torch.cuda.Event(), torch.cuda.Event()
         cs = self._chain_stream
         seg = _SegmentedStep(self, self.forks_per_segment)

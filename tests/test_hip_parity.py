@@ -1719,3 +1719,34 @@ def test_gradient_mailbox_equals_autograd_accumulation(dev, d, same, factorised)
         assert rel_err(a.cpu(), b.grad) < TOL
     for a, (k, q) in zip(res[True][1], [kv for r in refs for kv in r.named_parameters()]):
         assert rel_err(a.cpu(), q.grad) < TOL, k
+
+
+def test_stream_layout_gives_the_chain_a_hardware_queue_of_its_own(dev):
+    """ops.stream_layout() (DESIGN finding 54): the streams of a process are bound to a few in-order hardware queues; the layout is found
+    by observation -- a tiny launch behind a spinning kernel finishes late exactly when the two streams share a queue -- and must hand out
+    a chain stream that shares its queue with no side stream and not with the caller's stream, side streams off the caller's queue,
+    and the same objects on every call."""
+    from neural_lam_amd import ops
+
+    L1 = ops.stream_layout()
+    assert ops.stream_layout() is L1
+    if not L1["groups"]:
+        pytest.skip("queue probe switched off (NLAM_QUEUE_PROBE=0)")
+    tick = torch.zeros(1, device=dev)
+    main = torch.cuda.default_stream()
+    ngroups = len([g for g in L1["groups"] if g])
+    assert sum(len(g) for g in L1["groups"]) == 13
+    if ngroups >= 2:
+        assert not ops._streams_share_queue(main, L1["chain"], tick)
+    if ngroups >= 3:
+        for s in L1["sides"]:
+            assert not ops._streams_share_queue(L1["chain"], s, tick)
+            assert not ops._streams_share_queue(main, s, tick)
+    # the grouping is an equivalence: members of one group share, representatives of different groups do not
+    reps = [g[0] for g in L1["groups"] if g]
+    for i, a in enumerate(reps):
+        for b in reps[i + 1 :]:
+            assert not ops._streams_share_queue(a, b, tick)
+    for g in L1["groups"]:
+        if len(g) > 1:
+            assert ops._streams_share_queue(g[0], g[-1], tick)
