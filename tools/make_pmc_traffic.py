@@ -37,10 +37,10 @@ STEP = {
 # prefix -> (kind, k, n); the two weight gradients of an edge MLP share one launch key (m = n = d): their mean
 WIDE = {
     512: {"mlp_fwd_edge_kernel<1, 512": ("mlp_fwd", 1536, 512), "mlp_fwd_wbf_kernel<1,": ("mlp_fwd", 1536, 512),
-          "mlp_bwd_edge_kernel<512": ("mlp_bwd", 1536, 512), "mlp_bwd_wbf_kernel<1,": ("mlp_bwd", 1536, 512),
+          "mlp_bwd_edge_kernel<1, 512": ("mlp_bwd", 1536, 512), "mlp_bwd_wbf_kernel<1,": ("mlp_bwd", 1536, 512),
           "wgrad_ldma_kernel<1, true": ("wgrad", 512, 512)},
     256: {"mlp_fwd_edge_kernel<3, 256": ("mlp_fwd", 768, 256), "mlp_fwd_wbf_kernel<3,": ("mlp_fwd", 768, 256),
-          "mlp_bwd_wbf_kernel<3,": ("mlp_bwd", 768, 256), "wgrad_wbf_kernel<3,": ("wgrad", 256, 256), "wgrad_ldma_kernel<3,": ("wgrad", 256, 256)},
+          "mlp_bwd_edge_kernel<3, 256": ("mlp_bwd", 768, 256), "mlp_bwd_wbf_kernel<3,": ("mlp_bwd", 768, 256), "wgrad_wbf_kernel<3,": ("wgrad", 256, 256), "wgrad_ldma_kernel<3,": ("wgrad", 256, 256)},
 }
 for arg in sys.argv[1:]:
     parts = arg.split(":")
