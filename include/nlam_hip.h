@@ -106,6 +106,11 @@ extern "C" {
  * only (nlam_mlp_bwd_family == 2): NLAM_EUNSUP elsewhere. */
 #define NLAM_F_ACC_DSRC0  (1u << 12)
 #define NLAM_F_S_BF16     (1u << 11)
+/* NLAM_F_WGRAD_SOLO (nlam_wgrad / nlam_wgrad_nparts, round 6): the launch has the chip to itself -- every launch of the step on one
+ * stream, the reference's drop-in path launched from Python -- so its row slices are chosen for ISOLATED speed: up to one
+ * workgroup per CU and at least 64 slices (the rounds 2-5 shape).  Without it a big split-bf16 gradient takes at most
+ * NLAM_TUNE_WGRAD_MAX_WGS workgroups: it is sized to run beside the data-gradient chain (DESIGN.md finding 53). */
+#define NLAM_F_WGRAD_SOLO (1u << 13)
 /* matrix path of the GEMMs (bits 8-9): 0 = v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains);
  * n = 1..3: operands split into n bf16 terms on the bf16 matrix cores, fp32 accumulate
  * (1 = plain bf16 operands, 2 = ~2^-16 product error, 3 = fp32-class ~2^-24).  Shapes the

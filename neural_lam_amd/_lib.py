@@ -21,6 +21,7 @@ NLAM_MAX_GROUP = 8
 F_ADD_SRC0, F_ADD_SRC1, F_MEAN, F_SILU_B, F_PRE_ADD, F_LEAF_WGRAD, F_WPACK_READY, F_NO_ACT = 1, 2, 4, 8, 16, 32, 64, 128
 F_STORE_BF16, F_A_BF16, F_S_BF16 = 1 << 10, 1 << 10, 1 << 11
 F_ACC_DSRC0 = 1 << 12
+F_WGRAD_SOLO = 1 << 13
 TUNE_WBF_MIN_SUPERTILES = 1   # nlam_set_tuning keys (include/nlam_hip.h)
 TUNE_WGRAD_CHUNKS = 2
 TUNE_LIN_WGS = 3

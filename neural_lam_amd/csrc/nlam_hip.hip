@@ -4761,8 +4761,9 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
     // 64 workgroups, not 64 slices: cfg5 112.2 -> 109.7 ms (its isolated launch 25.6 -> 34.8 us: the step gains what the partial
     // traffic cost its neighbours), cfg3 (one window: 64 slices as before) unchanged
     int minp_cfg = p->m > 128 ? nlam_detail::wgrad_min_parts_wide : nlam_detail::wgrad_min_parts;
+    const bool solo = (p->flags & NLAM_F_WGRAD_SOLO) != 0;   // nothing runs beside it: slices for isolated speed
     if (minp_cfg < 0) {
-        const int win = wgrad_is_wide(p) ? wgrad_windows_of(p, 256, 256) : 1;
+        const int win = wgrad_is_wide(p) && !solo ? wgrad_windows_of(p, 256, 256) : 1;
         minp_cfg = (64 + win - 1) / (win < 1 ? 1 : win);
     }
     const long minp = minp_cfg < 1 ? 1 : minp_cfg;
@@ -4775,7 +4776,7 @@ int32_t nlam_wgrad_nparts(const nlam_wgrad_t* p) {
         // then (profiles/round6/ab_wgrad_chunks.log, ab_wgrad_max_wgs.log): a 512 x 512 gradient over 57 616 rows in 29 slices x 4
         // windows instead of 64 x 4 -- half the partial sums, half the CUs taken from the chain -- cfg5 109.9 -> 108.1 ms; a
         // 256 x 256 one (one window) is indifferent between 113 and 226 slices and loses 3-5 % below 60
-        if (wgrad_wbf_ns(p) > 0 && wgrad_wbf_big(p)) cap = nlam_detail::wgrad_max_wgs / wgrad_windows_of(p, 256, 256);
+        if (wgrad_wbf_ns(p) > 0 && wgrad_wbf_big(p)) cap = (solo ? kNumCUs : nlam_detail::wgrad_max_wgs) / wgrad_windows_of(p, 256, 256);
         if (cap < 4) cap = 4;
     }
     if (np > cap) np = cap;

@@ -326,6 +326,11 @@ def stream_layout(nsides=None):
     return _LAYOUT
 
 
+def _wgrad_solo() -> int:
+    """NLAM_F_WGRAD_SOLO for a weight gradient launched while no side streams are in use: nothing runs beside it."""
+    return 0 if OVERLAP.active else L.F_WGRAD_SOLO
+
+
 class _WgradOverlap:
     """Weight-gradient kernels on a second HIP stream.
 
@@ -1098,7 +1103,7 @@ def _fused_mlp_backward(ctx, g_out, g_aggr, needs):
     # ---- weight gradients: TN GEMMs with a deterministic two-stage reduction ----
     def wgrad(A, m, src_list, n, flags):
         q = L.Wgrad()
-        q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(src_list), flags | ctx.mm_flags, n
+        q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(A), m, B, rows, len(src_list), flags | ctx.mm_flags | _wgrad_solo(), n
         for k, (t, bstride, w, idx) in enumerate(src_list):
             _fill_src(q.src[k], t, bstride, w, idx)
         nparts = lib.nlam_wgrad_nparts(C.byref(q))
@@ -2115,7 +2120,7 @@ def _node_linear_wgrad(prm, g_cols, x2d, mm):
         keep = []
         for g2d, col0 in g_cols:
             q = L.Wgrad()
-            q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(g2d), hid, 1, rows, 1, mm, k
+            q.A, q.m, q.batch, q.rows, q.nsrc, q.flags, q.n = _ptr(g2d), hid, 1, rows, 1, mm | _wgrad_solo(), k
             _fill_src(q.src[0], x2d, 0, k, None)
             nparts = lib.nlam_wgrad_nparts(C.byref(q))
             partials = torch.empty((nparts, hid, k), device=dev, dtype=torch.float32)
