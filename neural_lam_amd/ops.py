@@ -284,18 +284,25 @@ def stream_layout(nsides=None):
         _LAYOUT = {"chain": torch.cuda.Stream(), "sides": [torch.cuda.Stream() for _ in range(nsides)], "groups": []}
         return _LAYOUT
     dev = torch.cuda.current_device()
-    tick = torch.zeros(1, device=f"cuda:{dev}")
     main = torch.cuda.default_stream()   # where a step is launched from (the first call comes from inside a trainer's warm-up stream)
     cands = [torch.cuda.Stream() for _ in range(12)]
     groups = [[main]]   # group 0 = the queue of the device's default stream
-    for c in cands:
-        for g in groups:
-            if _streams_share_queue(g[0], c, tick):
-                g.append(c)
-                break
-        else:
-            groups.append([c])
-    torch.cuda.synchronize()
+    try:
+        tick = torch.zeros(1, device=f"cuda:{dev}")
+        for c in cands:
+            for g in groups:
+                if _streams_share_queue(g[0], c, tick):
+                    g.append(c)
+                    break
+            else:
+                groups.append([c])
+        torch.cuda.synchronize()
+    except (AttributeError, RuntimeError) as exc:   # no spin kernel in this torch build, ...: unplaced streams, said once
+        import warnings
+
+        warnings.warn(f"hardware-queue probe failed ({exc!r}); the trainer's streams are not placed")
+        _LAYOUT = {"chain": cands[0], "sides": cands[1 : 1 + nsides], "groups": []}
+        return _LAYOUT
     others = [g for g in groups[1:] if g]
     if not others:   # one queue for everything (GPU_MAX_HW_QUEUES=1): nothing to choose
         _LAYOUT = {"chain": cands[0], "sides": cands[1 : 1 + nsides], "groups": groups}
@@ -326,9 +333,16 @@ def stream_layout(nsides=None):
     return _LAYOUT
 
 
+WGRAD_SOLO_MODE = os.environ.get("NLAM_WGRAD_SOLO", "auto")   # "auto" | "0" (always the co-running shape) | "1" (always the solo shape)
+
+
 def _wgrad_solo() -> int:
-    """NLAM_F_WGRAD_SOLO for a weight gradient launched while no side streams are in use: nothing runs beside it."""
-    return 0 if OVERLAP.active else L.F_WGRAD_SOLO
+    """NLAM_F_WGRAD_SOLO for a weight gradient launched while no side streams are in use: nothing runs beside it.  Not while
+    bench.py's roofline pass brackets launches with events (PROFILE: it times the shapes of the trainer's step, one by one) and
+    not under WGRAD_SOLO_MODE "0" (tools/kernel_bench.py, the PMC passes: the same)."""
+    if WGRAD_SOLO_MODE != "auto":
+        return L.F_WGRAD_SOLO if WGRAD_SOLO_MODE == "1" else 0
+    return 0 if (OVERLAP.active or PROFILE.enabled) else L.F_WGRAD_SOLO
 
 
 class _WgradOverlap:
