@@ -289,9 +289,11 @@ int32_t nlam_max_width(void);
 #define NLAM_TUNE_WBF_V4 8
 /*   NLAM_TUNE_WGRAD_LDMA (round 6): one-term weight gradients with 256 x 256 windows on wgrad_ldma_kernel (both operands streamed
  *   by LDS-DMA into a 3-stage ring, bf16 operands read with the LDS transpose read): bit 0 = launches with bf16 operands
- *   (NLAM_F_A_BF16), bit 1 = fp32-operand one-term launches, bit 2 = fp32-class (three-term) launches; default 1: with fp32 operands
- *   the kernel measured no faster than the column-per-thread kernel of rounds 1-5 (profiles/round6/wgrad_check.log: three terms
- *   67.9 vs 64.8 us at 57 616 x 256 x 256, bit-identical results), 0 = that kernel everywhere. */
+ *   (NLAM_F_A_BF16), bit 1 = fp32-operand one-term launches, bit 2 = fp32-class (three-term) launches; default 3.  With fp32 operands
+ *   the kernel alone is no faster than the column-per-thread kernel of rounds 1-5 (profiles/round6/wgrad_check.log: one term 112 vs
+ *   98 us without / 84 vs 102 us with the SiLU; three terms 67.9 vs 64.8 us at 57 616 x 256 x 256, bit-identical results); inside the
+ *   step the one-term form gains 1.2 % at cfg5 (profiles/round6/ab_wgrad_ldma_fp32.log), the three-term form nothing.  0 = the
+ *   column-per-thread kernel everywhere. */
 #define NLAM_TUNE_WGRAD_LDMA 9
 /*   NLAM_TUNE_WGRAD_LDMA_VAR: (rows per stage, ring depth) variant of wgrad_ldma_kernel, 0 = default (A/B runs). */
 #define NLAM_TUNE_WGRAD_LDMA_VAR 10

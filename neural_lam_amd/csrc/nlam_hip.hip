@@ -4474,7 +4474,7 @@ int nlam_detail::wbf_edge = 1;
 int nlam_detail::chain_cus = kNumCUs;
 int nlam_detail::wgrad_max_wgs = 128;   // round 6: 256 (one per CU) until then -- see nlam_wgrad_nparts
 int nlam_detail::wgrad_ldma_var = 0;
-int nlam_detail::wgrad_ldma = 1;           // bit 0: bf16-operand launches, bit 1: fp32-operand one-term launches with 256 x 256 windows (NLAM_TUNE_WGRAD_LDMA)
+int nlam_detail::wgrad_ldma = 3;           // bit 0: bf16-operand launches, bit 1: fp32-operand one-term launches with 256 x 256 windows (NLAM_TUNE_WGRAD_LDMA)
 int nlam_detail::wgrad_chunks_per_wg = 8;   // A/B at cfg2 (tools/ab_bench.sh): 2.13 -> 2.06 ms per step against one chunk per workgroup
 #endif
 

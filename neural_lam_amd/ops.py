@@ -256,20 +256,25 @@ QUEUE_PROBE = os.environ.get("NLAM_QUEUE_PROBE", "1") == "1"
 QUEUE_SIDES = os.environ.get("NLAM_QUEUE_SIDES", "")
 
 
-def _streams_share_queue(a, b, tick, spin_cycles=4_000_000):
-    """True when a launch on ``b`` waits for an earlier, long launch on ``a``: the two are bound to one in-order hardware queue."""
-    torch.cuda.synchronize()
-    ea, eb = torch.cuda.Event(), torch.cuda.Event()
-    with torch.cuda.stream(a):
-        torch.cuda._sleep(spin_cycles)   # ~2 ms
-        ea.record()
-    with torch.cuda.stream(b):
-        tick.add_(1)
-        eb.record()
-    eb.synchronize()
-    shared = ea.query()   # the spin was over before the tiny launch finished
-    ea.synchronize()
-    return bool(shared)
+def _streams_share_queue(a, b, tick, spin_cycles=6_000_000, attempts=3):
+    """True when a launch on ``b`` waits for an earlier, long launch on ``a``: the two are bound to one in-order hardware queue.
+    "The tiny launch finished while the spin was still running" cannot be observed by accident; "it finished after the spin" can
+    (a host thread descheduled for 2 ms between the two launches): only ``attempts`` such observations in a row count as sharing."""
+    for _ in range(attempts):
+        torch.cuda.synchronize()
+        ea, eb = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(spin_cycles)   # ~2.5 ms
+            ea.record()
+        with torch.cuda.stream(b):
+            tick.add_(1)
+            eb.record()
+        eb.synchronize()
+        shared = ea.query()   # the spin was over before the tiny launch finished
+        ea.synchronize()
+        if not shared:
+            return False
+    return True
 
 
 def stream_layout(nsides=None):

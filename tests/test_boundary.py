@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, 192) == 0
     assert lib.nlam_set_tuning(L.TUNE_WBF_MIN_SUPERTILES, -1) == -1 and lib.nlam_set_tuning(99, 1) == -1
     assert lib.nlam_set_tuning(L.TUNE_WBF_HALF, 8) == -1 and lib.nlam_set_tuning(L.TUNE_WBF_HALF, 1) == 0
-    assert lib.nlam_set_tuning(L.TUNE_WGRAD_LDMA, 8) == -1 and lib.nlam_set_tuning(L.TUNE_WGRAD_LDMA, 1) == 0
+    assert lib.nlam_set_tuning(L.TUNE_WGRAD_LDMA, 8) == -1 and lib.nlam_set_tuning(L.TUNE_WGRAD_LDMA, 3) == 0   # (3 = the default: the setting is process-wide)
     assert lib.nlam_set_tuning(L.TUNE_WGRAD_LDMA_VAR, 4) == -1 and lib.nlam_set_tuning(L.TUNE_WGRAD_LDMA_VAR, 0) == 0
     assert lib.nlam_set_tuning(L.TUNE_WBF_EDGE, 4) == -1 and lib.nlam_set_tuning(L.TUNE_WBF_EDGE, 1) == 0
     assert lib.nlam_set_tuning(L.TUNE_WGRAD_MAX_WGS, 3) == -1 and lib.nlam_set_tuning(L.TUNE_WGRAD_MAX_WGS, 128) == 0
