@@ -252,7 +252,17 @@ def test_launch_shape_queries():
     for k in range(3):
         q.src[k].width = 256
     assert lib.nlam_wgrad_nparts(C.byref(q)) == 128 // 3      # split-bf16: three 256 x 256 windows, at most 128 workgroups (NLAM_TUNE_WGRAD_MAX_WGS)
-    q.flags = 0
+    q.flags = (3 << 8) | L.F_WGRAD_SOLO
+    assert lib.nlam_wgrad_nparts(C.byref(q)) == 256 // 3      # ... and one per CU when the launch has the chip to itself (NLAM_F_WGRAD_SOLO)
+    # small wide problems: the slice floor is 64 WORKGROUPS (row slices x 256 x 256 windows), 64 slices for a solo launch
+    q.m, q.n, q.rows, q.nsrc, q.flags = 512, 512, 6561, 1, 1 << 8
+    q.src[0].width = 512
+    assert lib.nlam_wgrad_nparts(C.byref(q)) == 26            # ceil(206 chunks / 8) >= 64 / 4 windows
+    q.flags = (1 << 8) | L.F_WGRAD_SOLO
+    assert lib.nlam_wgrad_nparts(C.byref(q)) == 64
+    q.m, q.n, q.rows, q.nsrc, q.flags = 256, 768, 255136, 3, 0
+    for k in range(3):
+        q.src[k].width = 256
     assert lib.nlam_wgrad_nparts(C.byref(q)) == 1024 // 12    # fp32: twelve 128 x 128 windows
 
 
@@ -388,6 +398,7 @@ def test_argument_errors_are_reported_before_any_launch():
     assert lib.nlam_affine_mix(None, None, None, None, None, None, None, None, 1, 1, 1, None) == EINVAL
     assert lib.nlam_segment_sum(None, 0, None, None, None, None, 1, 1, 1, None) == EINVAL
     assert lib.nlam_segment_sum_acc(None, 0, None, None, None, None, 1, 1, 1, None) == EINVAL
+    assert lib.nlam_segment_sum_add(None, 0, None, None, None, None, None, 1, 1, 1, None) == EINVAL   # (no `extra`: that is nlam_segment_sum_acc)
 
 
 def test_pack_and_layout_queries_are_host_logic():
