@@ -249,7 +249,7 @@ def early_backward_leaf(out, force: bool = False):
 # chain + two side streams on one queue, one queue idle).  The binding cannot be queried, but it can be OBSERVED: a tiny launch on
 # stream b behind a spinning kernel on stream a finishes late exactly when the two share a queue.  stream_layout() does that once per
 # process over a handful of pool streams and hands out a chain stream with a queue to itself and side streams spread over the others.
-_LAYOUT = None
+_LAYOUTS = {}   # device index -> layout
 QUEUE_PROBE = os.environ.get("NLAM_QUEUE_PROBE", "1") == "1"
 # side streams per hardware queue the chain does not use, in the order of the groups found; "0" = do not place anything (round-5
 # behaviour: the next pool streams, wherever they land)
@@ -278,16 +278,22 @@ def _streams_share_queue(a, b, tick, spin_cycles=6_000_000, attempts=3):
 
 
 def stream_layout(nsides=None):
-    """-> {"chain": stream, "sides": [streams], "groups": [[streams of one hardware queue], ..]} -- process-wide, built once."""
-    global _LAYOUT
-    if _LAYOUT is not None:
-        return _LAYOUT
+    """-> {"chain": stream, "sides": [streams], "groups": [[streams of one hardware queue], ..]} -- per device, built once per process."""
+    dev = torch.cuda.current_device()
+    if dev in _LAYOUTS:
+        return _LAYOUTS[dev]
+    lay = _stream_layout_build(nsides)
+    if lay.pop("cache", True):
+        _LAYOUTS[dev] = lay
+    return lay
+
+
+def _stream_layout_build(nsides):
     nsides = max(1, _WgradOverlap.NSTREAMS if nsides is None else nsides)
     if not QUEUE_PROBE or torch.cuda.is_current_stream_capturing():
-        if torch.cuda.is_current_stream_capturing():   # never probe inside a capture; do not cache either
-            return {"chain": torch.cuda.Stream(), "sides": [torch.cuda.Stream() for _ in range(nsides)], "groups": []}
-        _LAYOUT = {"chain": torch.cuda.Stream(), "sides": [torch.cuda.Stream() for _ in range(nsides)], "groups": []}
-        return _LAYOUT
+        # never probe inside a capture; do not cache what was handed out there either
+        return {"chain": torch.cuda.Stream(), "sides": [torch.cuda.Stream() for _ in range(nsides)], "groups": [],
+                "cache": not torch.cuda.is_current_stream_capturing()}
     dev = torch.cuda.current_device()
     main = torch.cuda.default_stream()   # where a step is launched from (the first call comes from inside a trainer's warm-up stream)
     cands = [torch.cuda.Stream() for _ in range(12)]
@@ -306,12 +312,10 @@ def stream_layout(nsides=None):
         import warnings
 
         warnings.warn(f"hardware-queue probe failed ({exc!r}); the trainer's streams are not placed")
-        _LAYOUT = {"chain": cands[0], "sides": cands[1 : 1 + nsides], "groups": []}
-        return _LAYOUT
+        return {"chain": cands[0], "sides": cands[1 : 1 + nsides], "groups": []}
     others = [g for g in groups[1:] if g]
     if not others:   # one queue for everything (GPU_MAX_HW_QUEUES=1): nothing to choose
-        _LAYOUT = {"chain": cands[0], "sides": cands[1 : 1 + nsides], "groups": groups}
-        return _LAYOUT
+        return {"chain": cands[0], "sides": cands[1 : 1 + nsides], "groups": groups}
     chain = others[0][0]
     # side queues: the ones neither the chain nor the caller uses.  Measured (profiles/round6/queue_placement.log): two side streams
     # on each of the two remaining queues 42.5 ms (cfg3) / 108.7 (cfg5) whatever ran in the process before; one of the four on the
@@ -334,8 +338,7 @@ def stream_layout(nsides=None):
             sides += g[: min(per, nsides - len(sides))]
     if not sides:
         sides = [cands[-1]]
-    _LAYOUT = {"chain": chain, "sides": sides, "groups": groups}
-    return _LAYOUT
+    return {"chain": chain, "sides": sides, "groups": groups}
 
 
 WGRAD_SOLO_MODE = os.environ.get("NLAM_WGRAD_SOLO", "auto")   # "auto" | "0" (always the co-running shape) | "1" (always the solo shape)
