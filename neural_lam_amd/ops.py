@@ -344,6 +344,21 @@ def _stream_layout_build(nsides):
 WGRAD_SOLO_MODE = os.environ.get("NLAM_WGRAD_SOLO", "auto")   # "auto" | "0" (always the co-running shape) | "1" (always the solo shape)
 
 
+@contextlib.contextmanager
+def wgrad_shape(mode: str):
+    """Pin the weight-gradient launch shape ("0" co-running, "1" solo) for the launches recorded inside, unless NLAM_WGRAD_SOLO already
+    pins it.  trainer.graphed_training_step records its backward with the SOLO shape: the eager module it stands in for launches
+    that shape, and the row-slice count decides the summation order of a weight gradient -- the two stay bit-identical."""
+    global WGRAD_SOLO_MODE
+    prev = WGRAD_SOLO_MODE
+    if prev == "auto":
+        WGRAD_SOLO_MODE = mode
+    try:
+        yield
+    finally:
+        WGRAD_SOLO_MODE = prev
+
+
 def _wgrad_solo() -> int:
     """NLAM_F_WGRAD_SOLO for a weight gradient launched while no side streams are in use: nothing runs beside it.  Not while
     bench.py's roofline pass brackets launches with events (PROFILE: it times the shapes of the trainer's step, one by one) and

@@ -925,6 +925,8 @@ class _GraphedStep:
         def backward(outs, gouts, direct=False):
             live = [(o, g) for o, g in zip(outs, gouts) if g is not None]
             prev, ops.PACKER = ops.PACKER, self.packer
+            shape = ops.wgrad_shape("1")   # the eager module's weight-gradient launch shape: same row slices, same sums, bit for bit
+            shape.__enter__()
             try:
                 if not direct:
                     return torch.autograd.grad(tuple(o for o, _ in live), surface, grad_outputs=tuple(g for _, g in live),
@@ -957,6 +959,7 @@ class _GraphedStep:
                         got[k] = v if got[k] is None else v + got[k]
                 return tuple(got)
             finally:
+                shape.__exit__(None, None, None)
                 ops.PACKER = prev
 
         side = torch.cuda.Stream()

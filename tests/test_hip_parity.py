@@ -1597,6 +1597,10 @@ def test_optimizer_schedule_does_not_rerecord_the_step(dev, tmp_path, executor):
     ("graph_lam", dict(hidden_dim=128, processor_layers=1), False),
     ("graph_lam", dict(hidden_dim=128, processor_layers=1), True),
     ("hi_lam", dict(hidden_dim=16, processor_layers=2), False),
+    # d = 512: four 256 x 256 windows per weight gradient -- the row-slice count of a launch sized to co-run (side streams in use)
+    # differs from the eager module's; the captured backward must record the eager shape (ops.wgrad_shape) to stay bit-identical
+    ("graph_lam", dict(hidden_dim=512, processor_layers=1), False),
+    ("graph_lam", dict(hidden_dim=512, processor_layers=1), True),
 ])
 @pytest.mark.parametrize("overlap", [True, False])
 def test_graphed_training_step_equals_eager(dev, tmp_path, model, kw, autocast, overlap):
