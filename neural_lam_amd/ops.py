@@ -338,7 +338,9 @@ def _stream_layout_build(nsides):
             sides += g[: min(per, nsides - len(sides))]
     if not sides:
         sides = [cands[-1]]
-    return {"chain": chain, "sides": sides, "groups": groups}
+    # "comm": where a world > 1 step enqueues its waits for finished buckets -- on the default stream's queue, which carries nothing
+    # between the batch copy and the optimizer: a stream that waits for side-graph events on the chain's (in-order) queue stalls the chain
+    return {"chain": chain, "sides": sides, "groups": groups, "comm": mine[0] if mine else None}
 
 
 WGRAD_SOLO_MODE = os.environ.get("NLAM_WGRAD_SOLO", "auto")   # "auto" | "0" (always the co-running shape) | "1" (always the solo shape)

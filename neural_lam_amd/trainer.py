@@ -790,7 +790,10 @@ class Trainer:
             # the weight-gradient graphs completing the bucket; the chain goes on meanwhile.  RCCL calls stay outside every
             # capture: a communicator fault can never poison a graph.
             if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream()
+                from . import ops
+
+                placed = ops.stream_layout().get("comm") if ops.QUEUE_SIDES != "0" else None
+                self._comm_stream = placed if placed is not None else torch.cuda.Stream()
             comm, bk = self._comm_stream, self.buckets
             bk.handles, bk.launched = [], []
             self.bucket_launch_segments = []
