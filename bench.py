@@ -276,15 +276,18 @@ def lightning_shaped(cfg, device, steps, precision="fp32"):
                    "gradients through autograd; eager = every launch from Python; graphed = trainer.graphed_training_step (forward and backward one "
                    "HIP-graph replay each, weight gradients on side streams inside the backward graph, optimizer unchanged); graphed_fused_adamw = the same with torch.optim.AdamW(fused=True)"}
     amp = lambda: torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16")   # noqa: E731
-    for name in ("eager", "graphed", "graphed_fused_adamw"):
+    out["what"] += ("; graphed_flat = graphed_training_step(..., flat=True): the parameters are views of ONE flat leaf, autograd gets one gradient, "
+                    "torch.optim.AdamW([step.flat_parameter]) (the same element-wise update; one AccumulateGrad instead of ~130)")
+    for name in ("eager", "graphed", "graphed_fused_adamw", "graphed_flat", "graphed_flat_fused_adamw"):
         _, _, _, _, step, batch = build(cfg, device)
         # (the reference constructs torch.optim.AdamW with its defaults, models/module.py:293-304: the multi-tensor "foreach"
         # implementation, ~1 ms of host time per step for ~130 parameter tensors; fused=True is the same optimizer as one kernel)
-        opt = torch.optim.AdamW(step.parameters(), lr=1e-3, betas=(0.9, 0.95), fused=True if name == "graphed_fused_adamw" else None)
         fn = step
         if name != "eager":
             with amp():
-                fn = graphed_training_step(step, *batch)
+                fn = graphed_training_step(step, *batch, flat="flat" in name)
+        opt = torch.optim.AdamW([fn.flat_parameter] if "flat" in name else step.parameters(), lr=1e-3, betas=(0.9, 0.95),
+                                fused=True if name.endswith("fused_adamw") else None)
 
         def one():
             opt.zero_grad(set_to_none=True)
@@ -697,7 +700,7 @@ def main():
     drop_in = None
     if world == 1 and not args.no_lightning_leg:
         drop_in = lightning_shaped(cfg, device, args.steps, args.precision)
-        for k in ("eager", "graphed", "graphed_fused_adamw"):
+        for k in ("eager", "graphed", "graphed_fused_adamw", "graphed_flat", "graphed_flat_fused_adamw"):
             drop_in[f"{k}_vs_value_step"] = drop_in[f"ms_per_step_{k}_torch_adamw"] / ms_per_step
     if world == 1 and args.config == "cfg2" and args.precision == "fp32" and not args.no_also and os.environ.get("NLAM_BENCH_ALSO", "1") == "1":
         # N = 1: the wide BASELINE configurations on the driver's clock too -- configs[2] (d = 256, 8 layers, ar_steps 4, fp32 class)

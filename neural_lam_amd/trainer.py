@@ -884,7 +884,8 @@ class Trainer:
 class _GraphedStep:
     """See ``graphed_training_step``."""
 
-    def __init__(self, module: nn.Module, sample_args, warmup: int = 3, pack_weights: bool = True, overlap_wgrad: bool = True):
+    def __init__(self, module: nn.Module, sample_args, warmup: int = 3, pack_weights: bool = True, overlap_wgrad: bool = True,
+                 flat: bool = False):
         from . import ops
 
         if not all(isinstance(a, torch.Tensor) and a.is_cuda for a in sample_args):
@@ -893,6 +894,12 @@ class _GraphedStep:
         self.params = tuple(p for p in module.parameters() if p.requires_grad)
         if not self.params:
             raise ValueError("module has no trainable parameters")
+        self.flat_parameter = None
+        if flat:
+            if not overlap_wgrad:
+                raise ValueError("graphed_training_step(flat=True) needs overlap_wgrad=True (the fused MLPs write the flat gradient)")
+            if any(p.dtype != torch.float32 or p.device != self.params[0].device for p in self.params):
+                raise ValueError("graphed_training_step(flat=True): every trainable parameter must be fp32 and on one device")
         self.autocast = (torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"))
         self.static_in = [a.detach().clone().requires_grad_(a.requires_grad) for a in sample_args]
         self.sig = [(tuple(a.shape), a.dtype, a.requires_grad) for a in sample_args]
@@ -912,6 +919,16 @@ class _GraphedStep:
             self.gflat = torch.zeros(off, device=self.params[0].device, dtype=torch.float32)
             self.goffs = offs
             self.gviews = [self.gflat[o : o + p.numel()].view(p.shape) for o, p in zip(offs, self.params)]
+            if flat:
+                # ONE leaf for autograd and the optimizer: the module's parameters become views of one flat buffer laid out like
+                # the gradient staging buffer (names, shapes and state_dict unchanged: FlatParams does the same for Trainer), and
+                # the leaf the replay function takes -- and the caller's optimizer steps -- is a Parameter over that storage
+                pflat = torch.zeros(off, device=self.params[0].device, dtype=torch.float32)
+                with torch.no_grad():
+                    for o, p in zip(offs, self.params):
+                        pflat[o : o + p.numel()].copy_(p.data.reshape(-1))
+                        p.data = pflat[o : o + p.numel()].view(p.shape)
+                self.flat_parameter = nn.Parameter(pflat)
 
         import gc
 
@@ -958,7 +975,13 @@ class _GraphedStep:
                     k = self.n_in_grads + i
                     # what the fused MLPs accumulated themselves (+ whatever came back through autograd for this parameter); a
                     # parameter neither of them produced keeps None, as under the eager module (torch AdamW / DDP skip it)
-                    if ok and id(p) in touched:
+                    if self.flat_parameter is not None:
+                        # flat mode: whatever autograd delivered for a parameter is added onto its slice of the staging buffer
+                        # (captured); the buffer as a whole is the gradient of the flat leaf
+                        if got[k] is not None:
+                            v.add_(got[k])
+                        got[k] = None
+                    elif ok and id(p) in touched:
                         got[k] = v if got[k] is None else v + got[k]
                 return tuple(got)
             finally:
@@ -1009,6 +1032,9 @@ class _GraphedStep:
                         elif dst.data_ptr() != g.data_ptr():
                             dst.copy_(g)
                 outer.bwd_graph.replay()
+                if outer.flat_parameter is not None:   # one gradient for one leaf (a copy: AccumulateGrad keeps what it is handed)
+                    it = iter(g.detach().clone() if g is not None else None for g in outer.static_grads[: outer.n_in_grads])
+                    return (*[next(it) if a.requires_grad else None for a in outer.static_in], outer.gflat.clone())
                 if outer.gflat is not None:
                     # the staging buffer is copied once (one launch) and autograd gets views of the COPY: AccumulateGrad keeps
                     # (steals) what it is handed as ``.grad``, and a ``.grad`` that aliased the staging buffer would be added
@@ -1033,12 +1059,40 @@ class _GraphedStep:
         sig = [(tuple(a.shape), a.dtype, a.requires_grad) for a in args]
         ac = (torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"))
         if sig != self.sig or (ac[0] != self.autocast[0]) or (ac[0] and ac[1] != self.autocast[1]):
+            if self.flat_parameter is not None and torch.is_grad_enabled():
+                # the eager module would deliver its gradients to the individual parameters, which the caller's optimizer
+                # (built over ``flat_parameter``) never sees: refuse rather than train on nothing
+                raise ValueError("graphed_training_step(flat=True): batch signature %r differs from the captured %r; under grad mode "
+                                 "only the captured shape / autocast state is accepted" % (sig, self.sig))
             return self.module(*args)   # another batch shape / autocast state: the module itself (eager launches)
-        out = self._fn.apply(*args, *self.params)
+        if self.flat_parameter is not None:
+            out = self._fn.apply(*args, self.flat_parameter)
+        else:
+            out = self._fn.apply(*args, *self.params)
         return out if len(out) > 1 else out[0]
 
 
-def graphed_training_step(module: nn.Module, *sample_args, warmup: int = 3, pack_weights: bool = True, overlap_wgrad: bool = True):
+class FlatStepModule(nn.Module):
+    """A captured step (``graphed_training_step(..., flat=True)``) as an ``nn.Module`` whose ONLY parameter is the flat leaf:
+    what ``torch.nn.parallel.DistributedDataParallel`` wraps (one parameter, one bucket, one hook) and what
+    ``torch.optim.AdamW(m.parameters())`` steps.  ``forward(*batch)`` returns what the captured module returns, or element
+    ``pick`` of it (DDP wants tensors that need the backward: ``pick=1`` = the loss of ``models.ForecasterStep``)."""
+
+    def __init__(self, step: "_GraphedStep", pick=None):
+        super().__init__()
+        if step.flat_parameter is None:
+            raise ValueError("FlatStepModule needs graphed_training_step(..., flat=True)")
+        self.flat = step.flat_parameter
+        self._step = (step,)   # not a registered submodule: the captured module's own parameters are views of ``flat``
+        self.pick = pick
+
+    def forward(self, *batch):
+        out = self._step[0](*batch)
+        return out if self.pick is None else out[self.pick]
+
+
+def graphed_training_step(module: nn.Module, *sample_args, warmup: int = 3, pack_weights: bool = True, overlap_wgrad: bool = True,
+                          flat: bool = False):
     """``module`` (e.g. ``models.ForecasterStep``: batch -> (prediction, loss)) as a callable whose forward AND backward each
     replay one HIP graph -- for a training loop that keeps its own optimizer and gradient handling, i.e. the reference's:
     ``ForecasterModule.training_step`` called by ``pl.Trainer`` (models/module.py:394-417, train_model.py:564-578) returns the
@@ -1056,5 +1110,20 @@ def graphed_training_step(module: nn.Module, *sample_args, warmup: int = 3, pack
     by the first kernels of the forward graph (``pack_weights``), the weight-gradient kernels run on side streams inside the
     backward graph (``overlap_wgrad``), and the capture is thread-local, so a live RCCL watchdog thread does not disturb it.  ~330 launches of 3-150 us per cfg2 step become two graph launches; bench.py reports the step time of
     this path beside the eager one (``lightning_shaped``).  Results are bit-identical to the eager module (test_boundary.py /
-    test_hip_parity.py::test_graphed_training_step_equals_eager)."""
-    return _GraphedStep(module, sample_args, warmup=warmup, pack_weights=pack_weights, overlap_wgrad=overlap_wgrad)
+    test_hip_parity.py::test_graphed_training_step_equals_eager).
+
+    ``flat=True``: the host side of the loop above is ~130 ``AccumulateGrad`` nodes, ~130 gradient
+    views built in Python per backward and a multi-tensor optimizer over ~130 tensors -- more than the GPU work of a cfg2 step.
+    With ``flat=True`` the module's parameters are re-homed as views of ONE flat fp32 buffer (names, shapes, ``state_dict``
+    unchanged) and autograd sees a single leaf over that buffer, ``step.flat_parameter``: one ``AccumulateGrad``, one
+    gradient (the staging buffer the fused MLPs reduce into, copied once), and the caller builds its optimizer over that leaf,
+
+        step = graphed_training_step(forecaster_step, *batch, flat=True)
+        opt = torch.optim.AdamW([step.flat_parameter], lr=1e-3, betas=(0.9, 0.95))     # models/module.py:293-304
+
+    AdamW is element-wise and the reference puts every parameter in one group (no per-tensor weight decay exceptions), so the
+    update is the one ``AdamW(module.parameters())`` makes, bit for bit (test_graphed_flat_step_equals_eager); a parameter
+    the step never touches gets a zero gradient instead of ``None`` (it decays; the shipped models have none).  The individual
+    parameters get no ``.grad``: under DDP wrap ``FlatStepModule(step, pick=1)`` (one parameter, one bucket).  Under grad mode
+    only the captured batch shape is accepted (an eager fall-through would train parameters the optimizer does not hold)."""
+    return _GraphedStep(module, sample_args, warmup=warmup, pack_weights=pack_weights, overlap_wgrad=overlap_wgrad, flat=flat)

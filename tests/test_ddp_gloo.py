@@ -287,7 +287,7 @@ def test_graph_capture_with_live_rccl_process_group(tmp_path):
 # ordinary leaf nn.Parameters, a .grad for every parameter each step, AccumulateGrad hooks firing (no direct-gradient
 # mode outside our own Trainer).
 # ---------------------------------------------------------------------------
-def _torch_ddp_worker(rank, world, port, backend, out_dir):
+def _torch_ddp_worker(rank, world, port, backend, out_dir, flat=False):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dev = torch.device("cuda:0")
@@ -315,13 +315,20 @@ def _torch_ddp_worker(rank, world, port, backend, out_dir):
         def forward(self, *batch):
             return self.inner(*batch)[1]
 
-    ddp = torch.nn.parallel.DistributedDataParallel(LossOnly(step), device_ids=None if backend == "gloo" else [0])
-    assert ops.DIRECT_PARAM_GRADS is False
-    opt = torch.optim.AdamW(ddp.parameters(), lr=1e-3, betas=(0.9, 0.95))   # module.py:293-304
     N = ds.num_grid_points
     g = torch.Generator().manual_seed(100 + rank)
     batch = tuple(t.to(dev) for t in (torch.randn(1, 2, N, 5, generator=g), torch.randn(1, 2, N, 5, generator=g),
                                       torch.randn(1, 2, N, 6, generator=g)))
+    if flat:   # graphed_training_step(flat=True): DDP wraps ONE parameter (the flat leaf), one bucket, one hook
+        from neural_lam_amd.trainer import FlatStepModule, graphed_training_step
+
+        wrapped = FlatStepModule(graphed_training_step(step, *batch, flat=True), pick=1)
+        assert len(list(wrapped.parameters())) == 1
+    else:
+        wrapped = LossOnly(step)
+    ddp = torch.nn.parallel.DistributedDataParallel(wrapped, device_ids=None if backend == "gloo" else [0])
+    assert ops.DIRECT_PARAM_GRADS is False
+    opt = torch.optim.AdamW(ddp.parameters(), lr=1e-3, betas=(0.9, 0.95))   # module.py:293-304
     losses = []
     for _ in range(3):
         opt.zero_grad(set_to_none=True)
@@ -338,11 +345,11 @@ def _torch_ddp_worker(rank, world, port, backend, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
-def test_hip_modules_inside_torch_distributed_data_parallel(tmp_path, backend, world):
+@pytest.mark.parametrize("backend,world,flat", [("gloo", 2, False), ("nccl", 1, False), ("gloo", 2, True)])
+def test_hip_modules_inside_torch_distributed_data_parallel(tmp_path, backend, world, flat):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    mp.spawn(_torch_ddp_worker, args=(world, _free_port(), backend, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_torch_ddp_worker, args=(world, _free_port(), backend, str(tmp_path), flat), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "ddp0.pt", weights_only=False)
     assert all(l == l for l in r0["losses"]) and r0["losses"][-1] < r0["losses"][0]
     if world == 2:

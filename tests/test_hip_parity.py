@@ -1661,6 +1661,82 @@ def test_graphed_training_step_equals_eager(dev, tmp_path, model, kw, autocast, 
     assert float(l_e) == float(l_g)
 
 
+@pytest.mark.parametrize("model,kw,autocast,fused", [
+    ("graph_lam", dict(hidden_dim=64, processor_layers=2), False, False),
+    ("graph_lam", dict(hidden_dim=64, processor_layers=2), False, True),
+    ("graph_lam", dict(hidden_dim=128, processor_layers=1), True, False),
+    ("hi_lam", dict(hidden_dim=16, processor_layers=2), False, False),
+])
+def test_graphed_flat_step_equals_eager(dev, tmp_path, model, kw, autocast, fused):
+    """graphed_training_step(flat=True): the module's parameters as views of one flat leaf, ONE gradient handed to autograd, the
+    caller's torch.optim.AdamW built over that leaf (models/module.py:293-304: one parameter group, no per-tensor exceptions, so
+    the element-wise update is the same) -- against the eager module under AdamW(module.parameters()): loss, prediction, the
+    gradient slice of every parameter and the weights after three optimizer steps, bit for bit; names / shapes / state_dict
+    keys unchanged; a batch of another shape is refused under grad mode and falls through to the eager module without it."""
+    import contextlib
+
+    from neural_lam_amd import graph as G
+    from neural_lam_amd import models as hm
+    from neural_lam_amd.datastore import SyntheticDatastore
+    from neural_lam_amd.trainer import FlatStepModule, graphed_training_step
+
+    hier = model != "graph_lam"
+
+    def make():
+        ds = SyntheticDatastore(81 if hier else 30, 30 if hier else 27, 5, 2, 1, root_path=tmp_path, boundary="random", seed=1)
+        ext = ds.get_xy_extent("state")
+        raw = G.create_regular_grid_graph(ds.get_xy("state"), n_max_levels=3 if hier else None, hierarchical=hier)
+        graph = G.normalise_graph(raw, max(ext[1] - ext[0], ext[3] - ext[2]))
+        torch.manual_seed(1)
+        fc = hm.ARForecaster(hm.MODELS[model](ds, graph=graph, **kw), ds)
+        return ds, hm.ForecasterStep(fc, ds).to(dev)
+
+    amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
+    ds, s_e = make()
+    _, s_g = make()
+    keys = list(s_g.state_dict().keys())
+    N = ds.num_grid_points
+    g = torch.Generator().manual_seed(0)
+
+    def batch(T=2):
+        return [torch.randn(1, 2, N, 5, generator=g).to(dev), torch.randn(1, T, N, 5, generator=g).to(dev), torch.randn(1, T, N, 6, generator=g).to(dev)]
+
+    with amp():
+        graphed = graphed_training_step(s_g, *batch(), flat=True)
+    leaf = graphed.flat_parameter
+    assert leaf.is_leaf and leaf.requires_grad and list(s_g.state_dict().keys()) == keys
+    assert [p.shape for p in s_g.parameters()] == [p.shape for p in s_e.parameters()]
+    assert list(FlatStepModule(graphed, pick=1).parameters())[0] is leaf and len(list(FlatStepModule(graphed).parameters())) == 1
+    o_e = torch.optim.AdamW(s_e.parameters(), lr=1e-3, betas=(0.9, 0.95), fused=fused or None)
+    o_g = torch.optim.AdamW([leaf], lr=1e-3, betas=(0.9, 0.95), fused=fused or None)
+    for _ in range(3):
+        b = batch()
+        o_e.zero_grad(set_to_none=True)
+        with amp():
+            pred_e, loss_e = s_e(*b)
+        loss_e.backward()
+        o_g.zero_grad(set_to_none=True)
+        with amp():
+            pred_g, loss_g = graphed(*b)
+        loss_g.backward()
+        assert float(loss_e) == float(loss_g) and torch.equal(pred_e, pred_g)
+        assert all(p.grad is None for p in s_g.parameters())   # ONE AccumulateGrad: the leaf's
+        for p, o in zip(s_e.parameters(), graphed.goffs):
+            assert torch.equal(p.grad.reshape(-1), leaf.grad[o : o + p.numel()])
+        o_e.step()
+        o_g.step()
+        for a, c in zip(s_e.parameters(), s_g.parameters()):
+            assert torch.equal(a, c)
+    b = batch(T=1)   # another rollout length: not the captured shape
+    with pytest.raises(ValueError, match="captured"):
+        with amp():
+            graphed(*b)
+    with torch.no_grad(), amp():
+        _, l_e = s_e(*b)
+        _, l_g = graphed(*b)
+    assert float(l_e) == float(l_g)
+
+
 @pytest.mark.parametrize("d,same,factorised", [(64, True, True), (64, False, True), (128, True, True), (256, False, True),
                                                (64, True, False), (32, True, False)])
 def test_gradient_mailbox_equals_autograd_accumulation(dev, d, same, factorised):
