@@ -77,6 +77,9 @@
                              // reduce_jobs (78) or segment_sum (54) of a side stream to share the CU; at 225 it leaves 48: nothing fits.
                              // 2: 225 VGPRs as well; 3: 213 VGPRs, 1.742-1.747 against 1.726-1.740 ms for 0 on one box.
 #endif
+#ifndef NLAM_LIN_SK
+#define NLAM_LIN_SK 4   // K = 16 steps per chunk of the one-term 64-row-tile nlam_linear GEMM (2: the 32-column chunks of round 5; A/B builds)
+#endif
 #define NLAM_IN_TU(k) (NLAM_TU == 0 || NLAM_TU == (k))
 
 namespace nlam_detail {   // launchers: external linkage, each defined in exactly one slice; arguments are already validated
@@ -3721,8 +3724,12 @@ __host__ __device__ inline PackShape pack_shape(const nlam_pack_job_t& j) {
     r.OB = (j.dout + 31) >> 5;
     const bool pre = (j.flags & NLAM_F_PRE_ADD) != 0;
     r.ngemm = pre ? 1 : j.nsrc;
+    // (fixed trip counts and static indices: a dynamically indexed copy of the job makes the device compiler keep the struct
+    // in LDS and read it back element by element -- mlp_pack_kernel, round 6)
     int nunits = 0;
-    for (int s = 0; s < j.nsrc; ++s) {
+#pragma unroll
+    for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+        if (s >= j.nsrc) continue;
         if (j.width[s] < 1 || j.width[s] > kMaxWidth) return r;
         if (s < r.ngemm) nunits += (j.width[s] + 31) >> 5;
     }
@@ -3730,8 +3737,9 @@ __host__ __device__ inline PackShape pack_shape(const nlam_pack_job_t& j) {
     const int DPH = r.HB * 32, OP = r.OB * 32;
     r.fwd_floats = ((size_t)r.ns * r.HB * r.S1 * 64 + (size_t)r.ns * r.OB * (DPH / 16) * 64) * 4;
     r.bwd_floats = (size_t)r.ns * DPH * OP / 2;
-    for (int s = 0; s < r.ngemm; ++s)
-        if ((j.width[s] & 31) == 0) r.bwd_floats += (size_t)r.ns * j.width[s] * DPH / 2;
+#pragma unroll
+    for (int s = 0; s < NLAM_MAX_SRC; ++s)
+        if (s < r.ngemm && (j.width[s] & 31) == 0) r.bwd_floats += (size_t)r.ns * j.width[s] * DPH / 2;
     r.ok = 1;
     return r;
 }
@@ -3772,12 +3780,17 @@ __device__ __forceinline__ PackItem pack_item_load(int S, int s0, const float* W
             it.x[4 + c] = vb[c];
         }
     } else {
+        float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int k = min((q < 4 ? kA : kB) + (q & 3), K - 1);   // clamped: unconditional loads
-            const float v = W[(long)min(m, M - 1) * ldm + (long)k * ldk];
-            it.x[q] = (m < M && (q < 4 ? kA : kB) + (q & 3) < K) ? v : 0.f;
+            v[q] = W[(long)min(m, M - 1) * ldm + (long)k * ldk];
         }
+        // all eight in flight before the first select: left alone the compiler sinks each load into a branch of its own select
+        // and waits for it there -- eight dependent round trips per item (seen in the ISA; ~10 us of a 13 us one-job launch)
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) it.x[q] = (m < M && (q < 4 ? kA : kB) + (q & 3) < K) ? v[q] : 0.f;
     }
     return it;
 }
@@ -3812,18 +3825,25 @@ __device__ __forceinline__ void pack_item_store(u32x4* dst, const PackItem& it) 
 // grouped per chunk (two K steps), so results agree with linear_bfw_kernel to fp32 rounding, not bit for bit.
 // ---------------------------------------------------------------------------
 constexpr int kLinGemmThreads = 256;
-template <int NS, int WN>
+template <int NS, int WN, int SK = 2>
 __host__ __device__ constexpr size_t lin_gemm_lds_bytes() {
-    return ((size_t)2 * NS * 4 * 2 * 64 + (size_t)2 * NS * (2 * WN) * 2 * 64) * 16 + (size_t)4 * 32 * kStgStride * sizeof(float);
+    return ((size_t)2 * NS * 4 * SK * 64 + (size_t)2 * NS * (2 * WN) * SK * 64) * 16 + (size_t)4 * 32 * kStgStride * sizeof(float);
 }
 
 // TA: the weight operand is read transposed (ldn == 1: the data-gradient product, A[h][c] = W[h + c ldk]: eight dword loads per
 // fragment slot, each coalesced across the 32 features of a block) instead of along K (ldk == 1: two 16-byte loads).
-template <int NS, int WN, bool TA>
+// SK: K = 16 steps per chunk.  2 = 32-column chunks (rounds 5-6).  4 = 64-column chunks (round 6, the one-term mesh-level products:
+// a 6 561-row launch is 412 workgroups whose K loop is a chain of global-memory round trips, one chunk in flight, ~30 ns of MFMA per
+// chunk and wave -- 21 us for k = 512 = 16 chunks; twice the columns per round trip halves the chain and the barriers).
+template <int NS, int WN, bool TA, int SK = 2>
 __global__ __launch_bounds__(kLinGemmThreads) void linear_gemm_kernel(const nlam_linear_t p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WM = 2;                       // feature blocks per wave
-    constexpr int S = 2;                        // K = 16 steps per 32-column chunk
+    constexpr int S = SK;                       // K = 16 steps per chunk of 16 S columns
+    constexpr int SPR = 2 * S;                  // fragment slots (8 K values) per tile row and chunk
+    constexpr int RP = kLinGemmThreads / SPR;   // tile rows per row-major staging pass
+    constexpr int QA = S, QB = WN * S / 2;      // staging passes per chunk: 128 feature rows / RP (= the transposed staging's count too), 64 WN rows / RP
+    static_assert(SK == 2 || SK == 4, "32- or 64-column chunks");
     constexpr int MBA = 2 * WM, MBB = 2 * WN;   // 32-row fragment blocks of the workgroup's A (features) / B (rows) tile
     constexpr int BN = 32 * MBA, BM = 32 * MBB;
     constexpr size_t kAv = (size_t)NS * MBA * S * 64, kBv = (size_t)NS * MBB * S * 64;   // u32x4 per buffer
@@ -3854,7 +3874,7 @@ __global__ __launch_bounds__(kLinGemmThreads) void linear_gemm_kernel(const nlam
     const int mrows = (int)min((long)BM, p.rows - r0);
     const float* Wp = Wm + (long)(ft * BN) * p.ldn;
     const float* xp = p.x + r0 * p.k;
-    const int KC = p.k >> 5;
+    const int KC = p.k / (16 * S);
 
     // staging.  A fragment slot = 8 consecutive K values (32 bytes) of one tile row; a tile row's 32-column chunk = 4 slots =
     // one 128-byte line.  Rows read along K (x, and the weights in the forward layout): thread -> (row = tid / 4 + 64 q, slot
@@ -3866,66 +3886,66 @@ __global__ __launch_bounds__(kLinGemmThreads) void linear_gemm_kernel(const nlam
     // the rotation spreads the four slots of a line, which one wave instruction writes, over all 32 banks (unrotated they are
     // 512 bytes apart: a 4-way conflict), and the MFMA loop's reads stay one contiguous (rotated) 16-slot window per lane group.
     // No branch anywhere: rows past the end of x read the last row and are zeroed by a select.
-    const int ss = tid & 3, srow = tid >> 2;                 // row-major staging: slot (st = ss / 2, hi = ss % 2), row srow + 64 q
-    const int t_st = wave & 1, t_mb = wave >> 1;             // transposed staging: K step, block t_mb + 2 q, slot half hi, feature j
+    const int ss = tid & (SPR - 1), srow = tid / SPR;        // row-major staging: slot (st = ss / 2, hi = ss % 2), row srow + RP q
+    const int t_st = wave % S, t_mb = wave / S;              // transposed staging: K step, block t_mb + (4 / S) q, slot half hi, feature j
     auto frag_index = [&](int mb_, int st_, int hi_, int j_, int MB_) {   // u32x4 index inside one term of one buffer
         return (mb_ * S + st_) * 64 + hi_ * 32 + ((j_ + 2 * (2 * st_ + hi_)) & 31);
     };
-    const float* a_src[WM];
-    const float* b_src[WN];
-    int a_dst[WM], b_dst[WN];
-    bool b_live[WN];
+    const float* a_src[QA];
+    const float* b_src[QB];
+    int a_dst[QA], b_dst[QB];
+    bool b_live[QB];
 #pragma unroll
-    for (int q = 0; q < WM; ++q) {
+    for (int q = 0; q < QA; ++q) {
         if constexpr (TA) {
-            const int m = 32 * (t_mb + 2 * q) + j;
+            const int m = 32 * (t_mb + (4 / S) * q) + j;
             a_src[q] = Wp + m + (long)(16 * t_st + 8 * hi) * p.ldk;
-            a_dst[q] = frag_index(t_mb + 2 * q, t_st, hi, j, MBA);
+            a_dst[q] = frag_index(t_mb + (4 / S) * q, t_st, hi, j, MBA);
         } else {
-            const int m = srow + 64 * q;
+            const int m = srow + RP * q;
             a_src[q] = Wp + (long)m * p.ldn + 8 * ss;
             a_dst[q] = frag_index(m >> 5, ss >> 1, ss & 1, m & 31, MBA);
         }
     }
 #pragma unroll
-    for (int q = 0; q < WN; ++q) {
-        const int r = srow + 64 * q;
+    for (int q = 0; q < QB; ++q) {
+        const int r = srow + RP * q;
         b_live[q] = r < mrows;
         b_src[q] = xp + (long)min(r, mrows - 1) * p.k + 8 * ss;
         b_dst[q] = frag_index(r >> 5, ss >> 1, ss & 1, r & 31, MBB);
     }
-    float ia[WM][8], ib[WN][8];
+    float ia[QA][8], ib[QB][8];
     auto request = [&](int kc) {
 #pragma unroll
-        for (int q = 0; q < WM; ++q) {
+        for (int q = 0; q < QA; ++q) {
             if constexpr (TA) {
-                const float* src = a_src[q] + (long)(32 * kc) * p.ldk;
+                const float* src = a_src[q] + (long)(16 * S * kc) * p.ldk;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ia[q][e] = src[(long)e * p.ldk];
             } else {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(a_src[q] + 32 * kc);
-                const f32x4 up = *reinterpret_cast<const f32x4*>(a_src[q] + 32 * kc + 4);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(a_src[q] + 16 * S * kc);
+                const f32x4 up = *reinterpret_cast<const f32x4*>(a_src[q] + 16 * S * kc + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ia[q][e] = lo[e], ia[q][4 + e] = up[e];
             }
         }
 #pragma unroll
-        for (int q = 0; q < WN; ++q) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(b_src[q] + 32 * kc);
-            const f32x4 up = *reinterpret_cast<const f32x4*>(b_src[q] + 32 * kc + 4);
+        for (int q = 0; q < QB; ++q) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(b_src[q] + 16 * S * kc);
+            const f32x4 up = *reinterpret_cast<const f32x4*>(b_src[q] + 16 * S * kc + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) ib[q][e] = lo[e], ib[q][4 + e] = up[e];
         }
     };
     auto publish = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < WM; ++q) {
+        for (int q = 0; q < QA; ++q) {
             const BfFrag<NS> f = split8<NS>(ia[q]);
 #pragma unroll
             for (int t = 0; t < NS; ++t) As[(size_t)buf * kAv + (size_t)t * MBA * S * 64 + a_dst[q]] = f.t[t];
         }
 #pragma unroll
-        for (int q = 0; q < WN; ++q) {
+        for (int q = 0; q < QB; ++q) {
             float x[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = b_live[q] ? ib[q][e] : 0.f;
@@ -4001,64 +4021,87 @@ __global__ __launch_bounds__(kLinGemmThreads) void linear_gemm_kernel(const nlam
     }
 }
 
-// thread `tid` of the job's grid takes lane item `tid` of every piece (<= 512 items each; nlam_mlp_pack launches 512 threads per job, as eight single-wave workgroups)
-template <int NS>
-__device__ void pack_job(const nlam_pack_job_t& j, const PackShape& sh, int tid, int nthr) {
+// One PIECE of a job per workgroup column (blockIdx.z: the W1 piece of each source and W2 in the forward layout, W2^T and the W1^T
+// piece of each source in the backward layout), one lane item per thread, ONE call site of pack_item_load.  Rounds 3-6 gave a
+// thread lane item `tid` of EVERY piece of its job, all loads before the first store: 31 KB of straight-line code of which a wave
+// executes ~10 KB exactly once -- the launch runs once per optimizer step on a cold instruction cache and took 32 us at the head
+// of every cfg2 step (profiles/round6/cfg2_step_timeline.txt) for ~3 us of memory round trips.  A thread still has its load in
+// flight before its store (finding 22), and eight times as many waves share the latency.
+constexpr int kPackPieces = 2 * NLAM_MAX_SRC + 2;
+
+__device__ __forceinline__ void pack_piece(const nlam_pack_job_t& j, const PackShape& sh, int piece, int idx) {
     const int DPH = sh.HB * 32, OP = sh.OB * 32;
+    int wd[NLAM_MAX_SRC];   // widths of the sources that have a GEMM piece (0 past them); static indices only (see pack_shape)
     int kin = 0;
-    for (int s = 0; s < sh.ngemm; ++s) kin += j.width[s];
-    const int ldw1 = j.ldw1 > 0 ? j.ldw1 : kin;
-    const bool fwd = j.fwd_image != nullptr, bwd = j.bwd_image != nullptr;
-    u32x4* W1s = reinterpret_cast<u32x4*>(j.fwd_image);
-    u32x4* W2s = W1s + (size_t)NS * sh.HB * sh.S1 * 64;
-    for (int base = 0; base < 512; base += nthr) {   // a piece has at most 2 blocks x 4 steps x 64 lanes = 512 items (widths <= 64)
-        const int idx = base + tid;
-        PackItem f1[NLAM_MAX_SRC], f2, b2, b1[NLAM_MAX_SRC];
-        u32x4* b1dst[NLAM_MAX_SRC];
-        // ---- all loads ----
-        {
-            int s0 = 0, off = 0;
 #pragma unroll
-            for (int s = 0; s < NLAM_MAX_SRC; ++s) {
-                const int w = s < sh.ngemm ? j.width[s] : 0;
-                f1[s] = pack_item_load(sh.S1, s0, j.W1 + off, ldw1, j.hid, sh.HB, w > 0 ? w : 16, false, 1, ((w + 31) >> 5) * 32,
-                                       (fwd && w > 0) ? idx : (1 << 30));
-                off += w;
-                s0 += 2 * ((w + 31) >> 5);
-            }
-            f2 = pack_item_load(DPH / 16, 0, j.W2, j.hid, j.dout, sh.OB, j.hid, true, 1, 0, fwd ? idx : (1 << 30));
-            // backward: A[m = hidden][k = out (slot-permuted)] = W2[k][m];  A[m = source column][k = hidden] = W1[k][off + m]
-            b2 = pack_item_load(OP / 16, 0, j.W2, 1, j.hid, sh.HB, j.dout, true, j.hid, OP, bwd ? idx : (1 << 30));
-            size_t ioff = (size_t)NS * DPH * OP / 2;
-            off = 0;
-#pragma unroll
-            for (int s = 0; s < NLAM_MAX_SRC; ++s) {
-                const int w = s < sh.ngemm ? j.width[s] : 0;
-                const bool on = bwd && w > 0 && (w & 31) == 0;
-                b1dst[s] = reinterpret_cast<u32x4*>(j.bwd_image + ioff);
-                b1[s] = pack_item_load(DPH / 16, 0, j.W1 + off, 1, on ? w : 32, on ? (w >> 5) : 1, j.hid, true, ldw1, 0, on ? idx : (1 << 30));
-                if (on) ioff += (size_t)NS * w * DPH / 2;
-                off += w;
-            }
-        }
-        // ---- all conversions + stores ----
-#pragma unroll
-        for (int s = 0; s < NLAM_MAX_SRC; ++s) pack_item_store<NS>(W1s, f1[s]);
-        pack_item_store<NS>(W2s, f2);
-        pack_item_store<NS>(reinterpret_cast<u32x4*>(j.bwd_image), b2);
-#pragma unroll
-        for (int s = 0; s < NLAM_MAX_SRC; ++s) pack_item_store<NS>(b1dst[s], b1[s]);
+    for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+        wd[s] = s < sh.ngemm ? j.width[s] : 0;
+        kin += wd[s];
     }
+    const int ldw1 = j.ldw1 > 0 ? j.ldw1 : kin;
+    const size_t NSz = (size_t)sh.ns;
+    // arguments of the one pack_item_load / pack_item_store below
+    int S, s0 = 0, M, MB, K, Kpad = 0;
+    long ldm, ldk = 1;
+    bool perm2;
+    const float* W;
+    u32x4* dst;
+    if (piece <= NLAM_MAX_SRC) {   // forward image [W1s | W2s]
+        if (j.fwd_image == nullptr) return;
+        u32x4* W1s = reinterpret_cast<u32x4*>(j.fwd_image);
+        if (piece < NLAM_MAX_SRC) {
+            if (piece >= sh.ngemm) return;
+            int off = 0, w = 0;
+#pragma unroll
+            for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+                if (s < piece) {
+                    off += wd[s];
+                    s0 += 2 * ((wd[s] + 31) >> 5);
+                }
+                if (s == piece) w = wd[s];
+            }
+            S = sh.S1, W = j.W1 + off, ldm = ldw1, M = j.hid, MB = sh.HB, K = w, perm2 = false, Kpad = ((w + 31) >> 5) * 32;
+            dst = W1s;
+        } else {
+            S = DPH / 16, W = j.W2, ldm = j.hid, M = j.dout, MB = sh.OB, K = j.hid, perm2 = true;
+            dst = W1s + NSz * sh.HB * sh.S1 * 64;
+        }
+    } else {   // backward image [W2^T | W1_s^T ..]: A[m = hidden][k = out (slot-permuted)] = W2[k][m];  A[m = source column][k = hidden] = W1[k][off + m]
+        if (j.bwd_image == nullptr) return;
+        const int sb = piece - NLAM_MAX_SRC - 2;
+        if (sb < 0) {
+            S = OP / 16, W = j.W2, ldm = 1, M = j.hid, MB = sh.HB, K = j.dout, perm2 = true, ldk = j.hid, Kpad = OP;
+            dst = reinterpret_cast<u32x4*>(j.bwd_image);
+        } else {
+            if (sb >= sh.ngemm) return;
+            size_t ioff = NSz * DPH * OP / 2;
+            int off = 0, w = 0;
+#pragma unroll
+            for (int s = 0; s < NLAM_MAX_SRC; ++s) {
+                if (s < sb) {
+                    if ((wd[s] & 31) == 0) ioff += NSz * wd[s] * DPH / 2;
+                    off += wd[s];
+                }
+                if (s == sb) w = wd[s];
+            }
+            if ((w & 31) != 0) return;
+            S = DPH / 16, W = j.W1 + off, ldm = 1, M = w, MB = w >> 5, K = j.hid, perm2 = true, ldk = ldw1;
+            dst = reinterpret_cast<u32x4*>(j.bwd_image + ioff);
+        }
+    }
+    const PackItem it = pack_item_load(S, s0, W, ldm, M, MB, K, perm2, ldk, Kpad, idx);
+    if (sh.ns == 3) pack_item_store<3>(dst, it);
+    else if (sh.ns == 2) pack_item_store<2>(dst, it);
+    else pack_item_store<1>(dst, it);
 }
 
 __global__ __launch_bounds__(256) void mlp_pack_kernel(const nlam_pack_job_t* jobs) {
     const nlam_pack_job_t j = jobs[blockIdx.y];
     const PackShape sh = pack_shape(j);
     if (!sh.ok) return;
+    // a piece has at most 2 blocks x 4 steps x 64 lanes = 512 items (widths <= 64): nlam_mlp_pack launches 512 threads per piece
     const int tid = (int)(blockIdx.x * blockDim.x + threadIdx.x), nthr = (int)(gridDim.x * blockDim.x);
-    if (sh.ns == 3) pack_job<3>(j, sh, tid, nthr);
-    else if (sh.ns == 2) pack_job<2>(j, sh, tid, nthr);
-    else pack_job<1>(j, sh, tid, nthr);
+    for (int idx = tid; idx < 512; idx += nthr) pack_piece(j, sh, (int)blockIdx.z, idx);
 }
 
 #include "nlam_wide.inc"
@@ -4583,7 +4626,7 @@ int32_t nlam_mlp_pack(const nlam_pack_job_t* jobs_device, int32_t njobs, void* h
     // blocks takes item t of each piece, all loads in flight before the first store
     // (eight one-wave workgroups per job rather than two of four waves: the ~200 KB of images a job writes then drain through
     // eight CUs' store paths instead of two)
-    hipLaunchKernelGGL(mlp_pack_kernel, dim3(8, njobs), dim3(64), 0, (hipStream_t)hip_stream, jobs_device);
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(8, njobs, kPackPieces), dim3(64), 0, (hipStream_t)hip_stream, jobs_device);
     return (int32_t)hipGetLastError();
 }
 
@@ -5854,17 +5897,17 @@ int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream) {
         const long nftt = (long)(p->n / 128) * (p->W2 != nullptr ? 2 : 1);
         const long nwg = (nrt + 7) / 8 * 8 * nftt;
         if (nwg > 0x7fffffffL) return NLAM_EUNSUP;
-#define NLAM_LAUNCH_LING1(NS_, WN_, TA_)                                                                             \
+#define NLAM_LAUNCH_LING1(NS_, WN_, TA_, SK_)                                                                        \
     do {                                                                                                             \
-        const size_t glds = lin_gemm_lds_bytes<NS_, WN_>();                                                          \
-        int rc = set_lds(linear_gemm_kernel<NS_, WN_, TA_>, glds);                                                   \
+        const size_t glds = lin_gemm_lds_bytes<NS_, WN_, SK_>();                                                     \
+        int rc = set_lds(linear_gemm_kernel<NS_, WN_, TA_, SK_>, glds);                                              \
         if (rc != 0) return rc;                                                                                      \
-        hipLaunchKernelGGL((linear_gemm_kernel<NS_, WN_, TA_>), dim3((unsigned)nwg), dim3(kLinGemmThreads), glds, stream, *p); \
+        hipLaunchKernelGGL((linear_gemm_kernel<NS_, WN_, TA_, SK_>), dim3((unsigned)nwg), dim3(kLinGemmThreads), glds, stream, *p); \
     } while (0)
-#define NLAM_LAUNCH_LING(NS_, WN_)                    \
-    do {                                              \
-        if (ta) NLAM_LAUNCH_LING1(NS_, WN_, true);    \
-        else NLAM_LAUNCH_LING1(NS_, WN_, false);      \
+#define NLAM_LAUNCH_LING(NS_, WN_)                       \
+    do {                                                 \
+        if (ta) NLAM_LAUNCH_LING1(NS_, WN_, true, 2);    \
+        else NLAM_LAUNCH_LING1(NS_, WN_, false, 2);      \
     } while (0)
         if (big) {
             if (ns == 3) NLAM_LAUNCH_LING(3, 2);
@@ -5873,7 +5916,10 @@ int32_t nlam_linear(const nlam_linear_t* p, void* hip_stream) {
         } else {
             if (ns == 3) NLAM_LAUNCH_LING(3, 1);
             else if (ns == 2) NLAM_LAUNCH_LING(2, 1);
-            else NLAM_LAUNCH_LING(1, 1);
+            else if (p->k % 64 == 0 && NLAM_LIN_SK == 4) {   // one term, 64-row tiles: 64-column chunks (66 KB of LDS, two workgroups per CU)
+                if (ta) NLAM_LAUNCH_LING1(1, 1, true, 4);
+                else NLAM_LAUNCH_LING1(1, 1, false, 4);
+            } else NLAM_LAUNCH_LING(1, 1);
         }
     } else if (p->k % 64 == 0 && p->n % 64 == 0 && p->k <= kMaxWide && p->n <= kMaxWide) {
         // 64 x 64 weight blocks streamed through two LDS buffers (linear_bfw_kernel)
