@@ -2992,23 +2992,42 @@ __global__ void segment_sum_kernel(const float* in, long in_bstride, const int32
             // 8 gathered rows in flight per thread (segments of the sender view are ~40 edges long: a plain
             // dependent loop is latency-bound); fixed summation order
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // the addends that do not depend on the sum are requested first (behind the loop each was a round trip of its own)
+            f32x4 ex = {0.f, 0.f, 0.f, 0.f}, prev = {0.f, 0.f, 0.f, 0.f};
+            if (extra != nullptr) ex = *reinterpret_cast<const f32x4*>(extra + ((size_t)b * nseg + sgm) * width + 4 * c4);
+            if (accumulate) prev = *reinterpret_cast<const f32x4*>(o);   // every output row has exactly one writer
             int q = lo;
             for (; q + 8 <= hi_; q += 8) {
+                // all eight row ids first, then all eight rows: with id and row loads interleaved the wait for id u + 1 (vmcnt
+                // counts in order) also waited for row u -- sixteen dependent round trips per batch (seen in the ISA, round 6)
+                long rw[8];
                 f32x4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const long row = order != nullptr ? order[q + u] : q + u;
-                    v[u] = *reinterpret_cast<const f32x4*>(base + row * width + 4 * c4);
-                }
+                for (int u = 0; u < 8; ++u) rw[u] = order != nullptr ? order[q + u] : q + u;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + rw[u] * width + 4 * c4);
                 acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
             }
-            for (; q < hi_; ++q) {
-                const long row = order != nullptr ? order[q] : q;
-                acc += *reinterpret_cast<const f32x4*>(base + row * width + 4 * c4);
+            if (q < hi_) {
+                // the last 1 .. 7 rows: all in flight together (clamped index), added one by one in row order -- the sums of the
+                // row-by-row loop this replaces (mesh segments are ~9 rows long: that loop was 1 .. 7 dependent round trips)
+                long rw[8];
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 7; ++u) {
+                    const int qq = min(q + u, hi_ - 1);
+                    rw[u] = order != nullptr ? order[qq] : qq;
+                }
+#pragma unroll
+                for (int u = 0; u < 7; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + rw[u] * width + 4 * c4);
+                asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]));
+#pragma unroll
+                for (int u = 0; u < 7; ++u)
+                    if (q + u < hi_) acc += v[u];
             }
             acc = acc * sc;
-            if (extra != nullptr) acc += *reinterpret_cast<const f32x4*>(extra + ((size_t)b * nseg + sgm) * width + 4 * c4);
-            if (accumulate) acc += *reinterpret_cast<const f32x4*>(o);   // every output row has exactly one writer
+            if (extra != nullptr) acc += ex;
+            if (accumulate) acc += prev;
             *reinterpret_cast<f32x4*>(o) = acc;
         } else {
             for (int c = 0; c < 4 && 4 * c4 + c < width; ++c) {
@@ -3050,17 +3069,28 @@ __global__ __launch_bounds__(256) void segment_sum_split_kernel(const float* in,
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         int q = lo + part;
         for (; q + 7 * S < hi_; q += 8 * S) {
+            long rw[8];   // ids first, then rows (see segment_sum_kernel)
             f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long row = order != nullptr ? order[q + u * S] : q + u * S;
-                v[u] = *reinterpret_cast<const f32x4*>(base + row * width);
-            }
+            for (int u = 0; u < 8; ++u) rw[u] = order != nullptr ? order[q + u * S] : q + u * S;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + rw[u] * width);
             acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
-        for (; q < hi_; q += S) {
-            const long row = order != nullptr ? order[q] : q;
-            acc += *reinterpret_cast<const f32x4*>(base + row * width);
+        if (q < hi_) {   // the group's last 1 .. 7 rows: in flight together, added in row order (see segment_sum_kernel)
+            long rw[8];
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int qq = q + u * S < hi_ ? q + u * S : q;
+                rw[u] = order != nullptr ? order[qq] : qq;
+            }
+#pragma unroll
+            for (int u = 0; u < 7; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + rw[u] * width);
+            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]));
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                if (q + u * S < hi_) acc += v[u];
         }
 #pragma unroll
         for (int k = S / 2; k >= 1; k >>= 1) {   // fixed combination order: (0 + 2) + (1 + 3) for S = 4
@@ -5977,18 +6007,29 @@ __global__ void segment_sum_bf16_kernel(const unsigned short* in, long in_bstrid
         };
         int q = lo;
         for (; q + 8 <= hi_; q += 8) {
+            long rw[8];   // ids first, then rows (see segment_sum_kernel)
             u32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long row = order != nullptr ? order[q + u] : q + u;
-                v[u] = *reinterpret_cast<const u32x4*>(base + row * width);
-            }
+            for (int u = 0; u < 8; ++u) rw[u] = order != nullptr ? order[q + u] : q + u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const u32x4*>(base + rw[u] * width);
 #pragma unroll
             for (int u = 0; u < 8; ++u) add(v[u]);
         }
-        for (; q < hi_; ++q) {
-            const long row = order != nullptr ? order[q] : q;
-            add(*reinterpret_cast<const u32x4*>(base + row * width));
+        if (q < hi_) {   // the last 1 .. 7 rows: in flight together, added in row order (see segment_sum_kernel)
+            long rw[8];
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int qq = min(q + u, hi_ - 1);
+                rw[u] = order != nullptr ? order[qq] : qq;
+            }
+#pragma unroll
+            for (int u = 0; u < 7; ++u) v[u] = *reinterpret_cast<const u32x4*>(base + rw[u] * width);
+            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]));
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                if (q + u < hi_) add(v[u]);
         }
         const float sc = scale != nullptr ? scale[sgm] : 1.f;
         float* o = out + ((size_t)b * nseg + sgm) * width + 8 * c8;
