@@ -3138,7 +3138,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* parti
 // The partials of one step add up to hundreds of MB at cfg2 (up to 512 x 48 KB per edge MLP) and every launch is a
 // latency chain of dependent loads: a workgroup is 16 waves, wave w sums its slice of the parts with up to eight 16-byte
 // loads per lane in flight, the slices are combined through LDS in wave order (fixed summation order: deterministic).
-constexpr int kRedWaves = 16;
+#ifndef NLAM_RED_WAVES
+#define NLAM_RED_WAVES 4   // waves per reduce_jobs workgroup (16 up to round 6: A/B builds)
+#endif
+// (round 6: 4 waves instead of 16.  A 1 024-thread workgroup needs a CU with sixteen free wave slots -- beside chain kernels that
+// fill every CU it waits for one to drain, and with 32 parts each of its waves had two dependent loads; a 4-wave workgroup fits
+// into any free slot, has its eight parts in flight at once, and all 2 048 workgroups of a 512 x 512 pair are resident together.)
+constexpr int kRedWaves = NLAM_RED_WAVES;
 __global__ __launch_bounds__(kRedWaves * 64) void reduce_jobs_kernel(const nlam_reduce_jobs_t jobs) {
     __shared__ f32x4 red[kRedWaves][64];
     if ((int)blockIdx.y >= jobs.njobs) return;
@@ -3151,8 +3157,11 @@ __global__ __launch_bounds__(kRedWaves * 64) void reduce_jobs_kernel(const nlam_
     if (vec) {
         for (int base = blockIdx.x * 256; base < jb.n; base += gridDim.x * 256) {
             const int idx = base + 4 * lane;
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, prev = {0.f, 0.f, 0.f, 0.f};
+            float* o = jb.out + (jb.ncols > 0 ? (size_t)(idx / jb.ncols) * jb.ld + idx % jb.ncols : (size_t)idx);   // ncols % 4 == 0 here
             if (idx < jb.n) {
+                // the value accumulated onto is requested with the parts (behind the reduction it was a round trip of its own)
+                if (wave == 0 && jb.accumulate) prev = *reinterpret_cast<const f32x4*>(o);
                 const float* pp = jb.partials + idx;
                 int q = q0;
                 for (; q + 8 <= q1; q += 8) {
@@ -3161,7 +3170,15 @@ __global__ __launch_bounds__(kRedWaves * 64) void reduce_jobs_kernel(const nlam_
                     for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)(q + u) * jb.stride);
                     s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                 }
-                for (; q < q1; ++q) s += *reinterpret_cast<const f32x4*>(pp + (size_t)q * jb.stride);
+                if (q < q1) {   // the last 1 .. 7 parts: in flight together, added in part order
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) v[u] = *reinterpret_cast<const f32x4*>(pp + (size_t)min(q + u, q1 - 1) * jb.stride);
+                    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]));
+#pragma unroll
+                    for (int u = 0; u < 7; ++u)
+                        if (q + u < q1) s += v[u];
+                }
             }
             red[wave][lane] = s;
             __syncthreads();
@@ -3169,8 +3186,7 @@ __global__ __launch_bounds__(kRedWaves * 64) void reduce_jobs_kernel(const nlam_
                 f32x4 t = red[0][lane];
 #pragma unroll
                 for (int w = 1; w < kRedWaves; ++w) t += red[w][lane];
-                float* o = jb.out + (jb.ncols > 0 ? (size_t)(idx / jb.ncols) * jb.ld + idx % jb.ncols : (size_t)idx);   // ncols % 4 == 0 here
-                if (jb.accumulate) t += *reinterpret_cast<const f32x4*>(o);
+                if (jb.accumulate) t += prev;
                 *reinterpret_cast<f32x4*>(o) = t;
             }
             __syncthreads();
