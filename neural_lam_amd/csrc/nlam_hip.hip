@@ -2754,6 +2754,12 @@ __global__ __launch_bounds__(kWgradThreads) void wgrad_dma_kernel(const nlam_wgr
     int ix[2][NLAM_MAX_SRC];
     if (ch < total_chunks) {
         load_idx(ch, ix);
+        // ONE wait for the first chunk's gather indices, and the registers re-defined by the (empty) asm: with the index loads still
+        // pending in the compiler's books, every address computation in issue() got an s_waitcnt vmcnt(0) of its own -- behind an
+        // LDS-DMA it cannot count past, so each of the chunk's eight DMAs waited for the one before (seen in the ISA, round 6:
+        // eight dependent round trips at the head of a launch of ~14 chunks per workgroup).  The loop's chunks never had the problem.
+        static_assert(NLAM_MAX_SRC == 3, "the asm below lists ix[2][3]");
+        asm volatile("" : "+v"(ix[0][0]), "+v"(ix[0][1]), "+v"(ix[0][2]), "+v"(ix[1][0]), "+v"(ix[1][1]), "+v"(ix[1][2]));
         issue(ch, 0, ix);
     }
     if (ch + gridDim.x < total_chunks) load_idx(ch + gridDim.x, ix);
